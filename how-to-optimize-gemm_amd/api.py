@@ -1,0 +1,308 @@
+"""Python host side over the C ABI of libmmult_hip.so (include/mmult_hip.h).
+
+Mirrors the reference's operator interface for the hot path -- the names,
+argument order and semantics of `MY_MMult(m, n, k, a, lda, b, ldb, c, ldc)`
+(host flavour: armv7/test_MMult.c:8,76 / aarch64/test_MMult.cpp:17,113,
+C += A*B on host buffers; device flavour: cuda/test_MMult.cpp:13-14,102,
+C = A*B on device pointers, asynchronous) -- so parity tests read like the
+reference's own harness.  PyTorch appears only as a source of device memory,
+streams and torch.distributed; every FLOP is issued by the HIP library.
+
+There is NO CPU fallback: if the library or a gfx950 device is missing, calls
+raise MMultError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libmmult_hip.so")
+
+# status codes / kernel ids (include/mmult_hip.h)
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALLOC, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
+KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_256, KERNEL_NAIVE = 0, 1, 2, 3, 4
+KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
+           "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE}
+
+# every symbol include/mmult_hip.h declares (tests assert the .so exports them all)
+EXPORTS = [
+    "mmh_strerror", "mmh_last_error", "mmh_version", "mmh_device_count", "mmh_device_info",
+    "mmh_create", "mmh_destroy", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name",
+    "mmh_sgemm", "mmh_sgemm_host", "mmh_igemm_s8", "mmh_sgemm_rocblas", "mmh_shard_rows",
+    "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_probe_mfma_f32", "mmh_probe_hbm_copy",
+]
+
+
+class MMultError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: status {status} ({detail})")
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libmmult_hip.so (built in-tree by build.py).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MMultError(ERR_UNSUPPORTED, "load",
+                         f"{LIB_PATH} is missing -- run __graft_entry__.build(); "
+                         "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+    L.mmh_strerror.argtypes = [C.c_int]
+    L.mmh_strerror.restype = C.c_char_p
+    L.mmh_last_error.restype = C.c_char_p
+    L.mmh_version.restype = C.c_int
+    L.mmh_device_count.argtypes = [ip]
+    L.mmh_device_info.argtypes = [C.c_int, C.c_char_p, ip, ip]
+    L.mmh_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.mmh_destroy.argtypes = [vp]
+    L.mmh_set_kernel.argtypes = [vp, C.c_int]
+    L.mmh_get_kernel.argtypes = [vp, ip]
+    L.mmh_kernel_name.argtypes = [C.c_int]
+    L.mmh_kernel_name.restype = C.c_char_p
+    gemm = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]
+    L.mmh_sgemm.argtypes = gemm + [C.c_int, vp]
+    L.mmh_sgemm_host.argtypes = gemm + [C.c_int]
+    L.mmh_igemm_s8.argtypes = gemm + [C.c_int, vp]
+    L.mmh_sgemm_rocblas.argtypes = gemm + [vp]
+    L.mmh_shard_rows.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
+    L.mmh_sgemm_sharded.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int,
+                                    vp, C.c_int, C.c_int, fp]
+    L.mmh_time_sgemm.argtypes = gemm + [C.c_int, C.c_int, vp, fp]
+    L.mmh_probe_mfma_f32.argtypes = [vp, fp]
+    L.mmh_probe_hbm_copy.argtypes = [vp, C.c_size_t, fp]
+    _lib = L
+    return L
+
+
+def _check(status: int, where: str) -> None:
+    if status != OK:
+        L = lib()
+        detail = L.mmh_strerror(status).decode()
+        last = L.mmh_last_error().decode()
+        raise MMultError(status, where, f"{detail}; {last}" if last else detail)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(lib().mmh_device_count(C.byref(n)), "mmh_device_count")
+    return n.value
+
+
+def shard_rows(m: int, nranks: int, rank: int) -> tuple[int, int]:
+    """(row0, rows) of the C/A row panel owned by `rank` (pure host arithmetic)."""
+    r0, nr = C.c_int(0), C.c_int(0)
+    _check(lib().mmh_shard_rows(m, nranks, rank, C.byref(r0), C.byref(nr)), "mmh_shard_rows")
+    return r0.value, nr.value
+
+
+def kernel_name(kernel: int) -> Optional[str]:
+    s = lib().mmh_kernel_name(kernel)
+    return s.decode() if s else None
+
+
+def _kernel_id(kernel) -> int:
+    if isinstance(kernel, str):
+        return KERNELS[kernel]
+    return int(kernel)
+
+
+def _np_ptr(x: np.ndarray) -> int:
+    return x.ctypes.data
+
+
+class MMult:
+    """One handle = one device + the selected kernel variant (the reference's
+    cublasHandle_t lifetime, cuda/test_MMult.cpp:43-44,142)."""
+
+    def __init__(self, device: int = 0, kernel="mfma"):
+        self._h = C.c_void_p(None)
+        _check(lib().mmh_create(C.byref(self._h), device), "mmh_create")
+        self.device = device
+        self.set_kernel(kernel)
+
+    def close(self) -> None:
+        if self._h:
+            lib().mmh_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- configuration ------------------------------------------------------
+    def set_kernel(self, kernel) -> None:
+        _check(lib().mmh_set_kernel(self._h, _kernel_id(kernel)), "mmh_set_kernel")
+
+    def get_kernel(self) -> int:
+        k = C.c_int(0)
+        _check(lib().mmh_get_kernel(self._h, C.byref(k)), "mmh_get_kernel")
+        return k.value
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cu, mhz = C.c_int(0), C.c_int(0)
+        _check(lib().mmh_device_info(self.device, name, C.byref(cu), C.byref(mhz)), "mmh_device_info")
+        return {"name": name.value.decode(), "cu_count": cu.value, "clock_mhz": mhz.value}
+
+    # -- the hot path, raw-pointer form (device flavour of MY_MMult) ---------
+    def sgemm(self, m, n, k, dA: int, lda, dB: int, ldb, dC: int, ldc, accumulate=False,
+              stream: int = 0) -> None:
+        _check(lib().mmh_sgemm(self._h, m, n, k, dA, lda, dB, ldb, dC, ldc, int(bool(accumulate)),
+                               stream), "mmh_sgemm")
+
+    def MY_MMult_device(self, m, n, k, d_A: int, lda, d_B: int, ldb, d_C: int, ldc, stream: int = 0):
+        """cuda/test_MMult.cpp:102 -- MY_MMult(handle, m, n, k, d_A, k, d_B, n, d_C, n):
+        C = A*B on device pointers, asynchronous."""
+        self.sgemm(m, n, k, d_A, lda, d_B, ldb, d_C, ldc, False, stream)
+
+    # -- host flavour ----------------------------------------------------------
+    def MY_MMult(self, m, n, k, a: np.ndarray, lda, b: np.ndarray, ldb, c: np.ndarray, ldc) -> None:
+        """armv7/MMult0.c:9-24 semantics on host buffers: C = A*B + C (the caller
+        pre-zeroes C, armv7/test_MMult.c:57,71).  a, b, c are flat or 2-D fp32
+        numpy buffers addressed row-major with the given leading dimensions."""
+        for x in (a, b, c):
+            if x.dtype != np.float32 or not x.flags["C_CONTIGUOUS"]:
+                raise MMultError(ERR_INVALID_ARG, "MY_MMult", "need C-contiguous float32 buffers")
+        if k > 0 and m > 0 and (a.size < (m - 1) * lda + k or b.size < (k - 1) * ldb + n):
+            raise MMultError(ERR_INVALID_ARG, "MY_MMult", "input buffer smaller than (rows-1)*ld+cols")
+        if m > 0 and n > 0 and c.size < (m - 1) * ldc + n:
+            raise MMultError(ERR_INVALID_ARG, "MY_MMult", "C buffer smaller than (m-1)*ldc+n")
+        _check(lib().mmh_sgemm_host(self._h, m, n, k, _np_ptr(a), lda, _np_ptr(b), ldb, _np_ptr(c),
+                                    ldc, 1), "mmh_sgemm_host")
+
+    def sgemm_host(self, a: np.ndarray, b: np.ndarray, c: Optional[np.ndarray] = None,
+                   accumulate: bool = False) -> np.ndarray:
+        m, k = a.shape
+        k2, n = b.shape
+        if k != k2:
+            raise MMultError(ERR_INVALID_ARG, "sgemm_host", "inner dimensions differ")
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        if c is None:
+            c = np.zeros((m, n), dtype=np.float32)
+        _check(lib().mmh_sgemm_host(self._h, m, n, k, _np_ptr(a), max(k, 1), _np_ptr(b), max(n, 1),
+                                    _np_ptr(c), max(n, 1), int(accumulate)), "mmh_sgemm_host")
+        return c
+
+    # -- torch device-tensor glue (device memory + streams only) -------------
+    @staticmethod
+    def _tensor_args(t, rows, cols, what):
+        if not t.is_cuda:
+            raise MMultError(ERR_INVALID_ARG, what, "tensor is not on a GPU (no CPU fallback)")
+        if t.dim() != 2 or t.shape[0] != rows or t.shape[1] != cols or (cols > 1 and t.stride(1) != 1):
+            raise MMultError(ERR_INVALID_ARG, what, f"need a ({rows},{cols}) row-major 2-D tensor")
+        ld = t.stride(0) if rows > 1 else max(cols, 1)
+        return t.data_ptr(), max(ld, cols, 1)
+
+    def matmul(self, a, b, out=None, accumulate: bool = False):
+        """C = A @ B (+ C) for fp32 CUDA tensors, on torch's current stream."""
+        import torch
+        if a.dtype != torch.float32 or b.dtype != torch.float32:
+            raise MMultError(ERR_INVALID_ARG, "matmul", "fp32 only")
+        m, k = a.shape
+        k2, n = b.shape
+        if k != k2:
+            raise MMultError(ERR_INVALID_ARG, "matmul", "inner dimensions differ")
+        if out is None:
+            if accumulate:
+                raise MMultError(ERR_INVALID_ARG, "matmul", "accumulate needs out=")
+            out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        pa, lda = self._tensor_args(a, m, k, "matmul(A)")
+        pb, ldb = self._tensor_args(b, k, n, "matmul(B)")
+        pc, ldc = self._tensor_args(out, m, n, "matmul(C)")
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        self.sgemm(m, n, k, pa, lda, pb, ldb, pc, ldc, accumulate, stream)
+        return out
+
+    def igemm_s8(self, a, b, out=None, accumulate: bool = False):
+        """int8 x int8 -> int32 for CUDA tensors (inputs expected in [-127,127])."""
+        import torch
+        if a.dtype != torch.int8 or b.dtype != torch.int8:
+            raise MMultError(ERR_INVALID_ARG, "igemm_s8", "int8 inputs only")
+        m, k = a.shape
+        k2, n = b.shape
+        if k != k2:
+            raise MMultError(ERR_INVALID_ARG, "igemm_s8", "inner dimensions differ")
+        if out is None:
+            if accumulate:
+                raise MMultError(ERR_INVALID_ARG, "igemm_s8", "accumulate needs out=")
+            out = torch.empty((m, n), dtype=torch.int32, device=a.device)
+        pa, lda = self._tensor_args(a, m, k, "igemm_s8(A)")
+        pb, ldb = self._tensor_args(b, k, n, "igemm_s8(B)")
+        pc, ldc = self._tensor_args(out, m, n, "igemm_s8(C)")
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        _check(lib().mmh_igemm_s8(self._h, m, n, k, pa, lda, pb, ldb, pc, ldc, int(accumulate), stream),
+               "mmh_igemm_s8")
+        return out
+
+    def matmul_rocblas(self, a, b, out=None):
+        """Vendor comparator (cuda/MMult_cuBLAS_1.cpp:11-19)."""
+        import torch
+        m, k = a.shape
+        _, n = b.shape
+        if out is None:
+            out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        pa, lda = self._tensor_args(a, m, k, "rocblas(A)")
+        pb, ldb = self._tensor_args(b, k, n, "rocblas(B)")
+        pc, ldc = self._tensor_args(out, m, n, "rocblas(C)")
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        _check(lib().mmh_sgemm_rocblas(self._h, m, n, k, pa, lda, pb, ldb, pc, ldc, stream),
+               "mmh_sgemm_rocblas")
+        return out
+
+    # -- measurement -------------------------------------------------------------
+    def time_sgemm(self, m, n, k, dA, lda, dB, ldb, dC, ldc, warmup=1, reps=20, stream: int = 0) -> float:
+        """Mean ms per call: one hipEvent pair around `reps` back-to-back launches on
+        `stream` (the reference's convention, cuda/test_MMult.cpp:98-114)."""
+        ms = C.c_float(0)
+        _check(lib().mmh_time_sgemm(self._h, m, n, k, dA, lda, dB, ldb, dC, ldc, warmup, reps, stream,
+                                    C.byref(ms)), "mmh_time_sgemm")
+        return ms.value
+
+    def probe_mfma_f32(self) -> float:
+        v = C.c_float(0)
+        _check(lib().mmh_probe_mfma_f32(self._h, C.byref(v)), "mmh_probe_mfma_f32")
+        return v.value
+
+    def probe_hbm_copy(self, nbytes: int = 1 << 30) -> float:
+        v = C.c_float(0)
+        _check(lib().mmh_probe_hbm_copy(self._h, nbytes, C.byref(v)), "mmh_probe_hbm_copy")
+        return v.value
+
+
+def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
+    """Single-process multi-device row-panel shard (mmh_sgemm_sharded).
+    Returns (C, {"h2d","bcast","gemm","d2h"} ms)."""
+    m, k = a.shape
+    _, n = b.shape
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    c = np.zeros((m, n), dtype=np.float32)
+    t = (C.c_float * 4)()
+    _check(lib().mmh_sgemm_sharded(ngpus, m, n, k, _np_ptr(a), max(k, 1), _np_ptr(b), max(n, 1),
+                                   _np_ptr(c), max(n, 1), _kernel_id(kernel), t), "mmh_sgemm_sharded")
+    return c, dict(zip(("h2d", "bcast", "gemm", "d2h"), list(t)))
+
+
+__all__ = ["MMult", "MMultError", "lib", "device_count", "shard_rows", "kernel_name", "sgemm_sharded",
+           "KERNELS", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE",
+           "EXPORTS", "LIB_PATH", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
+           "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

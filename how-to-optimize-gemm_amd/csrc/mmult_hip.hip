@@ -1,0 +1,434 @@
+// mmult_hip.hip -- libmmult_hip.so: the C ABI declared in include/mmult_hip.h
+// over the hand-written gfx950 kernels in this directory.
+//
+// This file is the "thin C-ABI shim" of BASELINE.json's north star: argument
+// validation, kernel selection (the reference's `NEW := MMult_xxx` makefile
+// switch, cuda/makefile:1-3, made a run-time choice), launch, and the
+// host-pointer flavour's staging.  No torch, no CPU fallback: if no gfx950
+// device is visible every compute entry point returns MMH_ERR_NO_DEVICE /
+// MMH_ERR_HIP.
+#include "../../include/mmult_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "igemm_s8.hpp"
+#include "probes.hpp"
+#include "sgemm_mfma.hpp"
+#include "sgemm_valu.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int hip_fail(hipError_t e, const char *what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return MMH_ERR_HIP;
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return MMH_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
+      g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+      return MMH_ERR_ALLOC;
+    }
+    bytes = need;
+    return MMH_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+}  // namespace
+
+struct mmh_context {
+  int device = 0;
+  int kernel = MMH_KERNEL_MFMA;
+  int cu_count = 0;
+  DevBuf a, b, c;          // staging for the host-pointer flavour
+  void *rocblas = nullptr; // rocblas_handle, created on first use
+};
+
+namespace {
+
+constexpr size_t lds_bytes(int BM, int BN) {
+  return 2ull * (size_t)mmh::BK * (BM + BN) * sizeof(float);
+}
+
+template <typename K>
+int allow_big_lds(K kernel, size_t bytes) {
+  // > 64 KiB of dynamic LDS must be opted into (per kernel symbol, per device).
+  if (bytes <= 64 * 1024) return MMH_OK;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return MMH_OK;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int BM, int BN>
+int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, int ldb,
+                float *C, int ldc, int acc, hipStream_t s) {
+  const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
+  const bool fast = (m % BM == 0) && (n % BN == 0) && (k % mmh::BK == 0) && (lda % 4 == 0) &&
+                    (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(A) && aligned16(B) &&
+                    aligned16(C);
+  constexpr int threads = BM * BN / (64 * 64) * 64;
+  constexpr size_t lds = lds_bytes(BM, BN);
+  dim3 grid((unsigned)(nbm * nbn)), block(threads);
+  if (fast) {
+    auto kern = mmh::sgemm_mfma_kernel<BM, BN, false>;
+    const int ok = allow_big_lds(kern, lds);
+    if (ok != MMH_OK) return ok;
+    hipLaunchKernelGGL(kern, grid, block, lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm, nbn);
+  } else {
+    auto kern = mmh::sgemm_mfma_kernel<BM, BN, true>;
+    const int ok = allow_big_lds(kern, lds);
+    if (ok != MMH_OK) return ok;
+    hipLaunchKernelGGL(kern, grid, block, lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm, nbn);
+  }
+  HIP_TRY(hipGetLastError());
+  return MMH_OK;
+}
+
+int launch_valu(int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
+                int ldc, int acc, hipStream_t s) {
+  constexpr int BM = 128, BN = 128;
+  const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
+  const bool fast = (m % BM == 0) && (n % BN == 0) && (k % mmh::BK == 0) && (lda % 4 == 0) &&
+                    (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(A) && aligned16(B) &&
+                    aligned16(C);
+  constexpr size_t lds = lds_bytes(BM, BN);
+  dim3 grid((unsigned)(nbm * nbn)), block(256);
+  if (fast)
+    hipLaunchKernelGGL(mmh::sgemm_valu_kernel<false>, grid, block, lds, s, m, n, k, A, lda, B, ldb,
+                       C, ldc, acc, nbm, nbn);
+  else
+    hipLaunchKernelGGL(mmh::sgemm_valu_kernel<true>, grid, block, lds, s, m, n, k, A, lda, B, ldb,
+                       C, ldc, acc, nbm, nbn);
+  HIP_TRY(hipGetLastError());
+  return MMH_OK;
+}
+
+int launch_naive(int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
+                 int ldc, int acc, hipStream_t s) {
+  dim3 grid((unsigned)((n + 63) / 64), (unsigned)((m + 3) / 4)), block(256);
+  hipLaunchKernelGGL(mmh::sgemm_naive_kernel, grid, block, 0, s, m, n, k, A, lda, B, ldb, C, ldc,
+                     acc);
+  HIP_TRY(hipGetLastError());
+  return MMH_OK;
+}
+
+int check_gemm_args(int m, int n, int k, const void *A, int lda, const void *B, int ldb,
+                    const void *C, int ldc) {
+  if (m < 0 || n < 0 || k < 0) return MMH_ERR_INVALID_ARG;
+  if (m == 0 || n == 0) return MMH_OK;
+  if (!C || ldc < n) return MMH_ERR_INVALID_ARG;
+  if (k > 0 && (!A || !B || lda < k || ldb < n)) return MMH_ERR_INVALID_ARG;
+  return MMH_OK;
+}
+
+int sgemm_on(int kernel, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
+             float *dC, int ldc, int accumulate, hipStream_t s) {
+  int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
+  if (rc != MMH_OK) {
+    g_last_error = "invalid argument";
+    return rc;
+  }
+  if (m == 0 || n == 0) return MMH_OK;
+  if (k == 0) {
+    // empty contraction: C = 0 (overwrite) or C unchanged (accumulate)
+    if (!accumulate)
+      HIP_TRY(hipMemset2DAsync(dC, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float),
+                               (size_t)m, s));
+    return MMH_OK;
+  }
+  const int acc = accumulate ? 1 : 0;
+  switch (kernel) {
+    case MMH_KERNEL_VALU:
+      return launch_valu(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_NAIVE:
+      return launch_naive(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_MFMA_256:
+      return launch_mfma<256, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_AUTO:
+    case MMH_KERNEL_MFMA:
+      return launch_mfma<128, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    default:
+      g_last_error = "unknown kernel variant";
+      return MMH_ERR_INVALID_ARG;
+  }
+}
+
+bool is_gfx950(int device) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+const char *mmh_strerror(int status) {
+  switch (status) {
+    case MMH_OK: return "success";
+    case MMH_ERR_INVALID_ARG: return "invalid argument";
+    case MMH_ERR_HIP: return "HIP runtime error";
+    case MMH_ERR_NO_DEVICE: return "no gfx950 device";
+    case MMH_ERR_UNSUPPORTED: return "unsupported in this build";
+    case MMH_ERR_ALLOC: return "allocation failed";
+    case MMH_ERR_COMM: return "RCCL error";
+    default: return "unknown status";
+  }
+}
+
+const char *mmh_last_error(void) { return g_last_error.c_str(); }
+
+int mmh_version(void) { return 100; }
+
+int mmh_device_count(int *count) {
+  if (!count) return MMH_ERR_INVALID_ARG;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    (void)hipGetLastError();
+    return MMH_OK;  // "no devices" is an answer, not a failure
+  }
+  *count = c;
+  return MMH_OK;
+}
+
+int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (name) snprintf(name, 256, "%s (%s)", prop.name, prop.gcnArchName);
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+  return MMH_OK;
+}
+
+int mmh_create(mmh_handle_t *handle, int device) {
+  if (!handle) return MMH_ERR_INVALID_ARG;
+  *handle = nullptr;
+  int count = 0;
+  mmh_device_count(&count);
+  if (count <= 0 || device < 0 || device >= count) {
+    g_last_error = "no such HIP device";
+    return MMH_ERR_NO_DEVICE;
+  }
+  if (!is_gfx950(device)) {
+    g_last_error = "device is not gfx950 (this library carries gfx950 code objects only)";
+    return MMH_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  mmh_context *ctx = new (std::nothrow) mmh_context;
+  if (!ctx) return MMH_ERR_ALLOC;
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+  *handle = ctx;
+  return MMH_OK;
+}
+
+int mmh_destroy(mmh_handle_t h) {
+  if (!h) return MMH_OK;
+  (void)hipSetDevice(h->device);
+  h->a.release();
+  h->b.release();
+  h->c.release();
+  mmh::rocblas_release(h->rocblas);
+  delete h;
+  return MMH_OK;
+}
+
+int mmh_set_kernel(mmh_handle_t h, int kernel) {
+  if (!h || !mmh_kernel_name(kernel)) return MMH_ERR_INVALID_ARG;
+  h->kernel = kernel;
+  return MMH_OK;
+}
+
+int mmh_get_kernel(mmh_handle_t h, int *kernel) {
+  if (!h || !kernel) return MMH_ERR_INVALID_ARG;
+  *kernel = h->kernel;
+  return MMH_OK;
+}
+
+const char *mmh_kernel_name(int kernel) {
+  switch (kernel) {
+    case MMH_KERNEL_AUTO: return "MMult_hip_auto";
+    case MMH_KERNEL_VALU: return "MMult_hip_valu";
+    case MMH_KERNEL_MFMA: return "MMult_hip_mfma";
+    case MMH_KERNEL_MFMA_256: return "MMult_hip_mfma256";
+    case MMH_KERNEL_NAIVE: return "MMult_hip_naive";
+    default: return nullptr;
+  }
+}
+
+int mmh_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, const float *dB,
+              int ldb, float *dC, int ldc, int accumulate, void *stream) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  return sgemm_on(h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate,
+                  static_cast<hipStream_t>(stream));
+}
+
+int mmh_sgemm_host(mmh_handle_t h, int m, int n, int k, const float *A, int lda, const float *B,
+                   int ldb, float *C, int ldc, int accumulate) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  int rc = check_gemm_args(m, n, k, A, lda, B, ldb, C, ldc);
+  if (rc != MMH_OK) return rc;
+  if (m == 0 || n == 0) return MMH_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  // Device images are dense (lda=k, ldb=n, ldc=n) whatever the host strides.
+  const size_t ab = (size_t)m * k * sizeof(float), bb = (size_t)k * n * sizeof(float),
+               cb = (size_t)m * n * sizeof(float);
+  if ((rc = h->a.reserve(ab ? ab : 16)) != MMH_OK) return rc;
+  if ((rc = h->b.reserve(bb ? bb : 16)) != MMH_OK) return rc;
+  if ((rc = h->c.reserve(cb)) != MMH_OK) return rc;
+  float *dA = static_cast<float *>(h->a.p), *dB = static_cast<float *>(h->b.p),
+        *dC = static_cast<float *>(h->c.p);
+  if (k > 0) {
+    HIP_TRY(hipMemcpy2D(dA, (size_t)k * 4, A, (size_t)lda * 4, (size_t)k * 4, m,
+                        hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D(dB, (size_t)n * 4, B, (size_t)ldb * 4, (size_t)n * 4, k,
+                        hipMemcpyHostToDevice));
+  }
+  if (accumulate)
+    HIP_TRY(hipMemcpy2D(dC, (size_t)n * 4, C, (size_t)ldc * 4, (size_t)n * 4, m,
+                        hipMemcpyHostToDevice));
+  rc = sgemm_on(h->kernel, m, n, k, dA, k, dB, n, dC, n, accumulate, nullptr);
+  if (rc != MMH_OK) return rc;
+  HIP_TRY(hipMemcpy2D(C, (size_t)ldc * 4, dC, (size_t)n * 4, (size_t)n * 4, m,
+                      hipMemcpyDeviceToHost));
+  return MMH_OK;
+}
+
+int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda, const int8_t *dB,
+                 int ldb, int32_t *dC, int ldc, int accumulate, void *stream) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
+  if (rc != MMH_OK) return rc;
+  if (m == 0 || n == 0) return MMH_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k == 0) {
+    if (!accumulate)
+      HIP_TRY(hipMemset2DAsync(dC, (size_t)ldc * 4, 0, (size_t)n * 4, (size_t)m, s));
+    return MMH_OK;
+  }
+  mmh::launch_igemm_s8(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s);
+  HIP_TRY(hipGetLastError());
+  return MMH_OK;
+}
+
+int mmh_sgemm_rocblas(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
+                      const float *dB, int ldb, float *dC, int ldc, void *stream) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
+  if (rc != MMH_OK) return rc;
+  if (m == 0 || n == 0 || k == 0) return sgemm_on(MMH_KERNEL_MFMA, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, static_cast<hipStream_t>(stream));
+  HIP_TRY(hipSetDevice(h->device));
+  return mmh::rocblas_sgemm_rowmajor(&h->rocblas, m, n, k, dA, lda, dB, ldb, dC, ldc, stream,
+                                     &g_last_error);
+}
+
+int mmh_shard_rows(int m, int nranks, int rank, int *row0, int *rows) {
+  if (m < 0 || nranks <= 0 || rank < 0 || rank >= nranks || !row0 || !rows)
+    return MMH_ERR_INVALID_ARG;
+  // Whole 128-row tiles first, dealt as evenly as possible from rank 0 up;
+  // the ragged tail (m % 128 rows) rides with the last rank that has tiles
+  // (or rank 0 if there are none), so every boundary is tile-aligned.
+  const int tiles = m / 128, tail = m % 128;
+  const int base = tiles / nranks, extra = tiles % nranks;
+  const int my_tiles = base + (rank < extra ? 1 : 0);
+  const int first_tile = rank * base + (rank < extra ? rank : extra);
+  int r0 = first_tile * 128, nr = my_tiles * 128;
+  int last_with_tiles = tiles == 0 ? 0 : (tiles >= nranks ? nranks - 1 : tiles - 1);
+  if (rank == last_with_tiles) nr += tail;
+  if (rank > last_with_tiles) r0 = m;  // empty panels sit at the end
+  *row0 = r0;
+  *rows = nr;
+  return MMH_OK;
+}
+
+int mmh_sgemm_sharded(int ngpus, int m, int n, int k, const float *A, int lda, const float *B,
+                      int ldb, float *C, int ldc, int kernel, float *timings_ms) {
+  int rc = check_gemm_args(m, n, k, A, lda, B, ldb, C, ldc);
+  if (rc != MMH_OK) return rc;
+  if (ngpus <= 0 || !mmh_kernel_name(kernel)) return MMH_ERR_INVALID_ARG;
+  int count = 0;
+  mmh_device_count(&count);
+  if (count < ngpus) {
+    g_last_error = "fewer visible devices than ngpus";
+    return MMH_ERR_NO_DEVICE;
+  }
+  return mmh::sgemm_sharded_impl(ngpus, m, n, k, A, lda, B, ldb, C, ldc, kernel, timings_ms,
+                                 &g_last_error,
+                                 [](int kern, int mm, int nn, int kk, const float *a, int la,
+                                    const float *b, int lb, float *c, int lc, hipStream_t s) {
+                                   return sgemm_on(kern, mm, nn, kk, a, la, b, lb, c, lc, 0, s);
+                                 });
+}
+
+int mmh_time_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, const float *dB,
+                   int ldb, float *dC, int ldc, int warmup, int reps, void *stream,
+                   float *ms_per_call) {
+  if (!h || reps <= 0 || warmup < 0 || !ms_per_call) return MMH_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc;
+  for (int i = 0; i < warmup; ++i)
+    if ((rc = sgemm_on(h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s)) != MMH_OK) return rc;
+  hipEvent_t t0, t1;
+  HIP_TRY(hipEventCreate(&t0));
+  HIP_TRY(hipEventCreate(&t1));
+  HIP_TRY(hipEventRecord(t0, s));
+  for (int i = 0; i < reps; ++i)
+    if ((rc = sgemm_on(h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s)) != MMH_OK) return rc;
+  HIP_TRY(hipEventRecord(t1, s));
+  HIP_TRY(hipEventSynchronize(t1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  *ms_per_call = ms / reps;
+  return MMH_OK;
+}
+
+int mmh_probe_mfma_f32(mmh_handle_t h, float *tflops) {
+  if (!h || !tflops) return MMH_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  return mmh::probe_mfma_f32(h->cu_count, tflops, &g_last_error);
+}
+
+int mmh_probe_hbm_copy(mmh_handle_t h, size_t bytes, float *gbps) {
+  if (!h || !gbps || bytes < (1u << 20)) return MMH_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  return mmh::probe_hbm_copy(bytes, gbps, &g_last_error);
+}
+
+}  // extern "C"

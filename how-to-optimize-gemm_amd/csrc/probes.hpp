@@ -1,0 +1,341 @@
+// probes.hpp -- peak probes and the two vendor-library bridges (rocBLAS
+// comparator, RCCL broadcast for the single-process row-panel shard).
+//
+// Probes: the reference measures its ceilings before quoting percentages
+// (aarch64/gflops_benchmark/main.c:19-25 -- an FMLA-only loop;
+// vulkan/benchmark/gmem_bandwidth.cpp:8-48 -- a copy kernel).  Same idea on
+// gfx950: an MFMA-only loop (v_mfma_f32_16x16x4_f32, 8 independent
+// accumulators per wave, no memory traffic) and a float4 stream copy.
+//
+// rocBLAS and RCCL are loaded with dlopen on first use so that the core
+// library has no link-time dependency on either.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/mmult_hip.h"
+#include "sgemm_tile.hpp"
+
+namespace mmh {
+
+#define MMH_HIP_TRY(expr, err)                                         \
+  do {                                                                 \
+    hipError_t e_ = (expr);                                            \
+    if (e_ != hipSuccess) {                                            \
+      if (err) *(err) = std::string(#expr) + ": " + hipGetErrorString(e_); \
+      return MMH_ERR_HIP;                                              \
+    }                                                                  \
+  } while (0)
+
+// ------------------------------------------------------------- MFMA probe --
+__global__ void __launch_bounds__(256) probe_mfma_kernel(float *out, int iters, float seed) {
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{seed, seed, seed, seed};
+  const float a = seed + threadIdx.x * 1e-9f, b = seed - threadIdx.x * 1e-9f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+  }
+  f32x4 s = acc[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) s += acc[i];
+  if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];  // keep the chain live
+}
+
+inline int probe_mfma_f32(int cu_count, float *tflops, std::string *err) {
+  if (cu_count <= 0) cu_count = 256;
+  float *d = nullptr;
+  MMH_HIP_TRY(hipMalloc(&d, 64), err);
+  const int iters = 20000, blocks = cu_count * 2;
+  hipEvent_t t0, t1;
+  MMH_HIP_TRY(hipEventCreate(&t0), err);
+  MMH_HIP_TRY(hipEventCreate(&t1), err);
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, 0, d, 2000, 0.001f);
+  MMH_HIP_TRY(hipEventRecord(t0, 0), err);
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, 0, d, iters, 0.001f);
+  MMH_HIP_TRY(hipEventRecord(t1, 0), err);
+  MMH_HIP_TRY(hipEventSynchronize(t1), err);
+  float ms = 0.f;
+  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
+  const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
+  *tflops = (float)(flops / (ms * 1e-3) / 1e12);
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  (void)hipFree(d);
+  return MMH_OK;
+}
+
+// -------------------------------------------------------------- HBM probe --
+__global__ void __launch_bounds__(256) probe_copy_kernel(const f32x4 *__restrict__ src,
+                                                         f32x4 *__restrict__ dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+
+inline int probe_hbm_copy(size_t bytes, float *gbps, std::string *err) {
+  const size_t n = bytes / sizeof(f32x4);
+  f32x4 *src = nullptr, *dst = nullptr;
+  MMH_HIP_TRY(hipMalloc(&src, n * sizeof(f32x4)), err);
+  if (hipMalloc(&dst, n * sizeof(f32x4)) != hipSuccess) {
+    (void)hipFree(src);
+    if (err) *err = "hipMalloc(dst) failed";
+    return MMH_ERR_ALLOC;
+  }
+  MMH_HIP_TRY(hipMemset(src, 1, n * sizeof(f32x4)), err);
+  hipEvent_t t0, t1;
+  MMH_HIP_TRY(hipEventCreate(&t0), err);
+  MMH_HIP_TRY(hipEventCreate(&t1), err);
+  const int blocks = 256 * 8, reps = 10;
+  hipLaunchKernelGGL(probe_copy_kernel, dim3(blocks), dim3(256), 0, 0, src, dst, n);
+  MMH_HIP_TRY(hipEventRecord(t0, 0), err);
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(probe_copy_kernel, dim3(blocks), dim3(256), 0, 0, src, dst, n);
+  MMH_HIP_TRY(hipEventRecord(t1, 0), err);
+  MMH_HIP_TRY(hipEventSynchronize(t1), err);
+  float ms = 0.f;
+  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
+  *gbps = (float)(2.0 * n * sizeof(f32x4) * reps / (ms * 1e-3) / 1e9);
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  return MMH_OK;
+}
+
+// ---------------------------------------------------------------- rocBLAS --
+// Comparator only (the reference's OLD := MMult_cuBLAS_1 line,
+// cuda/makefile:1; cuda/MMult_cuBLAS_1.cpp:17-18): a column-major library
+// computes C^T = B^T * A^T, which is row-major C = A * B.
+struct RocblasApi {
+  void *lib = nullptr;
+  int (*create)(void **) = nullptr;
+  int (*destroy)(void *) = nullptr;
+  int (*set_stream)(void *, hipStream_t) = nullptr;
+  int (*sgemm)(void *, int, int, int, int, int, const float *, const float *, int, const float *,
+               int, const float *, float *, int) = nullptr;
+  bool ok = false;
+};
+
+inline RocblasApi &rocblas_api() {
+  static RocblasApi api = [] {
+    RocblasApi a;
+    a.lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (!a.lib) a.lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (!a.lib) return a;
+    a.create = reinterpret_cast<decltype(a.create)>(dlsym(a.lib, "rocblas_create_handle"));
+    a.destroy = reinterpret_cast<decltype(a.destroy)>(dlsym(a.lib, "rocblas_destroy_handle"));
+    a.set_stream = reinterpret_cast<decltype(a.set_stream)>(dlsym(a.lib, "rocblas_set_stream"));
+    a.sgemm = reinterpret_cast<decltype(a.sgemm)>(dlsym(a.lib, "rocblas_sgemm"));
+    a.ok = a.create && a.destroy && a.set_stream && a.sgemm;
+    return a;
+  }();
+  return api;
+}
+
+inline void rocblas_release(void *&handle) {
+  if (handle && rocblas_api().ok) rocblas_api().destroy(handle);
+  handle = nullptr;
+}
+
+inline int rocblas_sgemm_rowmajor(void **handle, int m, int n, int k, const float *dA, int lda,
+                                  const float *dB, int ldb, float *dC, int ldc, void *stream,
+                                  std::string *err) {
+  RocblasApi &api = rocblas_api();
+  if (!api.ok) {
+    if (err) *err = "librocblas.so could not be loaded";
+    return MMH_ERR_UNSUPPORTED;
+  }
+  if (!*handle && api.create(handle) != 0) {
+    if (err) *err = "rocblas_create_handle failed";
+    return MMH_ERR_UNSUPPORTED;
+  }
+  api.set_stream(*handle, static_cast<hipStream_t>(stream));
+  const float one = 1.0f, zero = 0.0f;
+  constexpr int op_none = 111;  // rocblas_operation_none
+  const int st = api.sgemm(*handle, op_none, op_none, n, m, k, &one, dB, ldb, dA, lda, &zero, dC, ldc);
+  if (st != 0) {
+    if (err) *err = "rocblas_sgemm returned status " + std::to_string(st);
+    return MMH_ERR_HIP;
+  }
+  return MMH_OK;
+}
+
+// ------------------------------------------------------------------- RCCL --
+struct RcclApi {
+  void *lib = nullptr;
+  int (*comm_init_all)(void **, int, const int *) = nullptr;
+  int (*comm_destroy)(void *) = nullptr;
+  int (*group_start)() = nullptr;
+  int (*group_end)() = nullptr;
+  int (*broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  bool ok = false;
+};
+
+inline RcclApi &rccl_api() {
+  static RcclApi api = [] {
+    RcclApi a;
+    a.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!a.lib) a.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!a.lib) return a;
+    a.comm_init_all = reinterpret_cast<decltype(a.comm_init_all)>(dlsym(a.lib, "ncclCommInitAll"));
+    a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(a.lib, "ncclCommDestroy"));
+    a.group_start = reinterpret_cast<decltype(a.group_start)>(dlsym(a.lib, "ncclGroupStart"));
+    a.group_end = reinterpret_cast<decltype(a.group_end)>(dlsym(a.lib, "ncclGroupEnd"));
+    a.broadcast = reinterpret_cast<decltype(a.broadcast)>(dlsym(a.lib, "ncclBroadcast"));
+    a.ok = a.comm_init_all && a.comm_destroy && a.group_start && a.group_end && a.broadcast;
+    return a;
+  }();
+  return api;
+}
+
+using GemmLauncher = std::function<int(int, int, int, int, const float *, int, const float *, int,
+                                       float *, int, hipStream_t)>;
+
+// Single-process, `ngpus`-device row-panel shard (BASELINE.json config 4; no
+// reference analogue -- cuda/test_MMult.cpp:24-25 pins device 0).  Device d
+// owns C rows mmh_shard_rows(m, ngpus, d); A panels go host -> owner, B goes
+// host -> device 0 and then to everyone with ONE ncclBroadcast over xGMI;
+// C row panels are disjoint, so there is no reduction.
+inline int sgemm_sharded_impl(int ngpus, int m, int n, int k, const float *A, int lda,
+                              const float *B, int ldb, float *C, int ldc, int kernel,
+                              float *timings_ms, std::string *err, const GemmLauncher &gemm) {
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point t) {
+    return std::chrono::duration<float, std::milli>(clk::now() - t).count();
+  };
+  if (timings_ms) timings_ms[0] = timings_ms[1] = timings_ms[2] = timings_ms[3] = 0.f;
+  if (m == 0 || n == 0) return MMH_OK;
+
+  struct Dev {
+    int row0 = 0, rows = 0;
+    float *a = nullptr, *b = nullptr, *c = nullptr;
+    hipStream_t s = nullptr;
+  };
+  std::vector<Dev> dev(ngpus);
+  std::vector<void *> comms(ngpus, nullptr);
+  int rc = MMH_OK;
+  auto cleanup = [&]() {
+    for (int d = 0; d < ngpus; ++d) {
+      (void)hipSetDevice(d);
+      if (dev[d].a) (void)hipFree(dev[d].a);
+      if (dev[d].b) (void)hipFree(dev[d].b);
+      if (dev[d].c) (void)hipFree(dev[d].c);
+      if (dev[d].s) (void)hipStreamDestroy(dev[d].s);
+      if (comms[d]) rccl_api().comm_destroy(comms[d]);
+    }
+  };
+#define SH_TRY(expr)                                                      \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess) {                                               \
+      if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_);  \
+      cleanup();                                                          \
+      return MMH_ERR_HIP;                                                 \
+    }                                                                     \
+  } while (0)
+
+  if (ngpus > 1) {
+    if (!rccl_api().ok) {
+      if (err) *err = "librccl.so could not be loaded";
+      return MMH_ERR_UNSUPPORTED;
+    }
+    std::vector<int> ids(ngpus);
+    for (int d = 0; d < ngpus; ++d) ids[d] = d;
+    if (rccl_api().comm_init_all(comms.data(), ngpus, ids.data()) != 0) {
+      if (err) *err = "ncclCommInitAll failed";
+      return MMH_ERR_COMM;
+    }
+  }
+  const size_t kk = k > 0 ? k : 1;
+  for (int d = 0; d < ngpus; ++d) {
+    mmh_shard_rows(m, ngpus, d, &dev[d].row0, &dev[d].rows);
+    SH_TRY(hipSetDevice(d));
+    SH_TRY(hipStreamCreate(&dev[d].s));
+    const size_t rows = dev[d].rows > 0 ? dev[d].rows : 1;
+    SH_TRY(hipMalloc(&dev[d].a, rows * kk * sizeof(float)));
+    SH_TRY(hipMalloc(&dev[d].b, kk * n * sizeof(float)));
+    SH_TRY(hipMalloc(&dev[d].c, rows * n * sizeof(float)));
+  }
+  // ---- host -> device: A panels to their owners, B to device 0 only ----
+  auto t = clk::now();
+  for (int d = 0; d < ngpus && k > 0; ++d) {
+    SH_TRY(hipSetDevice(d));
+    if (dev[d].rows > 0)
+      SH_TRY(hipMemcpy2DAsync(dev[d].a, (size_t)k * 4, A + (size_t)dev[d].row0 * lda,
+                              (size_t)lda * 4, (size_t)k * 4, dev[d].rows, hipMemcpyHostToDevice,
+                              dev[d].s));
+    if (d == 0)
+      SH_TRY(hipMemcpy2DAsync(dev[0].b, (size_t)n * 4, B, (size_t)ldb * 4, (size_t)n * 4, k,
+                              hipMemcpyHostToDevice, dev[0].s));
+  }
+  for (int d = 0; d < ngpus; ++d) {
+    SH_TRY(hipSetDevice(d));
+    SH_TRY(hipStreamSynchronize(dev[d].s));
+  }
+  if (timings_ms) timings_ms[0] = ms_since(t);
+  // ---- the one collective: broadcast B from device 0 over xGMI ----
+  t = clk::now();
+  if (ngpus > 1 && k > 0) {
+    rccl_api().group_start();
+    for (int d = 0; d < ngpus; ++d) {
+      constexpr int nccl_float = 7;
+      if (rccl_api().broadcast(dev[0].b, dev[d].b, (size_t)k * n, nccl_float, 0, comms[d],
+                               dev[d].s) != 0)
+        rc = MMH_ERR_COMM;
+    }
+    if (rccl_api().group_end() != 0) rc = MMH_ERR_COMM;
+    if (rc != MMH_OK) {
+      if (err) *err = "ncclBroadcast failed";
+      cleanup();
+      return rc;
+    }
+    for (int d = 0; d < ngpus; ++d) {
+      SH_TRY(hipSetDevice(d));
+      SH_TRY(hipStreamSynchronize(dev[d].s));
+    }
+  }
+  if (timings_ms) timings_ms[1] = ms_since(t);
+  // ---- independent row-panel GEMMs ----
+  t = clk::now();
+  for (int d = 0; d < ngpus; ++d) {
+    if (dev[d].rows == 0) continue;
+    SH_TRY(hipSetDevice(d));
+    rc = gemm(kernel, dev[d].rows, n, k, dev[d].a, k, dev[d].b, n, dev[d].c, n, dev[d].s);
+    if (rc != MMH_OK) {
+      cleanup();
+      return rc;
+    }
+  }
+  for (int d = 0; d < ngpus; ++d) {
+    SH_TRY(hipSetDevice(d));
+    SH_TRY(hipStreamSynchronize(dev[d].s));
+  }
+  if (timings_ms) timings_ms[2] = ms_since(t);
+  // ---- device -> host: disjoint C panels ----
+  t = clk::now();
+  for (int d = 0; d < ngpus; ++d) {
+    if (dev[d].rows == 0) continue;
+    SH_TRY(hipSetDevice(d));
+    SH_TRY(hipMemcpy2DAsync(C + (size_t)dev[d].row0 * ldc, (size_t)ldc * 4, dev[d].c,
+                            (size_t)n * 4, (size_t)n * 4, dev[d].rows, hipMemcpyDeviceToHost,
+                            dev[d].s));
+  }
+  for (int d = 0; d < ngpus; ++d) {
+    SH_TRY(hipSetDevice(d));
+    SH_TRY(hipStreamSynchronize(dev[d].s));
+  }
+  if (timings_ms) timings_ms[3] = ms_since(t);
+  cleanup();
+#undef SH_TRY
+  return MMH_OK;
+}
+
+}  // namespace mmh

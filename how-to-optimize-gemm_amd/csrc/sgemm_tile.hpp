@@ -1,0 +1,158 @@
+// sgemm_tile.hpp -- shared pieces of the MI355X SGEMM kernels: tile geometry,
+// the XCD-aware block -> C-tile map, and the global -> LDS "packing" stage.
+//
+// Role in the reference's terms (paths relative to /root/reference): this is
+// what PackMatrixA/PackMatrixB do for the CPU kernels
+// (aarch64/MMult_4x4_12.cpp:41-63) and what the gmem->smem copy with a
+// k-major A does for the CUDA kernels (cuda/MMult_cuda_9.cu:43-63): re-lay
+// out one K-slice of the A and B panels so the inner kernel reads its
+// operands contiguously.  The layout itself is designed for CDNA4's LDS and
+// MFMA operand shapes, not translated.
+//
+// LDS image of one K-slice (BK = 32 deep), per buffer:
+//   As[k][m]  k-major ("transposed") A panel, BM floats per k-row, with the
+//             16-byte slot index (m/4) XOR-swizzled by swz(k/4);
+//   Bs[k][n]  B panel exactly as it lies in memory, BN floats per k-row.
+// A wave then fetches, for one k-step of 4, its whole 64-row A fragment set
+// and 64-column B fragment set with ONE ds_read_b128 each: lane (i = l&15,
+// kq = l>>4) reads As[k0+kq][m0+4i..4i+3] -> the A operands of the four
+// 16x16 tiles whose rows are interleaved {m0+4i+t}, t = 0..3; likewise B.
+// With a row pitch that is a multiple of 256 B those reads are bank-conflict
+// free on gfx950 (ds_read_b128 is served in the 16-lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...; MI355X_MICROARCH.md, LDS).
+//
+// The swizzle: A arrives row-major (k contiguous), so a thread that loads a
+// 4(m) x 4(k) block as four float4 along k holds the transposed block in
+// registers for free and writes four ds_write_b128, one per k.  The eight
+// lanes of a ds_write_b128 service group hold eight different k-chunks c of
+// the same four rows; without a swizzle they would all hit the same 4 banks
+// (k-rows are 512 B apart).  XOR-ing the slot index with
+//   swz(c) = (c & 7) | ((c & 4) << 1)        (bits 0-2 = c, bit 3 = bit 2)
+// spreads them over all 32 banks, and -- because a k-step's four k-rows share
+// one c, and flipping slot bits {0,1} or {2,3 together} maps each read
+// service group onto itself -- leaves the fragment reads conflict-free.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmh {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;       // K-slice depth staged per LDS buffer
+constexpr int NXCD = 8;      // XCDs on MI355X; block b is observed on XCD b % 8
+constexpr int GROUP_M = 8;   // tile-rows per rasterisation group (L2 reuse)
+
+__device__ __forceinline__ int swz_slot(int c) { return (c & 7) | ((c & 4) << 1); }
+
+// Bijective remap of the 1-D block id so that each XCD (private 4 MiB L2)
+// works on a contiguous run of C tiles, then a grouped raster inside the run
+// so that co-resident blocks share A row-panels and B column-panels.
+__device__ __forceinline__ void block_to_tile(int bid, int nblk, int nbm, int nbn,
+                                              int &tm, int &tn) {
+  const int xcd = bid % NXCD;
+  const int local = bid / NXCD;
+  const int q = nblk / NXCD, r = nblk % NXCD;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  const int per_group = GROUP_M * nbn;
+  const int group = logical / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(nbm - first_m, GROUP_M);
+  const int in_group = logical - group * per_group;
+  tm = first_m + in_group % gsize;
+  tn = in_group / gsize;
+}
+
+// ---------------------------------------------------------------------------
+// Staging registers for one K-slice of a BM x BK A panel and BK x BN B panel,
+// THREADS threads.  Each thread owns A_BLKS 4x4 blocks of A and B_VECS float4
+// of B.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int THREADS>
+struct Stage {
+  static constexpr int A_BLKS = (BM / 4) * (BK / 4) / THREADS;  // 4x4 blocks per thread
+  static constexpr int B_VECS = BK * (BN / 4) / THREADS;        // float4 per thread
+  static constexpr int B_ROWS_PER_PASS = THREADS / (BN / 4);
+  static_assert(A_BLKS >= 1 && B_VECS >= 1, "tile too small for the block");
+
+  f32x4 a[A_BLKS][4];  // a[blk][j] = A[row 4q+j][k 4c..4c+3]
+  f32x4 b[B_VECS];
+
+  // Full-tile, 16-byte-aligned fast path.
+  __device__ __forceinline__ void load(const float *__restrict__ A, int lda,
+                                       const float *__restrict__ B, int ldb, int row0,
+                                       int col0, int k0, int tid) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int blk = 0; blk < A_BLKS; ++blk) {
+      const int q = (tid >> 3) + blk * (THREADS / 8);
+      const float *p = A + (size_t)(row0 + 4 * q) * lda + k0 + 4 * c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        a[blk][j] = *reinterpret_cast<const f32x4 *>(p + (size_t)j * lda);
+    }
+    const int cb = tid % (BN / 4);
+    const int kr = tid / (BN / 4);
+#pragma unroll
+    for (int v = 0; v < B_VECS; ++v) {
+      const float *p = B + (size_t)(k0 + kr + v * B_ROWS_PER_PASS) * ldb + col0 + 4 * cb;
+      b[v] = *reinterpret_cast<const f32x4 *>(p);
+    }
+  }
+
+  // Guarded path: any m, n, k, any alignment; out-of-range elements read as 0
+  // (a zero product is an exact no-op on an fmaf chain unless the partner is
+  // inf/nan, which the fast path would not mask either side of the edge).
+  __device__ __forceinline__ void load_edge(const float *__restrict__ A, int lda,
+                                            const float *__restrict__ B, int ldb, int row0,
+                                            int col0, int k0, int m, int n, int k, int tid) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int blk = 0; blk < A_BLKS; ++blk) {
+      const int q = (tid >> 3) + blk * (THREADS / 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = row0 + 4 * q + j;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int kk = k0 + 4 * c + s;
+          a[blk][j][s] = (row < m && kk < k) ? A[(size_t)row * lda + kk] : 0.0f;
+        }
+      }
+    }
+    const int cb = tid % (BN / 4);
+    const int kr = tid / (BN / 4);
+#pragma unroll
+    for (int v = 0; v < B_VECS; ++v) {
+      const int kk = k0 + kr + v * B_ROWS_PER_PASS;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int col = col0 + 4 * cb + s;
+        b[v][s] = (kk < k && col < n) ? B[(size_t)kk * ldb + col] : 0.0f;
+      }
+    }
+  }
+
+  // Registers -> LDS.  As/Bs point at the destination buffer.
+  __device__ __forceinline__ void store(float *As, float *Bs, int tid) const {
+    const int c = tid & 7;
+    const int g = swz_slot(c);
+#pragma unroll
+    for (int blk = 0; blk < A_BLKS; ++blk) {
+      const int q = (tid >> 3) + blk * (THREADS / 8);
+      const int slot = q ^ g;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        f32x4 v = {a[blk][0][s], a[blk][1][s], a[blk][2][s], a[blk][3][s]};
+        *reinterpret_cast<f32x4 *>(As + (4 * c + s) * BM + 4 * slot) = v;
+      }
+    }
+    const int cb = tid % (BN / 4);
+    const int kr = tid / (BN / 4);
+#pragma unroll
+    for (int v = 0; v < B_VECS; ++v)
+      *reinterpret_cast<f32x4 *>(Bs + (kr + v * B_ROWS_PER_PASS) * BN + 4 * cb) = b[v];
+  }
+};
+
+}  // namespace mmh

@@ -1,0 +1,68 @@
+"""Row-panel shard of one large SGEMM across the GPUs of a node: one process
+per GPU, torch.distributed over RCCL/xGMI (backend "nccl"), or gloo on CPU
+for the host-logic tests.
+
+BASELINE.json config 4 -- there is no reference analogue (the reference pins
+device 0, cuda/test_MMult.cpp:24-25).  C[i,:] = A[i,:] * B: rank r owns the
+rows mmh_shard_rows(m, world, r) of A and C (128-row aligned, so every panel
+is whole block tiles), B is replicated by ONE broadcast from the root; the
+C panels are disjoint, so there is no reduction and no further exchange.
+Because each C element is the same k-ordered fmaf chain wherever it is
+computed, the sharded product is bit-identical to the single-GPU product.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+from . import api
+
+
+class RowPanelShard:
+    def __init__(self, m: int, n: int, k: int, rank: int, world: int):
+        self.m, self.n, self.k = m, n, k
+        self.rank, self.world = rank, world
+        self.row0, self.rows = api.shard_rows(m, world, rank)
+
+    # -- the single exchange step ---------------------------------------------
+    def broadcast_b(self, b, src: int = 0, chunks: int = 1):
+        """Replicate B (k x n) from `src` to every rank, in place.  `b` must be an
+        allocated (k, n) tensor on every rank (contents only matter on src).
+        chunks > 1 splits the broadcast along k so that a caller can overlap the
+        first GEMM K-slices with the tail of the transfer; the default is the
+        single collective the design calls for."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return b
+        if chunks <= 1:
+            dist.broadcast(b, src=src)
+        else:
+            step = (self.k + chunks - 1) // chunks
+            for k0 in range(0, self.k, step):
+                dist.broadcast(b[k0:k0 + step], src=src)
+        return b
+
+    # -- the independent unit of work ------------------------------------------
+    def local_gemm(self, gemm: Callable, a_panel, b, c_panel):
+        """c_panel (rows x n) = a_panel (rows x k) @ b.  `gemm(a, b, out)` is the
+        product kernel (MMult.matmul on GPUs)."""
+        if self.rows == 0:
+            return c_panel
+        return gemm(a_panel, b, c_panel)
+
+    # -- verification helper (tests / smoke only; not on the hot path) ----------
+    def gather_c(self, c_panel, like):
+        """Assemble the full C on every rank (all_gather of the padded panels)."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return c_panel
+        max_rows = max(api.shard_rows(self.m, self.world, r)[1] for r in range(self.world))
+        pad = torch.zeros((max_rows, self.n), dtype=c_panel.dtype, device=c_panel.device)
+        pad[:self.rows] = c_panel
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad)
+        full = torch.empty((self.m, self.n), dtype=like.dtype, device=c_panel.device)
+        for r in range(self.world):
+            r0, rows = api.shard_rows(self.m, self.world, r)
+            full[r0:r0 + rows] = parts[r][:rows]
+        return full

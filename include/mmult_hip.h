@@ -1,0 +1,147 @@
+/*
+ * mmult_hip.h -- C ABI of libmmult_hip.so, the MI355X (gfx950) backend behind
+ * the reference's MY_MMult entry point.
+ *
+ * Everything here is `extern "C"`, plain pointers and sizes, int status codes
+ * (0 = success, negative = MMH_ERR_*); nothing ever calls exit().  Matrices are
+ * ROW-MAJOR fp32 with explicit leading dimensions (elements per row), exactly
+ * as the reference harness passes them (cuda/test_MMult.cpp:62,102 --
+ * lda=k, ldb=n, ldc=n).  Unlike the reference's CUDA kernels (which ignore
+ * lda/ldb/ldc, e.g. cuda/MMult_cuda_3.cu:11,52) the leading dimensions ARE
+ * honoured, and any m, n, k >= 0 is accepted (the reference kernels >= _3 have
+ * no bounds checks and need multiples of the tile: cuda/MMult_cuda_9.cu:30-125).
+ *
+ * Which reference interface each entry point replaces (paths relative to
+ * /root/reference):
+ *
+ *   mmh_sgemm         device-pointer MY_MMult, asynchronous on a stream:
+ *                     cuda/test_MMult.cpp:13-14,102 and the launcher
+ *                     cuda/MMult_cuda_12.cu:228-235 (C = A*B, overwrite);
+ *                     accumulate=1 gives the host flavour's C = A*B + C
+ *                     (armv7/MMult0.c:9-24, aarch64/MMult0.cpp:3-19).
+ *   mmh_sgemm_host    host-pointer MY_MMult (armv7/test_MMult.c:8,76;
+ *                     aarch64/test_MMult.cpp:17,113): does H2D, kernel, D2H.
+ *   mmh_create/destroy the cublasHandle_t lifetime in the harness
+ *                     (cuda/test_MMult.cpp:43-44,142).
+ *   mmh_set_kernel    the makefile's `NEW := MMult_cuda_N` selection
+ *                     (cuda/makefile:1-3,25), as a run-time switch.
+ *   mmh_shard_rows / mmh_sgemm_sharded
+ *                     no reference analogue (single device only,
+ *                     cuda/test_MMult.cpp:24-25); BASELINE.json config 4.
+ *   mmh_igemm_s8      no reference code (aarch64-int8/ is an empty submodule,
+ *                     README.md:71-85); BASELINE.json config 5.
+ *   mmh_sgemm_rocblas vendor comparator, cuda/MMult_cuBLAS_1.cpp:11-19.
+ *   mmh_probe_*       peak probes, the idea of aarch64/gflops_benchmark/main.c:19-25
+ *                     and vulkan/benchmark/{gflops_fmla,gmem_bandwidth}.cpp.
+ *
+ * The C++-linkage forwarder `void MY_MMult(int,int,int,float*,int,float*,int,
+ * float*,int)` (mangled _Z8MY_MMultiiiPfiS_iS_i, what aarch64/test_MMult.cpp:17
+ * links against) lives in how-to-optimize-gemm_amd/harness/MMult_hip.cpp.
+ */
+#ifndef MMULT_HIP_H_
+#define MMULT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mmh_context *mmh_handle_t;
+
+/* status codes */
+#define MMH_OK 0
+#define MMH_ERR_INVALID_ARG (-1) /* negative size, ld < row length, NULL pointer */
+#define MMH_ERR_HIP (-2)         /* a HIP runtime call or kernel launch failed   */
+#define MMH_ERR_NO_DEVICE (-3)   /* no gfx950 device visible                     */
+#define MMH_ERR_UNSUPPORTED (-4) /* feature not built in (e.g. rocBLAS, RCCL)    */
+#define MMH_ERR_ALLOC (-5)       /* device or host allocation failed             */
+#define MMH_ERR_COMM (-6)        /* RCCL call failed                             */
+
+/* kernel variants (the reference's "NEW := MMult_xxx" ladder, MI355X edition) */
+#define MMH_KERNEL_AUTO 0        /* = MFMA */
+#define MMH_KERNEL_VALU 1        /* K1: LDS-tiled 128x128, 8x8 per thread, VALU fma only   */
+#define MMH_KERNEL_MFMA 2        /* K2: 128x128 block tile on v_mfma_f32_16x16x4_f32        */
+#define MMH_KERNEL_MFMA_256 3    /* K2b: 256x128 block tile, 8 waves                        */
+#define MMH_KERNEL_NAIVE 4       /* one thread per C element (cuda/MMult_cuda_2.cu analogue) */
+
+/* Library / device ------------------------------------------------------- */
+const char *mmh_strerror(int status);
+/* Text of the last HIP/RCCL error seen on this thread ("" if none). */
+const char *mmh_last_error(void);
+int mmh_version(void);                 /* 100*major + minor */
+int mmh_device_count(int *count);
+/* name must hold >= 256 bytes; cu_count / clock_mhz may be NULL. */
+int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
+
+int mmh_create(mmh_handle_t *handle, int device);
+int mmh_destroy(mmh_handle_t handle);
+int mmh_set_kernel(mmh_handle_t handle, int kernel);
+int mmh_get_kernel(mmh_handle_t handle, int *kernel);
+/* Name of a kernel variant ("MMult_hip_mfma", ...), NULL if unknown. */
+const char *mmh_kernel_name(int kernel);
+
+/* The hot path ------------------------------------------------------------ */
+/*
+ * C[m x n] = A[m x k] * B[k x n]            (accumulate == 0)
+ * C[m x n] = A[m x k] * B[k x n] + C        (accumulate != 0; C's value is the
+ *                                            first term of each element's chain)
+ * dA, dB, dC: device pointers on the handle's device.  Enqueued on `stream`
+ * (a hipStream_t passed as void*, NULL = the null stream) and returns without
+ * synchronising, like the reference launcher.  Each output element is an
+ * fp32 fused-multiply-add chain over ascending k -- for every kernel variant.
+ */
+int mmh_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, int lda,
+              const float *dB, int ldb, float *dC, int ldc, int accumulate,
+              void *stream);
+
+/* Host-pointer flavour: stages A, B (and C when accumulating) to the device,
+ * runs mmh_sgemm, copies C back, synchronises.  Staging buffers are cached in
+ * the handle and grow on demand. */
+int mmh_sgemm_host(mmh_handle_t handle, int m, int n, int k, const float *A, int lda,
+                   const float *B, int ldb, float *C, int ldc, int accumulate);
+
+/* int8 x int8 -> int32, C = A*B (+ C), row-major, inputs expected in
+ * [-127,127]; bit-exact integer arithmetic on v_mfma_i32_16x16x64_i8. */
+int mmh_igemm_s8(mmh_handle_t handle, int m, int n, int k, const int8_t *dA, int lda,
+                 const int8_t *dB, int ldb, int32_t *dC, int ldc, int accumulate,
+                 void *stream);
+
+/* Vendor comparator (rocBLAS sgemm, row-major via the swapped-operand trick
+ * of cuda/MMult_cuBLAS_1.cpp:17-18).  MMH_ERR_UNSUPPORTED if librocblas
+ * cannot be loaded. */
+int mmh_sgemm_rocblas(mmh_handle_t handle, int m, int n, int k, const float *dA, int lda,
+                      const float *dB, int ldb, float *dC, int ldc, void *stream);
+
+/* Multi-GPU row-panel shard ---------------------------------------------- */
+/* Rows [*row0, *row0 + *rows) of C (and A) owned by `rank` of `nranks`:
+ * contiguous panels, multiples of 128 rows while whole tiles remain, the
+ * remainder spread from rank 0 up.  Pure host arithmetic. */
+int mmh_shard_rows(int m, int nranks, int rank, int *row0, int *rows);
+
+/* Single-process form: host A, B, C; A row panels go to each of `ngpus`
+ * devices, B goes to device 0 and is broadcast with ONE ncclBroadcast over
+ * xGMI, one GEMM launch per device, C panels copied back.  ngpus == 1 skips
+ * RCCL.  timings_ms (may be NULL) receives {h2d, bcast, gemm, d2h}. */
+int mmh_sgemm_sharded(int ngpus, int m, int n, int k, const float *A, int lda,
+                      const float *B, int ldb, float *C, int ldc, int kernel,
+                      float *timings_ms);
+
+/* Measurement helpers ------------------------------------------------------ */
+/* Mean milliseconds per call over `reps` back-to-back mmh_sgemm launches
+ * bracketed by one hipEvent pair on `stream` (the reference's timing
+ * convention, cuda/test_MMult.cpp:98-114), after `warmup` untimed calls. */
+int mmh_time_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, int lda,
+                   const float *dB, int ldb, float *dC, int ldc, int warmup, int reps,
+                   void *stream, float *ms_per_call);
+
+/* Peak probes: sustained fp32 MFMA TFLOP/s (v_mfma_f32_16x16x4_f32 only, no
+ * memory traffic) and HBM copy GB/s (float4 stream copy, read+write bytes). */
+int mmh_probe_mfma_f32(mmh_handle_t handle, float *tflops);
+int mmh_probe_hbm_copy(mmh_handle_t handle, size_t bytes, float *gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMULT_HIP_H_ */

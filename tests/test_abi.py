@@ -1,0 +1,114 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every
+symbol include/mmult_hip.h declares, and its host-side logic (shard plan,
+error strings, argument validation before any device work) behaves.  No
+compute is attempted here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import how_to_optimize_gemm_amd as H
+from conftest import REPO
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "mmult_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mmh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = H.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/mmult_hip.h but not exported"
+    assert set(syms) == set(H.EXPORTS)
+
+
+def test_library_is_in_tree_and_has_gfx950_code_object():
+    assert os.path.dirname(H.LIB_PATH) == os.path.join(REPO, "how-to-optimize-gemm_amd")
+    blob = open(H.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"sgemm_mfma_kernel" in blob
+
+
+def test_strerror_and_names():
+    L = H.lib()
+    assert L.mmh_strerror(0) == b"success"
+    for code in range(-6, 0):
+        assert L.mmh_strerror(code) not in (b"", b"unknown status")
+    assert L.mmh_strerror(-99) == b"unknown status"
+    assert H.kernel_name(H.KERNEL_MFMA) == "MMult_hip_mfma"
+    assert H.kernel_name(H.KERNEL_VALU) == "MMult_hip_valu"
+    assert H.kernel_name(77) is None
+    assert L.mmh_version() >= 100
+
+
+@pytest.mark.parametrize("m", [0, 1, 100, 128, 300, 1000, 4096, 16384, 16389])
+@pytest.mark.parametrize("nranks", [1, 2, 3, 4, 8])
+def test_shard_rows_partition(m, nranks):
+    panels = [H.shard_rows(m, nranks, r) for r in range(nranks)]
+    # contiguous, disjoint, cover [0, m)
+    pos = 0
+    for r0, rows in panels:
+        assert rows >= 0
+        if rows:
+            assert r0 == pos
+            pos += rows
+    assert pos == m
+    # every internal boundary is 128-row aligned
+    for r0, rows in panels:
+        if rows and r0 + rows != m:
+            assert (r0 + rows) % 128 == 0
+    # balance: whole tiles differ by at most one between ranks
+    tiles = [rows // 128 for _, rows in panels]
+    assert max(tiles) - min(tiles) <= 1
+    if m == 16384 and nranks == 8:
+        assert panels == [(2048 * r, 2048) for r in range(8)]   # BASELINE.json config 4
+
+
+def test_shard_rows_rejects_bad_arguments():
+    L = H.lib()
+    r0, nr = ctypes.c_int(), ctypes.c_int()
+    assert L.mmh_shard_rows(-1, 2, 0, ctypes.byref(r0), ctypes.byref(nr)) == H.ERR_INVALID_ARG
+    assert L.mmh_shard_rows(10, 0, 0, ctypes.byref(r0), ctypes.byref(nr)) == H.ERR_INVALID_ARG
+    assert L.mmh_shard_rows(10, 2, 2, ctypes.byref(r0), ctypes.byref(nr)) == H.ERR_INVALID_ARG
+    assert L.mmh_shard_rows(10, 2, 0, None, ctypes.byref(nr)) == H.ERR_INVALID_ARG
+
+
+def test_null_handle_is_an_error_not_a_crash():
+    L = H.lib()
+    assert L.mmh_sgemm(None, 1, 1, 1, None, 1, None, 1, None, 1, 0, None) == H.ERR_INVALID_ARG
+    assert L.mmh_sgemm_host(None, 1, 1, 1, None, 1, None, 1, None, 1, 0) == H.ERR_INVALID_ARG
+    assert L.mmh_destroy(None) == H.OK
+    assert L.mmh_set_kernel(None, 2) == H.ERR_INVALID_ARG
+
+
+def test_no_device_fails_loudly_without_fallback():
+    """On a box without a gfx950 GPU the product path must refuse, not
+    compute on the CPU."""
+    if H.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(H.MMultError) as e:
+        H.MMult(0)
+    assert e.value.status == H.ERR_NO_DEVICE
+    import numpy as np
+    with pytest.raises(H.MMultError):
+        H.sgemm_sharded(1, np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: no file of the shipped package, the C
+    ABI or the harness may reference it."""
+    pkg = os.path.join(REPO, "how-to-optimize-gemm_amd")
+    offenders = []
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".c")) or f in ("makefile", "Makefile"):
+                p = os.path.join(root, f)
+                text = open(p, errors="ignore").read()
+                if re.search(r"(from|import)\s+oracle|oracle/|liboracle|orc_", text):
+                    offenders.append(p)
+    assert offenders == []

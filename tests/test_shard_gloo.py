@@ -1,0 +1,68 @@
+"""world_size-2 (and 3) gloo tests of the multi-GPU host logic on CPU: the
+row-panel plan, the single broadcast of B, and the reassembly.  The local
+GEMM is stood in for by the CPU oracle (tests may use it); on GPUs the same
+RowPanelShard drives MMult.matmul (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, m, n, k, chunks, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from how_to_optimize_gemm_amd.shard import RowPanelShard
+        from oracle import oracle as O
+        a, b_full = O.harness_inputs(m, n, k, seed=4321)        # same on every rank (seeded)
+        sh = RowPanelShard(m, n, k, rank, world)
+        a_panel = torch.from_numpy(a[sh.row0:sh.row0 + sh.rows].copy())
+        b = torch.from_numpy(b_full.copy()) if rank == 0 else torch.full((k, n), float("nan"))
+        sh.broadcast_b(b, src=0, chunks=chunks)
+        assert torch.equal(b, torch.from_numpy(b_full)), "B did not arrive intact"
+
+        def gemm(x, y, out):
+            out.copy_(torch.from_numpy(O.ref_mmult(x.numpy(), y.numpy(), fma=True)))
+            return out
+
+        c_panel = torch.empty((sh.rows, n))
+        sh.local_gemm(gemm, a_panel, b, c_panel)
+        full = sh.gather_c(c_panel, like=b)
+        want = O.ref_mmult(a, b_full, fma=True)
+        q.put((rank, bool(np.array_equal(full.numpy(), want)), sh.row0, sh.rows))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,m,n,k,chunks", [(2, 256, 96, 64, 1), (2, 300, 72, 40, 1),
+                                               (3, 520, 64, 48, 2), (2, 100, 33, 17, 1)])
+def test_row_panel_shard_over_gloo(world, m, n, k, chunks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, m, n, k, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in results)
+    assert sum(rows for _, _, _, rows in results) == m
