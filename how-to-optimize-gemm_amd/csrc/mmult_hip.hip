@@ -87,7 +87,10 @@ int allow_big_lds(K kernel, size_t bytes) {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int BM, int BN>
+// SIMPLE: the un-pipelined rung.  SCHED / BUFLD / ABL: see sgemm_mfma.hpp.  The
+// buffer-descriptor path needs every byte offset inside a 2 GiB window; larger
+// operands fall back to 64-bit global addressing (same kernel, BUFLD = false).
+template <int BM, int BN, bool SIMPLE = false, int SCHED = 4, int ABL = 0, bool BUFLD = true>
 int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, int ldb,
                 float *C, int ldc, int acc, hipStream_t s) {
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
@@ -97,17 +100,26 @@ int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, in
   constexpr int threads = BM * BN / (64 * 64) * 64;
   constexpr size_t lds = lds_bytes(BM, BN);
   dim3 grid((unsigned)(nbm * nbn)), block(threads);
-  if (fast) {
-    auto kern = mmh::sgemm_mfma_kernel<BM, BN, false>;
-    const int ok = allow_big_lds(kern, lds);
-    if (ok != MMH_OK) return ok;
-    hipLaunchKernelGGL(kern, grid, block, lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm, nbn);
+  const size_t lim = (1ull << 31) - 4096;
+  const bool window_ok = ((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim;
+#define MMH_LAUNCH(KERN)                                                                   \
+  do {                                                                                     \
+    auto kern = KERN;                                                                      \
+    const int ok = allow_big_lds(kern, lds);                                               \
+    if (ok != MMH_OK) return ok;                                                           \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm, nbn); \
+  } while (0)
+  if (SIMPLE) {
+    if (fast) MMH_LAUNCH((mmh::sgemm_mfma_simple_kernel<BM, BN, false>));
+    else      MMH_LAUNCH((mmh::sgemm_mfma_simple_kernel<BM, BN, true>));
+  } else if (!fast) {
+    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, false>));
+  } else if (BUFLD && window_ok) {
+    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, BUFLD>));
   } else {
-    auto kern = mmh::sgemm_mfma_kernel<BM, BN, true>;
-    const int ok = allow_big_lds(kern, lds);
-    if (ok != MMH_OK) return ok;
-    hipLaunchKernelGGL(kern, grid, block, lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm, nbn);
+    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, false>));
   }
+#undef MMH_LAUNCH
   HIP_TRY(hipGetLastError());
   return MMH_OK;
 }
@@ -170,11 +182,25 @@ int sgemm_on(int kernel, int m, int n, int k, const float *dA, int lda, const fl
       return launch_valu(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case MMH_KERNEL_NAIVE:
       return launch_naive(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_MFMA_SIMPLE:
+      return launch_mfma<128, 128, true>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_MFMA_PIPE:
+      return launch_mfma<128, 128, false, 0, 0, false>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case MMH_KERNEL_MFMA_256:
       return launch_mfma<256, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case MMH_KERNEL_AUTO:
     case MMH_KERNEL_MFMA:
       return launch_mfma<128, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    // Ablation builds of the shipping kernel (TIMING ONLY -- results are wrong):
+    // 32 no global loads, 33 + no LDS stores, 34 + no barrier, 35 + no fragment reads.
+    case 32:
+      return launch_mfma<128, 128, false, 4, 1>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 33:
+      return launch_mfma<128, 128, false, 4, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 34:
+      return launch_mfma<128, 128, false, 4, 7>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 35:
+      return launch_mfma<128, 128, false, 4, 15>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     default:
       g_last_error = "unknown kernel variant";
       return MMH_ERR_INVALID_ARG;
@@ -284,6 +310,12 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA: return "MMult_hip_mfma";
     case MMH_KERNEL_MFMA_256: return "MMult_hip_mfma256";
     case MMH_KERNEL_NAIVE: return "MMult_hip_naive";
+    case MMH_KERNEL_MFMA_SIMPLE: return "MMult_hip_mfma_simple";
+    case MMH_KERNEL_MFMA_PIPE: return "MMult_hip_mfma_pipe";
+    case 32: return "ablate_no_gload";
+    case 33: return "ablate_no_gload_no_ldswrite";
+    case 34: return "ablate_no_gload_no_ldswrite_no_barrier";
+    case 35: return "ablate_mfma_only";
     default: return nullptr;
   }
 }

@@ -1,4 +1,5 @@
-// sgemm_mfma.hpp -- K2: the MI355X SGEMM hot kernel.
+// sgemm_mfma.hpp -- K2: the MI355X SGEMM hot kernel (simple rung first, the
+// barrier-pipelined kernel that ships as MMH_KERNEL_MFMA below it).
 //
 // What it computes is what cuda/MMult_cuda_12.cu:86-223 (sgemm_128x128x8)
 // computes for the reference -- one C tile per workgroup, fp32, row-major,
@@ -23,13 +24,15 @@
 // CONSECUTIVE columns n0+4*(l&15)+{0..3} of one C row in the same lane across
 // the four column tiles, so the epilogue is global_store_dwordx4.
 #pragma once
+#include <type_traits>
+
 #include "sgemm_tile.hpp"
 
 namespace mmh {
 
 template <int BM, int BN, bool EDGE>
 __global__ void __launch_bounds__(BM * BN / (64 * 64) * 64)
-sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
+sgemm_mfma_simple_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                   const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                   int accumulate, int nbm, int nbn) {
   constexpr int WAVES_N = BN / 64;
@@ -122,6 +125,219 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   }
 
   // epilogue: 16 x global_store_dwordx4 per lane (256 B contiguous per 16 lanes)
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = crow + 4 * r + t;
+      f32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+      if (!EDGE) {
+        *reinterpret_cast<f32x4 *>(C + (size_t)row * ldc + ccol) = v;
+      } else if (row < m) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
+      }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// K2 proper: the same tile, packing and arithmetic, with the K-slice hand-over
+// software-pipelined ACROSS the barrier.
+//
+// In the simple kernel above every wave leaves the barrier with nothing to
+// feed the matrix pipe until its first ds_read_b128 of the new slice returns,
+// and the ds_write burst + vmcnt wait sit between the last MFMA and the
+// barrier: rocprofv3 (profiles/r01_*) shows the MFMA pipe only ~80 % busy.
+// Here
+//   * the fragments of k-step 7 are read BEFORE the barrier and their 16 MFMAs
+//     issue AFTER it, right behind the ds_reads for k-step 0 of the next
+//     slice -- 512 matrix-pipe cycles cover that LDS latency;
+//   * the next slice's registers -> LDS stores are issued in the shadow of
+//     k-steps 1..2, the global loads for the slice after next right after
+//     them, so nothing but the barrier itself sits at the slice boundary.
+// Two LDS buffers and ONE barrier per K-slice still suffice: the barrier comes
+// after every wave's last READ of `cur` (k-step 7's fragments are already in
+// registers) and after every wave's WRITES to `cur^1`.
+// Arithmetic order per C element is unchanged (ascending k), so the result is
+// bit-identical to the simple kernel and to the fmaf-chain oracle.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, bool EDGE, int SCHED = 0, int ABL = 0, bool BUFLD = false>
+__global__ void __launch_bounds__(BM * BN / (64 * 64) * 64, 2)  // 2 waves/SIMD: <= 256 VGPR+AGPR
+sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
+                  const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                  int accumulate, int nbm, int nbn) {
+  constexpr int WAVES_N = BN / 64;
+  constexpr int THREADS = BM * BN / (64 * 64) * 64;
+  constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * BN, BUF = A_FLOATS + B_FLOATS;
+  constexpr int KS = BK / 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  int tm, tn;
+  block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
+  const int row0 = tm * BM, col0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 15, kq = lane >> 4;
+  const int crow = row0 + wm * 64 + 16 * kq;
+  const int ccol = col0 + wn * 64 + 4 * li;
+
+  f32x4 acc[4][4];
+  if (accumulate) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = crow + 4 * r + t;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!EDGE) {
+          v = *reinterpret_cast<const f32x4 *>(C + (size_t)row * ldc + ccol);
+        } else if (row < m) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (ccol + u < n) v[u] = C[(size_t)row * ldc + ccol + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u][r] = v[u];
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  Stage<BM, BN, THREADS> st;
+  const int nk = (k + BK - 1) / BK;
+  const int a_slot = wm * 16 + li;
+  const int b_off = A_FLOATS + kq * BN + wn * 64 + 4 * li;
+
+  // buffer descriptors (BUFLD): wave-uniform bases, 4 GiB window each
+  __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+  uint32_t voff_a[Stage<BM, BN, THREADS>::A_BLKS], voff_b = 0;
+  if (BUFLD && !EDGE) {
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + (size_t)row0 * lda), 0,
+                                               0x7fffffff, 0x00020000);
+    rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + col0), 0, 0x7fffffff,
+                                               0x00020000);
+    st.buf_offsets(lda, ldb, tid, voff_a, voff_b);
+  }
+  auto stage_load = [&](int kt) {
+    if (EDGE)       st.load_edge(A, lda, B, ldb, row0, col0, kt * BK, m, n, k, tid);
+    else if (BUFLD) st.load_buf(rsrc_a, rsrc_b, voff_a, voff_b, lda, ldb, kt * BK);
+    else            st.load(A, lda, B, ldb, row0, col0, kt * BK, tid);
+  };
+  auto frag_a = [&](const float *buf, int ks) {
+    return *reinterpret_cast<const f32x4 *>(buf + (4 * ks + kq) * BM + 4 * (a_slot ^ swz_slot(ks)));
+  };
+  auto frag_b = [&](const float *buf, int ks) {
+    return *reinterpret_cast<const f32x4 *>(buf + b_off + 4 * ks * BN);
+  };
+
+  f32x4 fa[2], fb[2];
+  if (nk > 0) {
+    stage_load(0);
+    st.store(lds, lds + A_FLOATS, tid);
+    if (nk > 1) stage_load(1);            // slice 1 rides in registers into iteration 0
+  }
+  __syncthreads();
+  if (nk > 0) {
+    fa[0] = frag_a(lds, 0);
+    fb[0] = frag_b(lds, 0);
+  }
+
+  // One K-slice.  MORE: a next slice exists (its data is in the staging
+  // registers); MORE2: a slice after that exists (its global loads are issued
+  // here).  Compile-time flags keep the steady-state loop body branch-free so
+  // the scheduler sees all 128 MFMAs and their ds_read/ds_write/global_load
+  // shadow work as one block.
+  int cur = 0;
+  auto slice = [&](int kt, auto more_c, auto more2_c) {
+    constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
+    const float *buf = lds + cur * BUF;
+    float *nxt = lds + (cur ^ 1) * BUF;
+    auto kstep = [&](auto ks_c) {
+      constexpr int ks = decltype(ks_c)::value;
+      if (ABL & 8) {
+        // ablation: no fragment reads in the loop (keep the registers opaque)
+        asm volatile("" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fa[1]), "+v"(fb[1]));
+        if (ks + 1 == KS && !(ABL & 4)) __syncthreads();
+      } else if (ks + 1 < KS) {
+        fa[(ks + 1) & 1] = frag_a(buf, ks + 1);
+        fb[(ks + 1) & 1] = frag_b(buf, ks + 1);
+        // SCHED 3: keep the prefetch at the TOP of the k-step (the scheduler
+        // otherwise sinks it below the MFMAs and then waits on it at once)
+        if (SCHED == 3) __builtin_amdgcn_sched_barrier(0);
+      } else {
+        // slice boundary: every read of `cur` has been issued; writes to `cur^1` too
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 4)) __syncthreads();
+        if (MORE) {
+          fa[(ks + 1) & 1] = frag_a(nxt, 0);
+          fb[(ks + 1) & 1] = frag_b(nxt, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      constexpr bool DO_STORE = (ks == 1) && MORE && !(ABL & 2);
+      constexpr bool DO_LOAD = (ks == (SCHED == 2 ? 4 : 2)) && MORE2 && !(ABL & 1);
+      if (DO_STORE) st.store(nxt, nxt + A_FLOATS, tid);
+      if (DO_LOAD) stage_load((ABL & 16) ? (kt & 1) : kt + 2);
+      const f32x4 a = fa[ks & 1], b = fb[ks & 1];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
+      // SCHED 1..3: pin the k-step order (reads for ks+1 and the shadow memory
+      // ops stay inside the k-step whose 16 MFMAs cover them)
+      if (SCHED >= 1 && SCHED <= 3) __builtin_amdgcn_sched_barrier(0);
+      // SCHED 4: describe the k-step to the scheduler as a pipeline -- the two
+      // fragment prefetches first, then the slice's LDS stores / global loads
+      // dealt out one per two MFMAs instead of in a burst.
+      if (SCHED == 4) {
+        constexpr int NMEM = Stage<BM, BN, THREADS>::A_BLKS * 4 + Stage<BM, BN, THREADS>::B_VECS;
+        constexpr int USED = (DO_STORE || DO_LOAD) ? 2 * NMEM : 0;
+        static_assert(USED <= 16, "more staging ops than MFMA pairs in a k-step");
+        if (ks + 1 < KS || MORE) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+        if (DO_STORE) {
+#pragma unroll
+          for (int w = 0; w < NMEM; ++w) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+          }
+        }
+        if (DO_LOAD) {
+#pragma unroll
+          for (int w = 0; w < NMEM; ++w) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+          }
+        }
+        if (USED < 16) __builtin_amdgcn_sched_group_barrier(0x008, 16 - USED, 0);
+      }
+    };
+    static_assert(KS == 8, "k-steps are spelled out below");
+    kstep(std::integral_constant<int, 0>{});
+    kstep(std::integral_constant<int, 1>{});
+    kstep(std::integral_constant<int, 2>{});
+    kstep(std::integral_constant<int, 3>{});
+    kstep(std::integral_constant<int, 4>{});
+    kstep(std::integral_constant<int, 5>{});
+    kstep(std::integral_constant<int, 6>{});
+    kstep(std::integral_constant<int, 7>{});
+    cur ^= 1;
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) slice(kt, T{}, T{});
+  if (kt + 1 < nk) { slice(kt, T{}, F{}); ++kt; }
+  if (kt < nk) slice(kt, F{}, F{});
+
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll

@@ -100,6 +100,38 @@ struct Stage {
     }
   }
 
+  // Same fast path through buffer descriptors (T8): the per-lane byte offsets
+  // are loop-invariant VGPRs, the K-slice advance is a scalar soffset, so the
+  // steady-state loop carries no 64-bit VALU address arithmetic and each load
+  // ships 4 address bytes per lane instead of 8.  rsrc_a covers A from
+  // (row0, 0), rsrc_b covers B from (0, col0); offsets must stay < 2^32.
+  __device__ __forceinline__ void buf_offsets(int lda, int ldb, int tid, uint32_t (&voff_a)[A_BLKS],
+                                              uint32_t &voff_b) const {
+    const int c = tid & 7;
+#pragma unroll
+    for (int blk = 0; blk < A_BLKS; ++blk) {
+      const int q = (tid >> 3) + blk * (THREADS / 8);
+      voff_a[blk] = (uint32_t)((4 * q) * lda + 4 * c) * 4u;
+    }
+    voff_b = (uint32_t)((tid / (BN / 4)) * ldb + 4 * (tid % (BN / 4))) * 4u;
+  }
+  __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rsrc_a, __amdgpu_buffer_rsrc_t rsrc_b,
+                                           const uint32_t (&voff_a)[A_BLKS], uint32_t voff_b,
+                                           int lda, int ldb, int k0) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int blk = 0; blk < A_BLKS; ++blk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        a[blk][j] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[blk], (k0 + j * lda) * 4, 0));
+#pragma unroll
+    for (int v = 0; v < B_VECS; ++v)
+      b[v] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, voff_b,
+                                                       (k0 + v * B_ROWS_PER_PASS) * ldb * 4, 0));
+  }
+
   // Guarded path: any m, n, k, any alignment; out-of-range elements read as 0
   // (a zero product is an exact no-op on an fmaf chain unless the partner is
   // inf/nan, which the fast path would not mask either side of the edge).

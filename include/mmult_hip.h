@@ -62,9 +62,15 @@ typedef struct mmh_context *mmh_handle_t;
 /* kernel variants (the reference's "NEW := MMult_xxx" ladder, MI355X edition) */
 #define MMH_KERNEL_AUTO 0        /* = MFMA */
 #define MMH_KERNEL_VALU 1        /* K1: LDS-tiled 128x128, 8x8 per thread, VALU fma only   */
-#define MMH_KERNEL_MFMA 2        /* K2: 128x128 block tile on v_mfma_f32_16x16x4_f32        */
+#define MMH_KERNEL_MFMA 2        /* K2: 128x128 block tile on v_mfma_f32_16x16x4_f32; K-slice
+                                    hand-over pipelined across the barrier, staging ops dealt
+                                    out between MFMAs, buffer-descriptor loads              */
 #define MMH_KERNEL_MFMA_256 3    /* K2b: 256x128 block tile, 8 waves                        */
 #define MMH_KERNEL_NAIVE 4       /* one thread per C element (cuda/MMult_cuda_2.cu analogue) */
+#define MMH_KERNEL_MFMA_SIMPLE 5 /* K2a: MFMA tile, plain double buffering                      */
+#define MMH_KERNEL_MFMA_PIPE 6   /* K2b': + K-slice hand-over pipelined across the barrier, but
+                                    compiler-scheduled staging and 64-bit global loads      */
+/* ids >= 32 are timing-only ablation builds (tools/ab_bench.py); their results are invalid. */
 
 /* Library / device ------------------------------------------------------- */
 const char *mmh_strerror(int status);

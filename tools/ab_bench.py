@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Within-process interleaved A/B of kernel variants (cdna guide rule 24):
+N variants x R rounds, report median / best TFLOP/s per variant.
+usage: python tools/ab_bench.py [--n 4096] [--rounds 7] [--reps 10] mfma mfma_simple 16 17 ..."""
+import argparse
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import how_to_optimize_gemm_amd as H  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=4096)
+ap.add_argument("--m", type=int, default=0)
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--check", action="store_true")
+ap.add_argument("variants", nargs="+")
+args = ap.parse_args()
+n = args.n
+m = args.m or n
+mm = H.MMult(0)
+a = torch.rand((m, n), device="cuda") * 2 - 1
+b = torch.rand((n, n), device="cuda") * 2 - 1
+c = torch.empty((m, n), device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def vid(v):
+    return H.KERNELS[v] if v in H.KERNELS else int(v)
+
+
+ref = None
+res = {v: [] for v in args.variants}
+for r in range(args.rounds):
+    for v in args.variants:
+        H.lib().mmh_set_kernel(mm._h, vid(v))
+        if v == "rocblas":
+            continue
+        ms = mm.time_sgemm(m, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, warmup=1,
+                           reps=args.reps, stream=stream)
+        res[v].append(2.0 * m * n * n / (ms * 1e-3) / 1e12)
+        if args.check and r == 0:
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = c.clone()
+            else:
+                print(f"  {v}: bit-equal to first variant: {torch.equal(ref, c)}")
+for v in args.variants:
+    x = res[v]
+    print(f"{v:>14}: median {statistics.median(x):7.2f}  best {max(x):7.2f}  worst {min(x):7.2f} TFLOP/s  (m={m}, n=k={n})")
