@@ -1,0 +1,70 @@
+// MMult_hip.cpp -- the ONE symbol a reference-shaped harness links against:
+//
+//   void MY_MMult(int m, int n, int k, float *a, int lda, float *b, int ldb,
+//                 float *c, int ldc)            (_Z8MY_MMultiiiPfiS_iS_i)
+//
+// host-pointer flavour, C = A*B + C, exactly the contract of
+// armv7/MMult0.c:9-24 / aarch64/MMult0.cpp:3-19 as called from
+// armv7/test_MMult.c:76 and aarch64/test_MMult.cpp:113.  It forwards to the C
+// ABI (mmh_sgemm_host); all arithmetic happens in the gfx950 kernels.
+//
+// A second overload mirrors the CUDA directory's device-pointer flavour
+// (cuda/test_MMult.cpp:13-14: leading handle argument, C = A*B, asynchronous).
+//
+// Kernel variant: environment variable MMULT_KERNEL = mfma | mfma256 | mfma_pipe |
+// mfma_simple | valu | naive (the run-time form of the reference's
+// `NEW := MMult_xxx`, cuda/makefile:3).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/mmult_hip.h"
+
+namespace {
+
+int kernel_from_env() {
+  const char *e = std::getenv("MMULT_KERNEL");
+  if (!e || !*e) return MMH_KERNEL_MFMA;
+  struct { const char *name; int id; } table[] = {
+      {"mfma", MMH_KERNEL_MFMA}, {"mfma256", MMH_KERNEL_MFMA_256}, {"mfma_pipe", MMH_KERNEL_MFMA_PIPE},
+      {"mfma_simple", MMH_KERNEL_MFMA_SIMPLE}, {"valu", MMH_KERNEL_VALU}, {"naive", MMH_KERNEL_NAIVE},
+      {"auto", MMH_KERNEL_AUTO}};
+  for (auto &t : table)
+    if (!std::strcmp(e, t.name)) return t.id;
+  std::fprintf(stderr, "MMULT_KERNEL=%s is not a kernel variant\n", e);
+  std::exit(EXIT_FAILURE);
+}
+
+void die(int st, const char *what) {
+  std::fprintf(stderr, "MY_MMult: %s failed: %s (%s)\n", what, mmh_strerror(st), mmh_last_error());
+  std::exit(EXIT_FAILURE);   // the reference's checkCudaErrors behaviour (cuda/helper.h:10-14)
+}
+
+mmh_handle_t default_handle() {
+  static mmh_handle_t h = [] {
+    mmh_handle_t hh = nullptr;
+    int dev = 0;
+    if (const char *e = std::getenv("MMULT_DEVICE")) dev = std::atoi(e);
+    int st = mmh_create(&hh, dev);
+    if (st != MMH_OK) die(st, "mmh_create");
+    st = mmh_set_kernel(hh, kernel_from_env());
+    if (st != MMH_OK) die(st, "mmh_set_kernel");
+    return hh;
+  }();
+  return h;
+}
+
+}  // namespace
+
+// host flavour: C += A*B
+void MY_MMult(int m, int n, int k, float *a, int lda, float *b, int ldb, float *c, int ldc) {
+  const int st = mmh_sgemm_host(default_handle(), m, n, k, a, lda, b, ldb, c, ldc, /*accumulate=*/1);
+  if (st != MMH_OK) die(st, "mmh_sgemm_host");
+}
+
+// device flavour: C = A*B on device pointers, enqueued on the null stream, no sync
+void MY_MMult(mmh_handle_t handle, int m, int n, int k, float *d_A, int lda, float *d_B, int ldb,
+              float *d_C, int ldc) {
+  const int st = mmh_sgemm(handle, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, /*accumulate=*/0, nullptr);
+  if (st != MMH_OK) die(st, "mmh_sgemm");
+}

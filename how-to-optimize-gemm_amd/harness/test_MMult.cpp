@@ -1,0 +1,228 @@
+// test_MMult.cpp -- the sweep driver, MI355X edition.
+//
+// Control flow, timing convention, tolerance and stdout format are those of the
+// reference driver (cuda/test_MMult.cpp:21-146; host flavour:
+// armv7/test_MMult.c:16-103, aarch64/test_MMult.cpp:24-144):
+//
+//   for p = PFIRST..PLAST step PINC:            cuda/parameters.h:5-7
+//     m,n,k := p unless fixed; lda=k ldb=n ldc=n cuda/test_MMult.cpp:56-62
+//     a,b,cold <- random_matrix x3, cold=cref=0  :77-81 (same drand48 call pattern)
+//     d_A,d_B <- H2D (untimed)                   :84-89
+//     cref <- REF_MMult                          :94
+//     event pair around NREPEATS x MY_MMult      :98-112   GFLOPS = 2mnk/t_mean :116-118
+//     cold <- D2H; diff = compare_matrices       :121-123  |diff| > 0.5 -> exit(-1) :124-127
+//     printf("%d %.2f %le \n", p, gflops, diff)  :128
+//
+// so an `output_<kernel>.m` written by `make run` is read by the reference's
+// cuda/plot.py:5-28 unchanged.  Everything tunable is a run-time option
+// (environment variable NAME or --NAME=value), defaults from parameters.h:
+//
+//   PFIRST PLAST PINC M N K NREPEATS LDA LDB LDC   sweep shape
+//   KERNEL=mfma|mfma256|mfma_pipe|mfma_simple|valu|naive|rocblas
+//   FLAVOUR=device|host|cpu      device: C=A*B on device pointers (cuda/ flavour)
+//                                host  : MY_MMult(m,n,k,a,lda,...) on host pointers, C+=A*B,
+//                                        best-of-NREPEATS with dclock (armv7/aarch64 flavour)
+//                                cpu   : MY_MMult := the serial triple loop, no GPU at all
+//                                        (BASELINE.json config 1, plumbing check: diff = 0)
+//   INPUT=drand48|seed:<n>|mod3|mod2|ones           (cuda/random_matrix.cpp:9-15 variants)
+//   REF=threads|serial|skip    how cref is produced (skip: diff column is -1)
+//   WARMUP=<n>                 untimed launches before the timed loop (reference: 0)
+//   EXTENDED=1                 extra columns: pct_of_fp32_mfma_peak ref_gflops ref_cores
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "helper.h"
+#include "parameters.h"
+#include "utils.h"
+
+void MY_MMult(int, int, int, float *, int, float *, int, float *, int);
+void MY_MMult(mmh_handle_t, int, int, int, float *, int, float *, int, float *, int);
+
+namespace {
+
+struct Options {
+  int pfirst = PFIRST, plast = PLAST, pinc = PINC, m = M, n = N, k = K, nrepeats = NREPEATS;
+  int lda = LDA, ldb = LDB, ldc = LDC, warmup = 0, extended = 0;
+  std::string kernel = "mfma", flavour = "device", input = "drand48", ref = "threads";
+};
+
+const char *lookup(int argc, char **argv, const char *name) {
+  const std::string key = std::string("--") + name + "=";
+  for (int i = 1; i < argc; ++i)
+    if (!std::strncmp(argv[i], key.c_str(), key.size())) return argv[i] + key.size();
+  return std::getenv(name);
+}
+void opt_int(int argc, char **argv, const char *name, int &dst) {
+  if (const char *v = lookup(argc, argv, name)) dst = std::atoi(v);
+}
+void opt_str(int argc, char **argv, const char *name, std::string &dst) {
+  if (const char *v = lookup(argc, argv, name)) dst = v;
+}
+
+int kernel_id(const std::string &s) {
+  if (s == "mfma") return MMH_KERNEL_MFMA;
+  if (s == "mfma256") return MMH_KERNEL_MFMA_256;
+  if (s == "mfma_pipe") return MMH_KERNEL_MFMA_PIPE;
+  if (s == "mfma_simple") return MMH_KERNEL_MFMA_SIMPLE;
+  if (s == "valu") return MMH_KERNEL_VALU;
+  if (s == "naive") return MMH_KERNEL_NAIVE;
+  if (s == "rocblas") return -100;
+  std::fprintf(stderr, "unknown KERNEL=%s\n", s.c_str());
+  std::exit(EXIT_FAILURE);
+}
+
+void fill(const Options &o, int rows, int cols, float *buf, int ld) {
+  if (o.input == "mod3") pattern_matrix(rows, cols, buf, ld, 3);
+  else if (o.input == "mod2") pattern_matrix(rows, cols, buf, ld, 2);
+  else if (o.input == "ones") pattern_matrix(rows, cols, buf, ld, 0);
+  else random_matrix(rows, cols, buf, ld);
+}
+
+constexpr double kPeakTflops = 157.3;  // MI355X fp32 MFMA: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  Options o;
+  opt_int(argc, argv, "PFIRST", o.pfirst);  opt_int(argc, argv, "PLAST", o.plast);
+  opt_int(argc, argv, "PINC", o.pinc);      opt_int(argc, argv, "M", o.m);
+  opt_int(argc, argv, "N", o.n);            opt_int(argc, argv, "K", o.k);
+  opt_int(argc, argv, "NREPEATS", o.nrepeats);
+  opt_int(argc, argv, "LDA", o.lda);        opt_int(argc, argv, "LDB", o.ldb);
+  opt_int(argc, argv, "LDC", o.ldc);        opt_int(argc, argv, "WARMUP", o.warmup);
+  opt_int(argc, argv, "EXTENDED", o.extended);
+  opt_str(argc, argv, "KERNEL", o.kernel);  opt_str(argc, argv, "FLAVOUR", o.flavour);
+  opt_str(argc, argv, "INPUT", o.input);    opt_str(argc, argv, "REF", o.ref);
+  if (o.pinc <= 0 || o.nrepeats <= 0) { std::fprintf(stderr, "bad PINC/NREPEATS\n"); return 2; }
+  if (!o.input.compare(0, 5, "seed:")) srand48(std::atol(o.input.c_str() + 5));
+
+  const bool cpu_only = o.flavour == "cpu";
+  const bool host_flavour = o.flavour == "host";
+  mmh_handle_t handle = nullptr;
+  hipEvent_t start{}, stop{};
+  const int kid = kernel_id(o.kernel);
+  if (!cpu_only) {
+    char name[256];
+    int cus = 0, mhz = 0;
+    MMH_CHECK(mmh_create(&handle, 0));
+    MMH_CHECK(mmh_device_info(0, name, &cus, &mhz));
+    std::printf("GPU Device %d: \"%s\" with %d CUs @ %d MHz\n\n", 0, name, cus, mhz);
+    if (kid >= 0) MMH_CHECK(mmh_set_kernel(handle, kid));
+    if (host_flavour) setenv("MMULT_KERNEL", o.kernel.c_str(), 1);
+    HIP_CHECK(hipEventCreate(&start));
+    HIP_CHECK(hipEventCreate(&stop));
+  } else {
+    std::printf("CPU only: MY_MMult = serial triple loop (plumbing)\n\n");
+  }
+  std::printf("MY_MMult = [\n");
+
+  for (int p = o.pfirst; p <= o.plast; p += o.pinc) {
+    const int m = o.m == -1 ? p : o.m, n = o.n == -1 ? p : o.n, k = o.k == -1 ? p : o.k;
+    const int lda = o.lda == -1 ? k : o.lda, ldb = o.ldb == -1 ? n : o.ldb,
+              ldc = o.ldc == -1 ? n : o.ldc;
+    if (lda < k || ldb < n || ldc < n) { std::fprintf(stderr, "leading dimension too small\n"); return 2; }
+    const double flops = 2.0 * m * n * (double)k;
+
+    // Host buffers.  The generator writes column-major into a dense (rows x cols)
+    // block exactly as the reference calls it (lda = m / k / n); the block is then
+    // read row-major.  With padded leading dimensions it is embedded row by row.
+    std::vector<float> dense_a((size_t)m * k), dense_b((size_t)k * n),
+        burn((size_t)std::max(m, n) * n);
+    fill(o, m, k, dense_a.data(), m);
+    fill(o, k, n, dense_b.data(), k);
+    fill(o, m, n, burn.data(), n);  // the reference's third call (`cold`), then zeroed
+    std::vector<float> a((size_t)m * lda, 0.f), b((size_t)k * ldb, 0.f), cold((size_t)m * ldc, 0.f),
+        cref((size_t)m * ldc, 0.f);
+    copy_matrix(m, k, dense_a.data(), k, a.data(), lda);
+    copy_matrix(k, n, dense_b.data(), n, b.data(), ldb);
+
+    // the oracle, timed with dclock() so the CPU baseline sits beside the GPU number
+    double ref_gflops = 0.0;
+    int ref_cores = 0;
+    if (o.ref != "skip") {
+      const double t0 = dclock();
+      if (o.ref == "serial") {
+        REF_MMult_serial(m, n, k, a.data(), lda, b.data(), ldb, cref.data(), ldc);
+        ref_cores = 1;
+      } else {
+        REF_MMult(m, n, k, a.data(), lda, b.data(), ldb, cref.data(), ldc);
+        ref_cores = REF_MMult_threads();
+      }
+      ref_gflops = flops * 1e-9 / (dclock() - t0);
+    }
+
+    double seconds = 0.0;
+    if (cpu_only) {
+      double best = 0.0;
+      for (int rep = 0; rep < o.nrepeats; ++rep) {
+        std::fill(cold.begin(), cold.end(), 0.f);
+        const double t0 = dclock();
+        REF_MMult_serial(m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc);
+        const double dt = dclock() - t0;
+        best = rep == 0 ? dt : std::min(best, dt);
+      }
+      seconds = best;
+    } else if (host_flavour) {
+      // armv7/aarch64 convention: re-zero C, time each call with dclock, keep the best
+      double best = 0.0;
+      for (int rep = 0; rep < o.nrepeats + o.warmup; ++rep) {
+        std::fill(cold.begin(), cold.end(), 0.f);
+        const double t0 = dclock();
+        MY_MMult(m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc);
+        const double dt = dclock() - t0;
+        best = rep == 0 ? dt : std::min(best, dt);
+      }
+      seconds = best;
+    } else {
+      float *d_A, *d_B, *d_C;
+      HIP_CHECK(hipMalloc(&d_A, a.size() * sizeof(float)));
+      HIP_CHECK(hipMalloc(&d_B, b.size() * sizeof(float)));
+      HIP_CHECK(hipMalloc(&d_C, cold.size() * sizeof(float)));
+      HIP_CHECK(hipMemcpy(d_A, a.data(), a.size() * sizeof(float), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(d_B, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+      auto call = [&] {
+        if (kid == -100)
+          MMH_CHECK(mmh_sgemm_rocblas(handle, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, nullptr));
+        else
+          MY_MMult(handle, m, n, k, d_A, lda, d_B, ldb, d_C, ldc);
+      };
+      for (int rep = 0; rep < o.warmup; ++rep) call();
+      HIP_CHECK(hipEventRecord(start, nullptr));
+      for (int rep = 0; rep < o.nrepeats; ++rep) call();
+      HIP_CHECK(hipEventRecord(stop, nullptr));
+      HIP_CHECK(hipEventSynchronize(stop));
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, start, stop));
+      seconds = ms * 1e-3 / o.nrepeats;
+      HIP_CHECK(hipMemcpy(cold.data(), d_C, cold.size() * sizeof(float), hipMemcpyDeviceToHost));
+      HIP_CHECK(hipFree(d_A));
+      HIP_CHECK(hipFree(d_B));
+      HIP_CHECK(hipFree(d_C));
+    }
+    const double gflops = flops * 1e-9 / seconds;
+
+    double diff = -1.0;
+    if (o.ref != "skip") {
+      diff = compare_matrices(m, n, cold.data(), ldc, cref.data(), ldc);
+      if (diff > 0.5 || diff < -0.5) {
+        std::printf("diff too big !\n");
+        return -1;
+      }
+    }
+    if (o.extended)
+      std::printf("%d %.2f %le %.2f %.3f %d \n", p, gflops, diff,
+                  100.0 * gflops / (kPeakTflops * 1e3), ref_gflops, ref_cores);
+    else
+      std::printf("%d %.2f %le \n", p, gflops, diff);
+    std::fflush(stdout);
+  }
+
+  if (handle) MMH_CHECK(mmh_destroy(handle));
+  std::printf("];\n");
+  return 0;
+}

@@ -1,0 +1,119 @@
+"""The C++ host side (how-to-optimize-gemm_amd/harness): builds, exports the
+reference's MY_MMult symbol, reproduces the driver's stdout contract.  CPU
+tests use FLAVOUR=cpu (BASELINE.json config 1: MY_MMult := the triple loop,
+N=256, no GPU); GPU tests run the real sweep and the reference's own driver
+linked against our MY_MMult."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import REPO
+
+HARNESS = os.path.join(REPO, "how-to-optimize-gemm_amd", "harness")
+EXE = os.path.join(HARNESS, "test_MMult.x")
+DROPIN = os.path.join(REPO, "oracle", "_ref", "test_MMult_dropin.x")
+ROW = re.compile(r"^(\d+) (\d+\.\d+) (-?\d\.\d+e[+-]\d+) $")          # cuda flavour: %d %.2f %le
+ROW_LE = re.compile(r"^(\d+) (\d\.\d+e[+-]\d+) (-?\d\.\d+e[+-]\d+) $")  # armv7 flavour: %d %le %le
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HARNESS, "all"])
+
+
+def run(env_extra, exe=EXE, timeout=900):
+    env = dict(os.environ)
+    env.update({k: str(v) for k, v in env_extra.items()})
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=timeout)
+    return r.returncode, r.stdout, r.stderr
+
+
+def parse(stdout, row=ROW):
+    """cuda/plot.py:5-28's reading of an output file body: header lines, then
+    'p gflops diff ' rows until a line with <= 2 tokens."""
+    lines = stdout.splitlines()
+    i = lines.index("MY_MMult = [")
+    rows = []
+    for ln in lines[i + 1:]:
+        if ln == "];":
+            break
+        mobj = row.match(ln)
+        assert mobj, f"row does not match '%d %.2f %le ': {ln!r}"
+        rows.append((int(mobj.group(1)), float(mobj.group(2)), float(mobj.group(3))))
+    assert lines[-1] == "];"
+    return rows
+
+
+def test_builds_and_exports_reference_symbol():
+    build()
+    out = subprocess.check_output(["nm", os.path.join(HARNESS, "MMult_hip.o")], text=True)
+    assert " T _Z8MY_MMultiiiPfiS_iS_i" in out            # 9-arg host flavour, C++ linkage
+
+
+def test_cpu_plumbing_config1():
+    """configs[0]: REF_MMult triple loop, N=256 square, CPU only -> diff = 0."""
+    build()
+    rc, out, err = run({"FLAVOUR": "cpu", "PFIRST": 256, "PLAST": 256, "NREPEATS": 2, "REF": "serial"})
+    assert rc == 0, err
+    rows = parse(out)
+    assert [r[0] for r in rows] == [256] and rows[0][2] == 0.0 and rows[0][1] > 0.05
+
+
+def test_cpu_sweep_format_and_threaded_ref_identical():
+    build()
+    rc, out, _ = run({"FLAVOUR": "cpu", "PFIRST": 40, "PLAST": 200, "PINC": 40, "NREPEATS": 1,
+                      "INPUT": "seed:7"})
+    assert rc == 0
+    rows = parse(out)
+    assert [r[0] for r in rows] == [40, 80, 120, 160, 200]
+    # cref came from the row-parallel REF, cold from the serial loop: bit-identical
+    assert all(r[2] == 0.0 for r in rows)
+    # non-square and padded leading dimensions through the option parser
+    rc, out, _ = run({"FLAVOUR": "cpu", "PFIRST": 64, "PLAST": 64, "M": 96, "K": 80, "LDA": 88,
+                      "LDB": 72, "LDC": 100, "NREPEATS": 1, "INPUT": "mod3", "EXTENDED": 1})
+    assert rc == 0 and "64 " in out
+
+
+@pytest.mark.gpu
+def test_device_flavour_sweep_on_gpu():
+    build()
+    rc, out, err = run({"PFIRST": 1024, "PLAST": 1536, "PINC": 256, "INPUT": "seed:11", "WARMUP": 2})
+    assert rc == 0, err + out
+    assert out.startswith('GPU Device 0: "')
+    rows = parse(out)
+    assert [r[0] for r in rows] == [1024, 1280, 1536]
+    for p, gflops, diff in rows:
+        assert 0.0 <= diff <= 2e-7 * p + 1e-6        # vs the unfused triple loop
+        assert gflops > 5000
+    # known-answer inputs: exactly zero, every kernel on the ladder
+    for kern in ("mfma", "mfma256", "mfma_pipe", "mfma_simple", "valu", "naive", "rocblas"):
+        rc, out, err = run({"PFIRST": 1024, "PLAST": 1024, "INPUT": "mod3", "KERNEL": kern, "NREPEATS": 3})
+        assert rc == 0, kern + err
+        assert parse(out)[0][2] == 0.0, kern
+
+
+@pytest.mark.gpu
+def test_host_flavour_on_gpu():
+    build()
+    rc, out, err = run({"FLAVOUR": "host", "PFIRST": 48, "PLAST": 480, "PINC": 144, "INPUT": "seed:3",
+                        "NREPEATS": 3})
+    assert rc == 0, err
+    rows = parse(out)
+    assert [r[0] for r in rows] == [48, 192, 336, 480]
+    assert all(0.0 <= r[2] <= 1e-4 for r in rows)
+
+
+@pytest.mark.gpu
+def test_reference_driver_linked_against_our_MY_MMult():
+    """The reference's own armv7/test_MMult.c + REF_MMult.c + compare_matrices.c
+    (object code built from /root/reference by oracle/Makefile) with ONLY
+    MY_MMult replaced by ours: its (j-i)%2 inputs are integer-valued, so its
+    diff column must be exactly 0 over its whole sweep 40..700 step 40."""
+    if not os.path.exists(DROPIN):
+        pytest.skip("oracle/_ref/test_MMult_dropin.x was not built (no /root/reference at build time)")
+    rc, out, err = run({}, exe=DROPIN)
+    assert rc == 0, err
+    rows = parse(out, ROW_LE)
+    assert [r[0] for r in rows] == list(range(40, 701, 40))
+    assert all(r[2] == 0.0 for r in rows)
