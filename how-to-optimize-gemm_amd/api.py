@@ -47,11 +47,37 @@ class MMultError(RuntimeError):
 _lib: Optional[C.CDLL] = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One process must hold ONE HIP runtime.  PyTorch's ROCm wheels bundle their
+    own libamdhip64.so.7; libmmult_hip.so needs the same SONAME.  If this
+    library pulled in /opt/rocm's copy first, a later `import torch` would load a
+    second runtime and find "No HIP GPUs".  So when torch is installed (it need
+    not be imported), its copy is loaded first and ours binds to it.  C/C++
+    callers without torch in the process simply use /opt/rocm's runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> C.CDLL:
     """Load libmmult_hip.so (built in-tree by build.py).  Fails loudly."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise MMultError(ERR_UNSUPPORTED, "load",
                          f"{LIB_PATH} is missing -- run __graft_entry__.build(); "

@@ -113,7 +113,10 @@ int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, in
     if (fast) MMH_LAUNCH((mmh::sgemm_mfma_simple_kernel<BM, BN, false>));
     else      MMH_LAUNCH((mmh::sgemm_mfma_simple_kernel<BM, BN, true>));
   } else if (!fast) {
-    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, false>));
+    // guarded launch: buffer descriptors bound the reads (any alignment >= 4 B);
+    // operands larger than the descriptor window use the per-element path
+    if (BUFLD && window_ok) MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, true>));
+    else                    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, false>));
   } else if (BUFLD && window_ok) {
     MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, BUFLD>));
   } else {

@@ -186,6 +186,11 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   const int crow = row0 + wm * 64 + 16 * kq;
   const int ccol = col0 + wn * 64 + 4 * li;
 
+  // a guarded launch still uses 16-byte C accesses in its interior blocks; there
+  // the pointer may be only 4-byte aligned, which the type must say
+  typedef float c_vec_u __attribute__((ext_vector_type(4), aligned(4)));
+  using c_vec = std::conditional_t<EDGE, c_vec_u, f32x4>;
+  const bool whole_c = !EDGE || (row0 + BM <= m && col0 + BN <= n);
   f32x4 acc[4][4];
   if (accumulate) {
 #pragma unroll
@@ -194,8 +199,8 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
       for (int r = 0; r < 4; ++r) {
         const int row = crow + 4 * r + t;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!EDGE) {
-          v = *reinterpret_cast<const f32x4 *>(C + (size_t)row * ldc + ccol);
+        if (whole_c) {
+          v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
         } else if (row < m) {
 #pragma unroll
           for (int u = 0; u < 4; ++u)
@@ -219,18 +224,35 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   // buffer descriptors (BUFLD): wave-uniform bases, 4 GiB window each
   __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
   uint32_t voff_a[Stage<BM, BN, THREADS>::A_BLKS], voff_b = 0;
-  if (BUFLD && !EDGE) {
+  // EDGE + BUFLD: the descriptors' extents end at the last valid element of this
+  // block's A rows / B columns, so the hardware's per-dword range check zeroes
+  // rows >= m of A and rows >= k of B for free (probed on gfx950:
+  // tools/probes/buffer_oob_probe.hip -- straddling dwordx4 loads return the
+  // in-range dwords and 0 for the rest, 4-byte-aligned dwordx4 works).  Columns
+  // >= n of B read neighbouring valid memory and only feed C columns that are
+  // never stored.  Only the K tail of A needs explicit masking.
+  const int rows_valid = EDGE ? min(BM, m - row0) : BM;
+  const int cols_valid = EDGE ? min(BN, n - col0) : BN;
+  if (BUFLD) {
+    const uint32_t ext_a = EDGE ? (uint32_t)(((rows_valid - 1) * lda + k) * 4) : 0x7fffffffu;
+    const uint32_t ext_b = EDGE ? (uint32_t)(((k - 1) * ldb + cols_valid) * 4) : 0x7fffffffu;
     rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + (size_t)row0 * lda), 0,
-                                               0x7fffffff, 0x00020000);
-    rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + col0), 0, 0x7fffffff,
+                                               ext_a, 0x00020000);
+    rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + col0), 0, ext_b,
                                                0x00020000);
     st.buf_offsets(lda, ldb, tid, voff_a, voff_b);
   }
   auto stage_load = [&](int kt) {
-    if (EDGE)       st.load_edge(A, lda, B, ldb, row0, col0, kt * BK, m, n, k, tid);
-    else if (BUFLD) st.load_buf(rsrc_a, rsrc_b, voff_a, voff_b, lda, ldb, kt * BK);
-    else            st.load(A, lda, B, ldb, row0, col0, kt * BK, tid);
+    if (BUFLD) {
+      st.load_buf(rsrc_a, rsrc_b, voff_a, voff_b, lda, ldb, kt * BK);
+      if (EDGE && kt == nk - 1 && (k % BK) != 0) st.mask_k_tail(k - kt * BK, tid);
+    } else if (EDGE) {
+      st.load_edge(A, lda, B, ldb, row0, col0, kt * BK, m, n, k, tid);
+    } else {
+      st.load(A, lda, B, ldb, row0, col0, kt * BK, tid);
+    }
   };
+
   auto frag_a = [&](const float *buf, int ks) {
     return *reinterpret_cast<const f32x4 *>(buf + (4 * ks + kq) * BM + 4 * (a_slot ^ swz_slot(ks)));
   };
@@ -344,8 +366,8 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
     for (int r = 0; r < 4; ++r) {
       const int row = crow + 4 * r + t;
       f32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
-      if (!EDGE) {
-        *reinterpret_cast<f32x4 *>(C + (size_t)row * ldc + ccol) = v;
+      if (whole_c) {
+        *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + ccol) = v;
       } else if (row < m) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)

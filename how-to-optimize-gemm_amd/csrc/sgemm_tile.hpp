@@ -132,6 +132,21 @@ struct Stage {
                                                        (k0 + v * B_ROWS_PER_PASS) * ldb * 4, 0));
   }
 
+  // K tail of the guarded buffer path: in the last, partial K-slice the A loads
+  // run past column k into the next row (or the caller's padding); zero those
+  // lanes.  (B needs nothing: its rows >= k lie beyond the descriptor's extent
+  // and read as 0.)  `krem` = number of valid k in this slice.
+  __device__ __forceinline__ void mask_k_tail(int krem, int tid) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int blk = 0; blk < A_BLKS; ++blk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (4 * c + s >= krem) a[blk][j][s] = 0.0f;
+  }
+
   // Guarded path: any m, n, k, any alignment; out-of-range elements read as 0
   // (a zero product is an exact no-op on an fmaf chain unless the partner is
   // inf/nan, which the fast path would not mask either side of the edge).

@@ -215,6 +215,50 @@ def test_unaligned_pointers_take_the_guarded_path(mm, oracle):
     assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
 
 
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256"])
+def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
+    """Every operand only 4-byte aligned, odd lda/ldb/ldc, ragged m/n/k, with
+    poison around the matrices: the descriptor-bounded path must neither read
+    poison into the result nor write outside C's m x n window."""
+    import torch
+    mm.set_kernel(kernel)
+    for (m, n, k, lda, ldb, ldc) in [(300, 259, 101, 103, 261, 263), (128, 128, 32, 33, 129, 131),
+                                     (257, 130, 64, 67, 133, 130), (513, 384, 250, 250, 384, 384)]:
+        a, b = oracle.harness_inputs(m, n, k, seed=m + n + k)
+        c0 = np.random.default_rng(1).uniform(-1, 1, (m, n)).astype(np.float32)
+        bufs = {}
+        for name, mat, ld in (("a", a, lda), ("b", b, ldb), ("c", c0, ldc)):
+            rows, cols = mat.shape
+            flat = torch.full((rows * ld + 1 + 64,), float("nan"), device="cuda")
+            view = flat[1:1 + rows * ld].view(rows, ld)          # base is 4-byte aligned only
+            view[:, :cols] = torch.from_numpy(mat).cuda()
+            bufs[name] = (flat, view)
+        for accumulate in (False, True):
+            bufs["c"][1][:, :n] = torch.from_numpy(c0).cuda()
+            mm.sgemm(m, n, k, bufs["a"][1].data_ptr(), lda, bufs["b"][1].data_ptr(), ldb,
+                     bufs["c"][1].data_ptr(), ldc, accumulate, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = bufs["c"][1][:, :n].cpu().numpy()
+            want = oracle.ref_mmult(a, b, c0.copy() if accumulate else None, fma=True)
+            assert np.array_equal(got, want), (m, n, k, accumulate)
+            # nothing outside the window was touched
+            assert torch.isnan(bufs["c"][1][:, n:]).all()
+            assert torch.isnan(bufs["c"][0][0]) and torch.isnan(bufs["c"][0][1 + m * ldc:]).all()
+
+
+def test_nonfinite_padding_does_not_leak_through_the_k_tail(mm, oracle):
+    """k not a multiple of the K-slice: the loads run into the next row / the
+    padding, which here holds inf/nan; masked lanes must not poison C."""
+    import torch
+    mm.set_kernel("mfma")
+    m, n, k, lda = 256, 256, 100, 104
+    a, b = oracle.harness_inputs(m, n, k, seed=9)
+    abuf = torch.full((m, lda), float("inf"), device="cuda")
+    abuf[:, :k] = torch.from_numpy(a).cuda()
+    got = mm.matmul(abuf[:, :k], dev(b)).cpu().numpy()
+    assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
+
+
 def test_huge_leading_dimension_uses_64bit_addressing(mm, oracle):
     """Offsets beyond the 2 GiB buffer-descriptor window must fall back to
     64-bit global addressing, not wrap."""

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Assorted timings on one GPU: int8 GEMM, guarded (EDGE) shapes, sweep sizes."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import how_to_optimize_gemm_amd as H  # noqa: E402
+
+mm = H.MMult(0, "mfma")
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def ramp():
+    a = torch.rand((4096, 4096), device="cuda")
+    c = torch.empty_like(a)
+    for _ in range(150):
+        mm.matmul(a, a, out=c)
+    torch.cuda.synchronize()
+
+
+def time_f32(m, n, k, kernel="mfma", reps=20):
+    mm.set_kernel(kernel)
+    a = torch.rand((m, k), device="cuda") * 2 - 1
+    b = torch.rand((k, n), device="cuda") * 2 - 1
+    c = torch.empty((m, n), device="cuda")
+    ms = mm.time_sgemm(m, n, k, a.data_ptr(), k, b.data_ptr(), n, c.data_ptr(), n, warmup=5, reps=reps,
+                       stream=stream)
+    return 2.0 * m * n * k / (ms * 1e-3) / 1e12
+
+
+def time_i8(m, n, k, reps=20):
+    a = torch.randint(-127, 128, (m, k), device="cuda", dtype=torch.int8)
+    b = torch.randint(-127, 128, (k, n), device="cuda", dtype=torch.int8)
+    c = torch.empty((m, n), device="cuda", dtype=torch.int32)
+    for _ in range(5):
+        mm.igemm_s8(a, b, out=c)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        mm.igemm_s8(a, b, out=c)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * m * n * k / (e0.elapsed_time(e1) / reps * 1e-3) / 1e12
+
+
+ramp()
+what = sys.argv[1:] or ["i8", "edge", "sweep"]
+if "i8" in what:
+    for n in (1024, 2048, 4096, 8192):
+        print(f"int8 N={n}: {time_i8(n, n, n):8.1f} TOPS")
+if "edge" in what:
+    for (m, n, k) in [(4096, 4096, 4096), (4000, 4000, 4000), (4097, 4095, 4099), (4096, 4096, 4100),
+                      (8192, 8192, 8192), (16384, 2048, 16384), (2048, 16384, 16384)]:
+        print(f"fp32 {m}x{n}x{k}: mfma {time_f32(m, n, k):7.1f}  mfma256 {time_f32(m, n, k, 'mfma256'):7.1f} TFLOP/s")
+if "sweep" in what:
+    for n in range(1024, 4097, 256):
+        print(f"fp32 N={n}: mfma {time_f32(n, n, n):7.1f}  mfma256 {time_f32(n, n, n, 'mfma256'):7.1f}  "
+              f"valu {time_f32(n, n, n, 'valu'):7.1f} TFLOP/s")
+if "big" in what:
+    for n in (8192, 16384):
+        print(f"fp32 N={n}: mfma {time_f32(n, n, n, reps=5):7.1f}  mfma256 {time_f32(n, n, n, 'mfma256', reps=5):7.1f}")
