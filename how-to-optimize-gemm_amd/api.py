@@ -24,15 +24,17 @@ LIB_PATH = os.path.join(PKG_DIR, "libmmult_hip.so")
 
 # status codes / kernel ids (include/mmult_hip.h)
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALLOC, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
-KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_256, KERNEL_NAIVE, KERNEL_MFMA_SIMPLE, KERNEL_MFMA_PIPE = 0, 1, 2, 3, 4, 5, 6
+KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_256, KERNEL_NAIVE, KERNEL_MFMA_SIMPLE, KERNEL_MFMA_PIPE, KERNEL_MFMA_SMALL = 0, 1, 2, 3, 4, 5, 6, 7
+OPT_STREAMK, OPT_STREAMK_TIMEOUTS = 1, 2
 KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
-           "mfma_pipe": KERNEL_MFMA_PIPE}
+           "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_small": KERNEL_MFMA_SMALL, "mfma_tiles": 10}
 
 # every symbol include/mmult_hip.h declares (tests assert the .so exports them all)
 EXPORTS = [
     "mmh_strerror", "mmh_last_error", "mmh_version", "mmh_device_count", "mmh_device_info",
     "mmh_create", "mmh_destroy", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name",
+    "mmh_set_option", "mmh_get_option",
     "mmh_sgemm", "mmh_sgemm_host", "mmh_igemm_s8", "mmh_sgemm_rocblas", "mmh_shard_rows",
     "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_probe_mfma_f32", "mmh_probe_hbm_copy",
 ]
@@ -94,6 +96,8 @@ def lib() -> C.CDLL:
     L.mmh_destroy.argtypes = [vp]
     L.mmh_set_kernel.argtypes = [vp, C.c_int]
     L.mmh_get_kernel.argtypes = [vp, ip]
+    L.mmh_set_option.argtypes = [vp, C.c_int, C.c_int]
+    L.mmh_get_option.argtypes = [vp, C.c_int, ip]
     L.mmh_kernel_name.argtypes = [C.c_int]
     L.mmh_kernel_name.restype = C.c_char_p
     gemm = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]
@@ -182,6 +186,15 @@ class MMult:
         k = C.c_int(0)
         _check(lib().mmh_get_kernel(self._h, C.byref(k)), "mmh_get_kernel")
         return k.value
+
+    def set_streamk(self, on: bool) -> None:
+        _check(lib().mmh_set_option(self._h, OPT_STREAMK, int(bool(on))), "mmh_set_option")
+
+    def streamk_timeouts(self) -> int:
+        """Synchronises; number of stream-K hand-off waits that timed out (must be 0)."""
+        v = C.c_int(0)
+        _check(lib().mmh_get_option(self._h, OPT_STREAMK_TIMEOUTS, C.byref(v)), "mmh_get_option")
+        return v.value
 
     def device_info(self) -> dict:
         name = C.create_string_buffer(256)
@@ -330,6 +343,6 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
 
 
 __all__ = ["MMult", "MMultError", "lib", "device_count", "shard_rows", "kernel_name", "sgemm_sharded",
-           "KERNELS", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
-           "EXPORTS", "LIB_PATH", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
+           "KERNELS", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE", "KERNEL_MFMA_SMALL",
+           "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

@@ -21,6 +21,7 @@
 #include "igemm_s8.hpp"
 #include "probes.hpp"
 #include "sgemm_mfma.hpp"
+#include "sgemm_mfma_small.hpp"
 #include "sgemm_valu.hpp"
 
 namespace {
@@ -67,6 +68,9 @@ struct mmh_context {
   int kernel = MMH_KERNEL_MFMA;
   int cu_count = 0;
   DevBuf a, b, c;          // staging for the host-pointer flavour
+  DevBuf flags;            // stream-K per-tile hand-off flags (+1 error word)
+  long flags_tiles = -1;   // where the error word of the last stream-K launch sits
+  int streamk = 1;         // allow the persistent stream-K launch for ragged tile counts
   void *rocblas = nullptr; // rocblas_handle, created on first use
 };
 
@@ -127,6 +131,62 @@ int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, in
   return MMH_OK;
 }
 
+// Persistent chained stream-K launch of the 128x128 kernel (sgemm_mfma.hpp, K2p).
+// Returns MMH_OK if it launched, 1 if the shape does not qualify (caller then
+// uses the plain one-tile-per-workgroup launch).
+int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, int lda,
+                       const float *B, int ldb, float *C, int ldc, int acc, hipStream_t s) {
+  constexpr int BM = 128, BN = 128;
+  if (!ctx || !ctx->streamk) return 1;
+  if ((m % BM) || (n % BN) || (k % mmh::BK) || (lda % 4) || (ldb % 4) || !aligned16(A) || !aligned16(B))
+    return 1;
+  // C tiles must own whole 128-byte lines: partial tiles travel between
+  // workgroups through C and per-XCD L2s are not coherent with each other
+  if ((ldc % 32) || (reinterpret_cast<uintptr_t>(C) & 127)) return 1;
+  const size_t lim = (1ull << 31) - 4096;
+  if (!(((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim)) return 1;
+  const int nbm = m / BM, nbn = n / BN;
+  const long tiles = (long)nbm * nbn;
+  const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+  int grid = 0;
+  if (tiles >= 2L * cus) grid = 2 * cus;      // two workgroups per CU (64 KiB LDS each)
+  else if (tiles >= cus) grid = cus;          // one per CU
+  if (grid == 0 || tiles % grid == 0) return 1;   // too few tiles, or already balanced
+  if (tiles > (1L << 24)) return 1;
+  int rc = ctx->flags.reserve((size_t)(tiles + 1) * sizeof(int));
+  if (rc != MMH_OK) return rc;
+  int *flags = static_cast<int *>(ctx->flags.p);
+  ctx->flags_tiles = tiles;
+  HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(tiles + 1) * sizeof(int), s));
+  auto kern = mmh::sgemm_mfma_streamk_kernel<BM, BN, false>;
+  constexpr size_t lds = lds_bytes(BM, BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
+                     acc, nbm, nbn, flags, flags + tiles);
+  HIP_TRY(hipGetLastError());
+  return MMH_OK;
+}
+
+int launch_mfma_small(int m, int n, int k, const float *A, int lda, const float *B, int ldb,
+                      float *C, int ldc, int acc, hipStream_t s) {
+  constexpr int BM = 64, BN = 64;
+  const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
+  const bool fast = (m % BM == 0) && (n % BN == 0) && (k % mmh::BK == 0) && (lda % 4 == 0) &&
+                    (ldb % 4 == 0) && (ldc % 2 == 0) && aligned16(A) && aligned16(B) &&
+                    ((reinterpret_cast<uintptr_t>(C) & 7) == 0);
+  const size_t lim = (1ull << 31) - 4096;
+  if (!(((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim))
+    return launch_mfma<128, 128>(m, n, k, A, lda, B, ldb, C, ldc, acc, s);  // 64-bit addressing lives there
+  dim3 grid((unsigned)(nbm * nbn)), block(256);
+  if (fast)
+    hipLaunchKernelGGL(mmh::sgemm_mfma_small_kernel<false>, grid, block, 0, s, m, n, k, A, lda, B, ldb,
+                       C, ldc, acc, nbm, nbn);
+  else
+    hipLaunchKernelGGL(mmh::sgemm_mfma_small_kernel<true>, grid, block, 0, s, m, n, k, A, lda, B, ldb,
+                       C, ldc, acc, nbm, nbn);
+  HIP_TRY(hipGetLastError());
+  return MMH_OK;
+}
+
 int launch_valu(int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
                 int ldc, int acc, hipStream_t s) {
   constexpr int BM = 128, BN = 128;
@@ -164,7 +224,7 @@ int check_gemm_args(int m, int n, int k, const void *A, int lda, const void *B, 
   return MMH_OK;
 }
 
-int sgemm_on(int kernel, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
+int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
              float *dC, int ldc, int accumulate, hipStream_t s) {
   int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
   if (rc != MMH_OK) {
@@ -191,9 +251,26 @@ int sgemm_on(int kernel, int m, int n, int k, const float *dA, int lda, const fl
       return launch_mfma<128, 128, false, 0, 0, false>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case MMH_KERNEL_MFMA_256:
       return launch_mfma<256, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
-    case MMH_KERNEL_AUTO:
-    case MMH_KERNEL_MFMA:
+    case MMH_KERNEL_MFMA_SMALL:
+      return launch_mfma_small(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_AUTO: {
+      // fewer 128x128 tiles than a quarter of the CUs: the 64x64 kernel fills more of the chip
+      const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
+      if (tiles128 <= 64) return launch_mfma_small(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    }  // fall through
+    case MMH_KERNEL_MFMA: {
+      // ragged tile counts go to the persistent stream-K launch (same arithmetic,
+      // same bits); everything else is one workgroup per tile
+      const int sk = try_launch_streamk(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
       return launch_mfma<128, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    }
+    case MMH_KERNEL_MFMA_TILES:   // K2 without stream-K (one workgroup per tile, always)
+      return launch_mfma<128, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 8:   // 128x64 tile, 2 waves
+      return launch_mfma<128, 64>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 9:   // 64x64 tile, 1 wave
+      return launch_mfma<64, 64>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     // Ablation builds of the shipping kernel (TIMING ONLY -- results are wrong):
     // 32 no global loads, 33 + no LDS stores, 34 + no barrier, 35 + no fragment reads.
     case 32:
@@ -289,6 +366,7 @@ int mmh_destroy(mmh_handle_t h) {
   h->a.release();
   h->b.release();
   h->c.release();
+  h->flags.release();
   mmh::rocblas_release(h->rocblas);
   delete h;
   return MMH_OK;
@@ -298,6 +376,33 @@ int mmh_set_kernel(mmh_handle_t h, int kernel) {
   if (!h || !mmh_kernel_name(kernel)) return MMH_ERR_INVALID_ARG;
   h->kernel = kernel;
   return MMH_OK;
+}
+
+int mmh_set_option(mmh_handle_t h, int option, int value) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  if (option == MMH_OPT_STREAMK) {
+    h->streamk = value ? 1 : 0;
+    return MMH_OK;
+  }
+  return MMH_ERR_INVALID_ARG;
+}
+
+int mmh_get_option(mmh_handle_t h, int option, int *value) {
+  if (!h || !value) return MMH_ERR_INVALID_ARG;
+  if (option == MMH_OPT_STREAMK) {
+    *value = h->streamk;
+    return MMH_OK;
+  }
+  if (option == MMH_OPT_STREAMK_TIMEOUTS) {
+    *value = 0;
+    if (h->flags_tiles < 0 || !h->flags.p) return MMH_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(value, static_cast<int *>(h->flags.p) + h->flags_tiles, sizeof(int),
+                      hipMemcpyDeviceToHost));
+    return MMH_OK;
+  }
+  return MMH_ERR_INVALID_ARG;
 }
 
 int mmh_get_kernel(mmh_handle_t h, int *kernel) {
@@ -315,6 +420,10 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_NAIVE: return "MMult_hip_naive";
     case MMH_KERNEL_MFMA_SIMPLE: return "MMult_hip_mfma_simple";
     case MMH_KERNEL_MFMA_PIPE: return "MMult_hip_mfma_pipe";
+    case MMH_KERNEL_MFMA_SMALL: return "MMult_hip_mfma_small";
+    case MMH_KERNEL_MFMA_TILES: return "MMult_hip_mfma_tiles";
+    case 8: return "MMult_hip_mfma_128x64";
+    case 9: return "MMult_hip_mfma_64x64";
     case 32: return "ablate_no_gload";
     case 33: return "ablate_no_gload_no_ldswrite";
     case 34: return "ablate_no_gload_no_ldswrite_no_barrier";
@@ -327,7 +436,7 @@ int mmh_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, con
               int ldb, float *dC, int ldc, int accumulate, void *stream) {
   if (!h) return MMH_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
-  return sgemm_on(h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate,
+  return sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate,
                   static_cast<hipStream_t>(stream));
 }
 
@@ -355,7 +464,7 @@ int mmh_sgemm_host(mmh_handle_t h, int m, int n, int k, const float *A, int lda,
   if (accumulate)
     HIP_TRY(hipMemcpy2D(dC, (size_t)n * 4, C, (size_t)ldc * 4, (size_t)n * 4, m,
                         hipMemcpyHostToDevice));
-  rc = sgemm_on(h->kernel, m, n, k, dA, k, dB, n, dC, n, accumulate, nullptr);
+  rc = sgemm_on(h, h->kernel, m, n, k, dA, k, dB, n, dC, n, accumulate, nullptr);
   if (rc != MMH_OK) return rc;
   HIP_TRY(hipMemcpy2D(C, (size_t)ldc * 4, dC, (size_t)n * 4, (size_t)n * 4, m,
                       hipMemcpyDeviceToHost));
@@ -385,7 +494,7 @@ int mmh_sgemm_rocblas(mmh_handle_t h, int m, int n, int k, const float *dA, int 
   if (!h) return MMH_ERR_INVALID_ARG;
   int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
   if (rc != MMH_OK) return rc;
-  if (m == 0 || n == 0 || k == 0) return sgemm_on(MMH_KERNEL_MFMA, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, static_cast<hipStream_t>(stream));
+  if (m == 0 || n == 0 || k == 0) return sgemm_on(h, MMH_KERNEL_MFMA, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, static_cast<hipStream_t>(stream));
   HIP_TRY(hipSetDevice(h->device));
   return mmh::rocblas_sgemm_rowmajor(&h->rocblas, m, n, k, dA, lda, dB, ldb, dC, ldc, stream,
                                      &g_last_error);
@@ -425,7 +534,7 @@ int mmh_sgemm_sharded(int ngpus, int m, int n, int k, const float *A, int lda, c
                                  &g_last_error,
                                  [](int kern, int mm, int nn, int kk, const float *a, int la,
                                     const float *b, int lb, float *c, int lc, hipStream_t s) {
-                                   return sgemm_on(kern, mm, nn, kk, a, la, b, lb, c, lc, 0, s);
+                                   return sgemm_on(nullptr, kern, mm, nn, kk, a, la, b, lb, c, lc, 0, s);
                                  });
 }
 
@@ -437,13 +546,13 @@ int mmh_time_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   for (int i = 0; i < warmup; ++i)
-    if ((rc = sgemm_on(h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s)) != MMH_OK) return rc;
+    if ((rc = sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s)) != MMH_OK) return rc;
   hipEvent_t t0, t1;
   HIP_TRY(hipEventCreate(&t0));
   HIP_TRY(hipEventCreate(&t1));
   HIP_TRY(hipEventRecord(t0, s));
   for (int i = 0; i < reps; ++i)
-    if ((rc = sgemm_on(h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s)) != MMH_OK) return rc;
+    if ((rc = sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s)) != MMH_OK) return rc;
   HIP_TRY(hipEventRecord(t1, s));
   HIP_TRY(hipEventSynchronize(t1));
   float ms = 0.f;

@@ -163,19 +163,19 @@ sgemm_mfma_simple_kernel(int m, int n, int k, const float *__restrict__ A, int l
 // Arithmetic order per C element is unchanged (ascending k), so the result is
 // bit-identical to the simple kernel and to the fmaf-chain oracle.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool EDGE, int SCHED = 0, int ABL = 0, bool BUFLD = false>
-__global__ void __launch_bounds__(BM * BN / (64 * 64) * 64, 2)  // 2 waves/SIMD: <= 256 VGPR+AGPR
-sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
-                  const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
-                  int accumulate, int nbm, int nbn) {
+template <int BM, int BN, bool EDGE, int SCHED, int ABL, bool BUFLD>
+__device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int k,
+                                                  const float *__restrict__ A, int lda,
+                                                  const float *__restrict__ B, int ldb,
+                                                  float *__restrict__ C, int ldc, int tm, int tn,
+                                                  int kb, int ke, bool init_from_c) {
+  // One C tile (tm, tn), K-slices [kb, ke) of it.  init_from_c: the accumulators
+  // start from C's current value (accumulate mode, or the continuation of a
+  // chain another workgroup began -- stream-K below); the tile is stored at the end.
   constexpr int WAVES_N = BN / 64;
   constexpr int THREADS = BM * BN / (64 * 64) * 64;
   constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * BN, BUF = A_FLOATS + B_FLOATS;
   constexpr int KS = BK / 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-
-  int tm, tn;
-  block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
   const int row0 = tm * BM, col0 = tn * BN;
 
   const int tid = threadIdx.x;
@@ -192,7 +192,7 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   using c_vec = std::conditional_t<EDGE, c_vec_u, f32x4>;
   const bool whole_c = !EDGE || (row0 + BM <= m && col0 + BN <= n);
   f32x4 acc[4][4];
-  if (accumulate) {
+  if (init_from_c) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -261,13 +261,13 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   };
 
   f32x4 fa[2], fb[2];
-  if (nk > 0) {
-    stage_load(0);
+  if (ke > kb) {
+    stage_load(kb);
     st.store(lds, lds + A_FLOATS, tid);
-    if (nk > 1) stage_load(1);            // slice 1 rides in registers into iteration 0
+    if (ke > kb + 1) stage_load(kb + 1);  // the second slice rides in registers into iteration 0
   }
   __syncthreads();
-  if (nk > 0) {
+  if (ke > kb) {
     fa[0] = frag_a(lds, 0);
     fb[0] = frag_b(lds, 0);
   }
@@ -304,10 +304,14 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      constexpr bool DO_STORE = (ks == 1) && MORE && !(ABL & 2);
-      constexpr bool DO_LOAD = (ks == (SCHED == 2 ? 4 : 2)) && MORE2 && !(ABL & 1);
-      if (DO_STORE) st.store(nxt, nxt + A_FLOATS, tid);
-      if (DO_LOAD) stage_load((ABL & 16) ? (kt & 1) : kt + 2);
+      constexpr int NMEM = Stage<BM, BN, THREADS>::A_BLKS * 4 + Stage<BM, BN, THREADS>::B_VECS;
+      static_assert(8 + 2 * NMEM <= 56, "staging ops do not fit in the pre-barrier MFMA shadow");
+      constexpr bool HAVE_STORE = MORE && !(ABL & 2), HAVE_LOAD = MORE2 && !(ABL & 1);
+      // source position of the staging ops: stores at k-step 1; loads where their
+      // slots begin in the SCHED-4 pipeline (k-step 2 for the other schedules)
+      constexpr int KS_LOAD = SCHED == 4 ? (8 + NMEM) / 8 : (SCHED == 2 ? 4 : 2);
+      if (ks == 1 && HAVE_STORE) st.store(nxt, nxt + A_FLOATS, tid);
+      if (ks == KS_LOAD && HAVE_LOAD) stage_load((ABL & 16) ? (kt & 1) : kt + 2);
       const f32x4 a = fa[ks & 1], b = fb[ks & 1];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -317,29 +321,26 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
       // SCHED 1..3: pin the k-step order (reads for ks+1 and the shadow memory
       // ops stay inside the k-step whose 16 MFMAs cover them)
       if (SCHED >= 1 && SCHED <= 3) __builtin_amdgcn_sched_barrier(0);
-      // SCHED 4: describe the k-step to the scheduler as a pipeline -- the two
-      // fragment prefetches first, then the slice's LDS stores / global loads
-      // dealt out one per two MFMAs instead of in a burst.
+      // SCHED 4: describe the slice to the scheduler as a pipeline.  Number the
+      // MFMA pairs of k-steps 0..6 p = 0..55: every k-step opens with its two
+      // fragment prefetches; pairs 8..8+NMEM-1 are each followed by ONE LDS store
+      // of the next slice, pairs 8+NMEM..8+2*NMEM-1 by ONE global load of the slice
+      // after next -- staging ops dealt out one per two MFMAs instead of in bursts.
       if (SCHED == 4) {
-        constexpr int NMEM = Stage<BM, BN, THREADS>::A_BLKS * 4 + Stage<BM, BN, THREADS>::B_VECS;
-        constexpr int USED = (DO_STORE || DO_LOAD) ? 2 * NMEM : 0;
-        static_assert(USED <= 16, "more staging ops than MFMA pairs in a k-step");
         if (ks + 1 < KS || MORE) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
-        if (DO_STORE) {
+        if (ks + 1 < KS) {
 #pragma unroll
-          for (int w = 0; w < NMEM; ++w) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+          for (int jp = 0; jp < 8; ++jp) {
+            const int pr = 8 * ks + jp;
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                       // MFMA
+            if (HAVE_STORE && pr >= 8 && pr < 8 + NMEM)
+              __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                     // DS write
+            if (HAVE_LOAD && pr >= 8 + NMEM && pr < 8 + 2 * NMEM)
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // VMEM read
           }
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         }
-        if (DO_LOAD) {
-#pragma unroll
-          for (int w = 0; w < NMEM; ++w) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-          }
-        }
-        if (USED < 16) __builtin_amdgcn_sched_group_barrier(0x008, 16 - USED, 0);
       }
     };
     static_assert(KS == 8, "k-steps are spelled out below");
@@ -355,10 +356,10 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   };
   using T = std::true_type;
   using F = std::false_type;
-  int kt = 0;
-  for (; kt + 2 < nk; ++kt) slice(kt, T{}, T{});
-  if (kt + 1 < nk) { slice(kt, T{}, F{}); ++kt; }
-  if (kt < nk) slice(kt, F{}, F{});
+  int kt = kb;
+  for (; kt + 2 < ke; ++kt) slice(kt, T{}, T{});
+  if (kt + 1 < ke) { slice(kt, T{}, F{}); ++kt; }
+  if (kt < ke) slice(kt, F{}, F{});
 
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -374,6 +375,108 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
           if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
       }
     }
+}
+
+
+// The shipping kernel: one workgroup per C tile (XCD-aware block -> tile map).
+template <int BM, int BN, bool EDGE, int SCHED = 0, int ABL = 0, bool BUFLD = false>
+__global__ void __launch_bounds__(BM * BN / (64 * 64) * 64, 2)  // 2 waves/SIMD: <= 256 VGPR+AGPR
+sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
+                  const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                  int accumulate, int nbm, int nbn) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int tm, tn;
+  block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
+  mfma_tile_segment<BM, BN, EDGE, SCHED, ABL, BUFLD>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0,
+                                                     (k + BK - 1) / BK, accumulate != 0);
+}
+
+// ---------------------------------------------------------------------------
+// K2p: persistent, chained stream-K.  For tile counts that do not divide the
+// chip (e.g. N=3072: 576 tiles for 512 workgroup slots) the plain kernel runs
+// a nearly empty last round.  Here gridDim.x resident workgroups split the
+// T * nk (tile, K-slice) units evenly.  A workgroup's range is
+//     [tail of tile a] [whole tiles ...] [head of tile b]
+// and it works through it BACK TO FRONT-ish: the head of b first (slices
+// 0..h-1; the partial accumulators are stored to C and a per-tile flag is
+// published), then the whole tiles, the tail of a last.  The tail CONTINUES the
+// chain its predecessor started: it waits for tile a's flag, starts its
+// accumulators from C and runs slices h..nk-1 -- so every C(i,j) is still one
+// fp32 fmaf chain over ascending k and the result is bit-identical to the
+// plain kernel.  The predecessor publishes its head before doing anything else
+// and a range is at least one tile long (the launcher guarantees T >= grid), so
+// the wait is over before it starts in steady state.
+// Visibility across CUs/XCDs (cdna guide G16): producer = plain stores, every
+// wave drains vmcnt, barrier, one lane agent-scope release fence + drained
+// relaxed flag store; consumer = one lane relaxed poll (bounded), agent-scope
+// acquire fence, barrier, plain loads.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, bool EDGE>
+__global__ void __launch_bounds__(BM * BN / (64 * 64) * 64, 2)
+sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
+                          const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                          int accumulate, int nbm, int nbn, int *__restrict__ flags,
+                          int *__restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nk = (k + BK - 1) / BK;
+  const int T = nbm * nbn, G = gridDim.x;
+  // XCD-contiguous ranges: workgroup p (on XCD p % 8) takes range index q
+  const int xcd = blockIdx.x % NXCD, local = blockIdx.x / NXCD;
+  const int gq = G / NXCD, gr = G % NXCD;
+  const int q = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + local;
+  const long long total = (long long)T * nk;
+  const long long u0 = total * q / G, u1 = total * (q + 1) / G;
+  if (u1 <= u0) return;
+  const int t_first = (int)(u0 / nk), k_first = (int)(u0 % nk);
+  const int t_last = (int)((u1 - 1) / nk), k_last_end = (int)(u1 - (long long)t_last * nk);
+  auto tile_of = [&](int t, int &tm, int &tn) {   // grouped raster, no XCD remap (ranges are)
+    const int per_group = GROUP_M * nbn;
+    const int group = t / per_group, first_m = group * GROUP_M;
+    const int gsize = min(nbm - first_m, GROUP_M);
+    const int in_group = t - group * per_group;
+    tm = first_m + in_group % gsize;
+    tn = in_group / gsize;
+  };
+  auto run = [&](int t, int kb, int ke, bool from_c) {
+    int tm, tn;
+    tile_of(t, tm, tn);
+    __syncthreads();   // LDS is reused from segment to segment
+    mfma_tile_segment<BM, BN, EDGE, 4, 0, true>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke,
+                                                from_c);
+  };
+  const bool has_tail = k_first != 0;                       // tile t_first, slices [k_first, nk)
+  const bool has_head = k_last_end != nk && (t_last != t_first || !has_tail);
+  // 1. head of the last tile: publish
+  if (has_head) {
+    run(t_last, 0, k_last_end, accumulate != 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&flags[t_last], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // 2. whole tiles
+  const int w0 = has_tail ? t_first + 1 : t_first;
+  const int w1 = has_head ? t_last - 1 : t_last;
+  for (int t = w0; t <= w1; ++t) run(t, 0, nk, accumulate != 0);
+  // 3. tail of the first tile: continue the predecessor's chain
+  if (has_tail) {
+    if (threadIdx.x == 0) {
+      long long spins = 0;
+      while (__hip_atomic_load(&flags[t_first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1ll << 26)) {          // ~ seconds: give up loudly rather than hang
+          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    const int ke = (t_first == t_last) ? k_last_end : nk;
+    run(t_first, k_first, ke, true);
+  }
 }
 
 }  // namespace mmh

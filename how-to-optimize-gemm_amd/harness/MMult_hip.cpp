@@ -26,7 +26,7 @@ int kernel_from_env() {
   const char *e = std::getenv("MMULT_KERNEL");
   if (!e || !*e) return MMH_KERNEL_MFMA;
   struct { const char *name; int id; } table[] = {
-      {"mfma", MMH_KERNEL_MFMA}, {"mfma256", MMH_KERNEL_MFMA_256}, {"mfma_pipe", MMH_KERNEL_MFMA_PIPE},
+      {"mfma", MMH_KERNEL_MFMA}, {"mfma256", MMH_KERNEL_MFMA_256}, {"mfma_small", MMH_KERNEL_MFMA_SMALL}, {"mfma_pipe", MMH_KERNEL_MFMA_PIPE},
       {"mfma_simple", MMH_KERNEL_MFMA_SIMPLE}, {"valu", MMH_KERNEL_VALU}, {"naive", MMH_KERNEL_NAIVE},
       {"auto", MMH_KERNEL_AUTO}};
   for (auto &t : table)

@@ -60,16 +60,20 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_ERR_COMM (-6)        /* RCCL call failed                             */
 
 /* kernel variants (the reference's "NEW := MMult_xxx" ladder, MI355X edition) */
-#define MMH_KERNEL_AUTO 0        /* = MFMA */
+#define MMH_KERNEL_AUTO 0        /* K2 or K2s, chosen by how many 128x128 tiles the shape has */
 #define MMH_KERNEL_VALU 1        /* K1: LDS-tiled 128x128, 8x8 per thread, VALU fma only   */
 #define MMH_KERNEL_MFMA 2        /* K2: 128x128 block tile on v_mfma_f32_16x16x4_f32; K-slice
                                     hand-over pipelined across the barrier, staging ops dealt
-                                    out between MFMAs, buffer-descriptor loads              */
+                                    out between MFMAs, buffer-descriptor loads; tile counts
+                                    that do not divide the chip run as a persistent chained
+                                    stream-K launch (K2p) -- same bits                      */
 #define MMH_KERNEL_MFMA_256 3    /* K2b: 256x128 block tile, 8 waves                        */
 #define MMH_KERNEL_NAIVE 4       /* one thread per C element (cuda/MMult_cuda_2.cu analogue) */
 #define MMH_KERNEL_MFMA_SIMPLE 5 /* K2a: MFMA tile, plain double buffering                      */
 #define MMH_KERNEL_MFMA_PIPE 6   /* K2b': + K-slice hand-over pipelined across the barrier, but
                                     compiler-scheduled staging and 64-bit global loads      */
+#define MMH_KERNEL_MFMA_TILES 10 /* K2 always as one workgroup per tile (no stream-K), for A/B      */
+#define MMH_KERNEL_MFMA_SMALL 7  /* K2s: 64x64 block tile, 4 waves of 32x32, for small problems   */
 /* ids >= 32 are timing-only ablation builds (tools/ab_bench.py); their results are invalid. */
 
 /* Library / device ------------------------------------------------------- */
@@ -87,6 +91,17 @@ int mmh_set_kernel(mmh_handle_t handle, int kernel);
 int mmh_get_kernel(mmh_handle_t handle, int *kernel);
 /* Name of a kernel variant ("MMult_hip_mfma", ...), NULL if unknown. */
 const char *mmh_kernel_name(int kernel);
+
+/* Options.  MMH_OPT_STREAMK (default 1): let MMH_KERNEL_MFMA/AUTO run tile counts
+ * that do not divide the chip as ONE persistent chained stream-K launch (bit-identical
+ * results; uses a per-handle flag buffer, so drive a handle from one stream at a
+ * time).  MMH_OPT_STREAMK_TIMEOUTS (read-only): synchronises the device and returns
+ * how many stream-K hand-off waits have timed out since the last launch (0 unless
+ * something is badly wrong; a timed-out launch produced wrong results). */
+#define MMH_OPT_STREAMK 1
+#define MMH_OPT_STREAMK_TIMEOUTS 2
+int mmh_set_option(mmh_handle_t handle, int option, int value);
+int mmh_get_option(mmh_handle_t handle, int option, int *value);
 
 /* The hot path ------------------------------------------------------------ */
 /*

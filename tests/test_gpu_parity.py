@@ -19,7 +19,7 @@ from conftest import golden_cases, load_golden
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["mfma", "mfma256", "mfma_pipe", "mfma_simple", "valu", "naive"]
+KERNELS = ["mfma", "mfma256", "mfma_small", "auto", "mfma_pipe", "mfma_simple", "valu", "naive"]
 
 
 def tol(k):
@@ -77,7 +77,7 @@ SHAPES = [(256, 256, 256), (384, 640, 1024), (128, 128, 32), (128, 256, 4096), (
           (130, 129, 37), (3, 5, 7), (257, 255, 513), (512, 128, 2048), (1024, 1024, 1024)]
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "valu"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_small", "valu"])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_seeded_inputs_vs_oracle(mm, oracle, shape, kernel):
     m, n, k = shape
@@ -104,7 +104,7 @@ def test_headline_size_4096(mm, oracle):
     c64 = oracle.ref_mmult_f64(a, b)
     assert np.abs(got - c64).max() <= 1.05 * np.abs(unfused - c64).max() + 1e-6
     # every kernel variant is the same chain -> identical bits
-    for kern in ("mfma256", "valu"):
+    for kern in ("mfma256", "mfma_small", "valu"):
         mm.set_kernel(kern)
         assert np.array_equal(mm.matmul(dev(a), dev(b)).cpu().numpy(), got), kern
 
@@ -149,6 +149,44 @@ def test_size_independent_properties_at_full_size(mm):
     # views with leading dimensions larger than the row length
     sub2 = mm.matmul(a[512:640, :], b[:, 128:384])        # ldb = 4096 > n = 256
     assert torch.equal(sub2, c[512:640, 128:384])
+
+
+@pytest.mark.parametrize("shape", [(2176, 2176, 2176), (3072, 3072, 1024), (2560, 3200, 512),
+                                   (2944, 2944, 2944), (3328, 2176, 96)])
+def test_stream_k_is_bit_identical(mm, oracle, shape):
+    """Ragged tile counts run as ONE persistent chained stream-K launch: a tile
+    split between two workgroups is still one fmaf chain over ascending k
+    (the second workgroup continues from the first one's partial result in C),
+    so the bits equal the one-workgroup-per-tile kernel's and the oracle's."""
+    import torch
+    m, n, k = shape
+    a, b = oracle.harness_inputs(m, n, k, seed=m + 7 * n + 13 * k)
+    da, db = dev(a), dev(b)
+    mm.set_kernel("mfma")
+    mm.set_streamk(True)
+    got = mm.matmul(da, db)
+    assert mm.streamk_timeouts() == 0
+    mm.set_kernel("mfma_tiles")
+    ref = mm.matmul(da, db)
+    assert torch.equal(got, ref)
+    assert np.array_equal(got.cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
+    # accumulate mode: the head part starts from the caller's C, the tail from the partial
+    c0 = torch.rand((m, n), device="cuda")
+    c1, c2 = c0.clone(), c0.clone()
+    mm.set_kernel("mfma")
+    mm.matmul(da, db, out=c1, accumulate=True)
+    mm.set_kernel("mfma_tiles")
+    mm.matmul(da, db, out=c2, accumulate=True)
+    assert torch.equal(c1, c2)
+    # repeated launches reuse the flag buffer
+    mm.set_kernel("mfma")
+    for _ in range(5):
+        mm.matmul(da, db, out=c1)
+    assert torch.equal(c1, ref) and mm.streamk_timeouts() == 0
+    # switch it off: same bits from the plain launch
+    mm.set_streamk(False)
+    assert torch.equal(mm.matmul(da, db), ref)
+    mm.set_streamk(True)
 
 
 def test_accumulate_and_overwrite_semantics(mm, oracle):
@@ -215,7 +253,7 @@ def test_unaligned_pointers_take_the_guarded_path(mm, oracle):
     assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_small"])
 def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
     """Every operand only 4-byte aligned, odd lda/ldb/ldc, ragged m/n/k, with
     poison around the matrices: the descriptor-bounded path must neither read

@@ -21,13 +21,30 @@ def ramp():
 
 
 def time_f32(m, n, k, kernel="mfma", reps=20):
-    mm.set_kernel(kernel)
+    if kernel == "rocblas":
+        return time_rocblas(m, n, k, reps)
+    H.lib().mmh_set_kernel(mm._h, H.KERNELS[kernel] if kernel in H.KERNELS else int(kernel))
     a = torch.rand((m, k), device="cuda") * 2 - 1
     b = torch.rand((k, n), device="cuda") * 2 - 1
     c = torch.empty((m, n), device="cuda")
     ms = mm.time_sgemm(m, n, k, a.data_ptr(), k, b.data_ptr(), n, c.data_ptr(), n, warmup=5, reps=reps,
                        stream=stream)
     return 2.0 * m * n * k / (ms * 1e-3) / 1e12
+
+
+def time_rocblas(m, n, k, reps=20):
+    a = torch.rand((m, k), device="cuda") * 2 - 1
+    b = torch.rand((k, n), device="cuda") * 2 - 1
+    c = torch.empty((m, n), device="cuda")
+    for _ in range(5):
+        mm.matmul_rocblas(a, b, out=c)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        mm.matmul_rocblas(a, b, out=c)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * m * n * k / (e0.elapsed_time(e1) / reps * 1e-3) / 1e12
 
 
 def time_i8(m, n, k, reps=20):
@@ -58,6 +75,11 @@ if "sweep" in what:
     for n in range(1024, 4097, 256):
         print(f"fp32 N={n}: mfma {time_f32(n, n, n):7.1f}  mfma256 {time_f32(n, n, n, 'mfma256'):7.1f}  "
               f"valu {time_f32(n, n, n, 'valu'):7.1f} TFLOP/s")
+if "tiles" in what:
+    ks = ["mfma", "mfma256", "mfma_small", "auto", "rocblas"]
+    print("N      " + "  ".join(f"{k:>8}" for k in ks))
+    for n in range(1024, 4097, 128):
+        print(f"{n:5d}  " + "  ".join(f"{time_f32(n, n, n, k, reps=10):8.1f}" for k in ks), flush=True)
 if "big" in what:
     for n in (8192, 16384):
         print(f"fp32 N={n}: mfma {time_f32(n, n, n, reps=5):7.1f}  mfma256 {time_f32(n, n, n, 'mfma256', reps=5):7.1f}")
