@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--n", type=int, default=0, help="override the square size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sweep / probes extras")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="run the multi-GPU code path (process group, broadcast, all_reduce) even with one rank")
     return ap.parse_args()
 
 
@@ -108,16 +110,20 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_shard
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     mm = H.MMult(local_rank, args.kernel)
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    if world == 1:
+    if not sharded:
         n = args.n or 4096
         m = n
         row0, rows = 0, n
@@ -142,17 +148,17 @@ def main():
     c = torch.empty((rows, n), device=dev)
 
     bcast_ms = 0.0
-    if world > 1:
+    if sharded:
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sh.broadcast_b(b, src=0)
+        sh.broadcast_b(b, src=0, always=True)
         torch.cuda.synchronize()
         dist.barrier()
         bcast_ms = (time.perf_counter() - t0) * 1e3
         # second broadcast = steady-state cost without communicator warm-up
         t0 = time.perf_counter()
-        sh.broadcast_b(b, src=0)
+        sh.broadcast_b(b, src=0, always=True)
         torch.cuda.synchronize()
         dist.barrier()
         bcast_ms = min(bcast_ms, (time.perf_counter() - t0) * 1e3)
@@ -227,48 +233,52 @@ def main():
             "pct_of_fp32_mfma_peak": round(100.0 * gflops / (world * PEAK_FP32_MFMA_TFLOPS * 1e3), 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": pmc_traffic(n) if world == 1 else None,
+                         "traffic": pmc_traffic(n) if not sharded else None,
                          "kernel": "sgemm_mfma_kernel<128,128>" if args.kernel == "mfma" else args.kernel,
                          "kernel_ms": round(kern_ms, 4),
                          "algorithmic_flops_per_launch": launch_flops,
                          "algorithmic_bytes_per_launch": 4.0 * (rows * n + n * n + rows * n)},
         }
-        if world > 1:
+        if sharded:
             out["bcast_ms"] = round(bcast_ms, 3)
             out["bcast_gbps"] = round(4.0 * n * n / (bcast_ms * 1e-3) / 1e9, 1) if bcast_ms else None
             out["value_incl_bcast"] = round(2.0 * m * n * n * 1e-9 / ((ms_per_step + bcast_ms) * 1e-3), 1)
-        if world == 1 and not args.no_extras:
+        if not sharded and not args.no_extras:
             extras = {}
+            # configs[1]/[2]: the square sweep at the BASELINE sizes, LDS-tiled VALU kernel
+            # (K1), the MFMA kernel as shipped (AUTO: tile choice + stream-K) and rocBLAS
             sweep = {}
-            for kern in ("valu", "mfma", "mfma256"):
-                mm.set_kernel(kern)
-                for p in (1024, 2048, 4096):
+            for kern in ("valu", "auto", "rocblas"):
+                if kern != "rocblas":
+                    mm.set_kernel(kern)
+                for p in (1024, 2048, 3072, 4096):
                     if p > n:
                         continue
                     pa, pb = a[:p, :p].contiguous(), b[:p, :p].contiguous()
                     pc = torch.empty((p, p), device=dev)
-                    ms = mm.time_sgemm(p, p, p, pa.data_ptr(), p, pb.data_ptr(), p, pc.data_ptr(), p,
-                                       warmup=2, reps=20, stream=stream)
+                    if kern == "rocblas":
+                        try:
+                            for _ in range(3):
+                                mm.matmul_rocblas(pa, pb, out=pc)
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            for _ in range(20):
+                                mm.matmul_rocblas(pa, pb, out=pc)
+                            e1.record()
+                            torch.cuda.synchronize()
+                            ms = e0.elapsed_time(e1) / 20
+                        except H.MMultError:
+                            continue
+                    else:
+                        ms = mm.time_sgemm(p, p, p, pa.data_ptr(), p, pb.data_ptr(), p, pc.data_ptr(), p,
+                                           warmup=3, reps=20, stream=stream)
                     sweep[f"{kern}_{p}"] = round(2.0 * p ** 3 * 1e-9 / (ms * 1e-3), 1)
             mm.set_kernel(args.kernel)
             extras["sweep_gflops"] = sweep
-            try:
-                ref = torch.empty_like(c)
-                mm.matmul_rocblas(a, b, out=ref)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(10):
-                    mm.matmul_rocblas(a, b, out=ref)
-                e1.record()
-                torch.cuda.synchronize()
-                extras["rocblas_gflops"] = round(2.0 * n ** 3 * 1e-9 / (e0.elapsed_time(e1) / 10 * 1e-3), 1)
-            except H.MMultError as e:
-                extras["rocblas_gflops"] = f"unavailable: {e}"
             extras["probe_mfma_f32_tflops"] = round(mm.probe_mfma_f32(), 1)
             extras["probe_hbm_copy_gbps"] = round(mm.probe_hbm_copy(1 << 30), 1)
             out["extras"] = extras
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
     mm.close()
     if dist:

@@ -15,26 +15,226 @@
 // and of one B column.  Because both operands use the same lane->k mapping,
 // correctness does not depend on how the hardware numbers the k's inside.
 //
-// Packing: A rows are k-contiguous in memory, so the A slice is staged as-is
-// (As[m][k], 80-byte row pitch).  B is n-contiguous, so the stage transposes
-// 4x4 byte blocks in registers and stores Bt[n][k].  Column interleave
-// (tile u covers columns {n0+4j+u}) makes the epilogue a 16-byte store.
+// Two kernels:
+//  * igemm_s8_kernel   (K3): 128x128 tile, 4 waves x (4x4 MFMA tiles), K-slices
+//    of 128 bytes double-buffered in LDS, global loads one slice ahead in
+//    registers, slice hand-over pipelined across the barrier (as K2 does for
+//    fp32).  A rows are k-contiguous in memory and go to LDS as they are; B is
+//    n-contiguous, so each thread transposes 4(k) x 16(n) bytes with v_perm_b32
+//    and stores one dword (4 k's) per column into Bt[n][k].  Both LDS images
+//    are [row][128 B] with the 16-byte slot XOR-swizzled by (row>>1)&7, which
+//    makes the ds_read_b128 fragment reads conflict-free (two 128-B rows share
+//    a 256-B bank row; 16-lane service groups then hit 16 distinct slots); the
+//    B image orders its rows u-major (row = (n&3)*32 + n/4) so that the
+//    column-interleaved tiles {n0+4j+u} -- which make the epilogue a 16-byte
+//    store -- still read consecutive rows.  Reads are bounded by buffer
+//    descriptors: rows >= m of A and rows >= k of B come back as 0, and
+//    garbage * 0 == 0 exactly in integers, so ANY m, n, k works unmasked.
+//    Needs lda, ldb multiples of 4 and 4-byte-aligned A, B.
+//  * igemm_s8_simple_kernel: the correctness-first version (single buffer, byte
+//    loads at the edges) kept for operands that are not 4-byte aligned.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 namespace mmh {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// --------------------------------------------------------------------------
+// K3
+// --------------------------------------------------------------------------
+constexpr int IK = 128;            // k bytes per LDS slice (two 64-deep MFMA steps)
+constexpr int ITILE = 128 * IK;    // bytes of one operand image
+
+// 4x4 byte transpose: rows r0..r3 (4 bytes each) -> columns c0..c3
+__device__ __forceinline__ void transpose4x4_bytes(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3,
+                                                   uint32_t (&c)[4]) {
+  // v_perm_b32(hi, lo, sel): result byte i = byte sel[i] of the 8-byte {hi:lo}
+  const uint32_t t0 = __builtin_amdgcn_perm(r1, r0, 0x05010400);  // r0.0 r1.0 r0.1 r1.1
+  const uint32_t t1 = __builtin_amdgcn_perm(r3, r2, 0x05010400);  // r2.0 r3.0 r2.1 r3.1
+  const uint32_t t2 = __builtin_amdgcn_perm(r1, r0, 0x07030602);  // r0.2 r1.2 r0.3 r1.3
+  const uint32_t t3 = __builtin_amdgcn_perm(r3, r2, 0x07030602);  // r2.2 r3.2 r2.3 r3.3
+  c[0] = __builtin_amdgcn_perm(t1, t0, 0x05040100);               // r0.0 r1.0 r2.0 r3.0
+  c[1] = __builtin_amdgcn_perm(t1, t0, 0x07060302);               // r0.1 r1.1 r2.1 r3.1
+  c[2] = __builtin_amdgcn_perm(t3, t2, 0x05040100);
+  c[3] = __builtin_amdgcn_perm(t3, t2, 0x07060302);
+}
+
+template <bool EDGE>
+__global__ void __launch_bounds__(256, 2)
+igemm_s8_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
+                const int8_t *__restrict__ B, int ldb, int32_t *__restrict__ C, int ldc,
+                int accumulate, int nbm, int nbn) {
+  constexpr int BM = 128, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) int8_t ilds[];   // 2 x (A image | B image) = 64 KiB
+
+  const int tile = blockIdx.x;
+  const int tm = tile / nbn, tn = tile % nbn;
+  const int row0 = tm * BM, col0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, g = lane >> 4;
+
+  const int rows_valid = EDGE ? min(BM, m - row0) : BM;
+  const int cols_valid = EDGE ? min(BN, n - col0) : BN;
+  const bool whole_c = !EDGE || (rows_valid == BM && cols_valid == BN);
+  const int crow = row0 + wm * 64 + 4 * g;     // + 16 t + r
+  const int ccol = col0 + wn * 64 + 4 * li;    // .. +3 (u)
+  typedef int c_vec_u __attribute__((ext_vector_type(4), aligned(4)));
+  using c_vec = std::conditional_t<EDGE, c_vec_u, i32x4>;
+
+  i32x4 acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = crow + 16 * t + r;
+      i32x4 v = {0, 0, 0, 0};
+      if (accumulate) {
+        if (whole_c) {
+          v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
+        } else if (row < m) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (ccol + u < n) v[u] = C[(size_t)row * ldc + ccol + u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u][r] = v[u];
+    }
+
+  // ---- staging (per thread: 4 x 16 B of A, 4 x 16 B of B per slice) ----
+  const uint32_t ext_a = (uint32_t)((rows_valid - 1) * lda + k);
+  const uint32_t ext_b = (uint32_t)((k - 1) * ldb + cols_valid);
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int8_t *>(A + (size_t)row0 * lda), 0, ext_a, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(B + col0), 0, ext_b, 0x00020000);
+  const int a_row = tid >> 3, a_ch = tid & 7;        // A: rows a_row + 32 p, 16-byte chunk a_ch
+  const int b_nb = tid & 7, b_kb = tid >> 3;         // B: columns 16 b_nb.., k rows 4 b_kb..+3
+  const uint32_t voff_a = (uint32_t)(a_row * lda + 16 * a_ch);
+  const uint32_t voff_b = (uint32_t)(4 * b_kb * ldb + 16 * b_nb);
+  i32x4 sa[4], sb[4];
+  auto stage_load = [&](int kt) {
+    const int k0 = kt * IK;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      sa[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a, k0 + 32 * p * lda, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      sb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, voff_b, (k0 + j) * ldb, 0);
+  };
+  auto stage_store = [&](int8_t *buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = a_row + 32 * p;
+      *reinterpret_cast<i32x4 *>(buf + row * IK + 16 * (a_ch ^ ((row >> 1) & 7))) = sa[p];
+    }
+    // B: dword q of the four loaded k-rows holds columns 16 b_nb + 4q .. +3
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t col[4];
+      transpose4x4_bytes((uint32_t)sb[0][q], (uint32_t)sb[1][q], (uint32_t)sb[2][q], (uint32_t)sb[3][q], col);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int nloc = 16 * b_nb + 4 * q + c;                 // column inside the tile
+        const int prow = (nloc & 3) * 32 + (nloc >> 2);          // u-major row of the B image
+        const int slot = (b_kb >> 2) ^ ((prow >> 1) & 7);
+        *reinterpret_cast<uint32_t *>(buf + ITILE + prow * IK + 16 * slot + 4 * (b_kb & 3)) = col[c];
+      }
+    }
+  };
+  // fragment reads for MFMA step s (0/1) of a slice
+  const int swz = (li >> 1) & 7;
+  auto frag_a = [&](const int8_t *buf, int s, int t) {
+    const int row = wm * 64 + 16 * t + li;
+    return *reinterpret_cast<const i32x4 *>(buf + row * IK + 16 * ((4 * s + g) ^ swz));
+  };
+  auto frag_b = [&](const int8_t *buf, int s, int u) {
+    const int prow = u * 32 + wn * 16 + li;
+    return *reinterpret_cast<const i32x4 *>(buf + ITILE + prow * IK + 16 * ((4 * s + g) ^ swz));
+  };
+
+  const int nk = (k + IK - 1) / IK;
+  i32x4 fa[2][4], fb[2][4];
+  if (nk > 0) {
+    stage_load(0);
+    stage_store(ilds);
+    if (nk > 1) stage_load(1);
+  }
+  __syncthreads();
+  if (nk > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { fa[0][t] = frag_a(ilds, 0, t); fb[0][t] = frag_b(ilds, 0, t); }
+  }
+  int cur = 0;
+  auto slice = [&](int kt, auto more_c, auto more2_c) {
+    constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
+    const int8_t *buf = ilds + cur * 2 * ITILE;
+    int8_t *nxt = ilds + (cur ^ 1) * 2 * ITILE;
+    // step 0: prefetch step 1's fragments, write the next slice to LDS, MFMAs
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { fa[1][t] = frag_a(buf, 1, t); fb[1][t] = frag_b(buf, 1, t); }
+    if (MORE) stage_store(nxt);
+    if (MORE2) stage_load(kt + 2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[0][t], fb[0][u], acc[t][u], 0, 0, 0);
+    // hand-over: step 1's fragments are in registers; barrier; prefetch the next
+    // slice's step 0; step 1's MFMAs cover that LDS latency
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (MORE) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { fa[0][t] = frag_a(nxt, 0, t); fb[0][t] = frag_b(nxt, 0, t); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[1][t], fb[1][u], acc[t][u], 0, 0, 0);
+    cur ^= 1;
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) slice(kt, T{}, T{});
+  if (kt + 1 < nk) { slice(kt, T{}, F{}); ++kt; }
+  if (kt < nk) slice(kt, F{}, F{});
+
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = crow + 16 * t + r;
+      i32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+      if (whole_c) {
+        *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + ccol) = v;
+      } else if (row < m) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
+      }
+    }
+}
+
+// --------------------------------------------------------------------------
+// The correctness-first kernel (any alignment).
+// --------------------------------------------------------------------------
 constexpr int IBK = 64;      // k bytes per LDS slice
 constexpr int IPITCH = 80;   // LDS row pitch in bytes (64 + 16 pad, 16-B aligned)
 
 template <bool EDGE>
 __global__ void __launch_bounds__(256)
-igemm_s8_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
-                const int8_t *__restrict__ B, int ldb, int32_t *__restrict__ C, int ldc,
-                int accumulate, int nbm, int nbn) {
+igemm_s8_simple_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
+                       const int8_t *__restrict__ B, int ldb, int32_t *__restrict__ C, int ldc,
+                       int accumulate, int nbm, int nbn) {
   constexpr int BM = 128, BN = 128;
   __shared__ __attribute__((aligned(16))) int8_t lds[(BM + BN) * IPITCH];
   int8_t *As = lds, *Bt = lds + BM * IPITCH;
@@ -146,21 +346,38 @@ igemm_s8_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
     }
 }
 
-inline void launch_igemm_s8(int m, int n, int k, const int8_t *A, int lda, const int8_t *B,
-                            int ldb, int32_t *C, int ldc, int acc, hipStream_t s) {
+inline hipError_t launch_igemm_s8(int m, int n, int k, const int8_t *A, int lda, const int8_t *B,
+                                  int ldb, int32_t *C, int ldc, int acc, hipStream_t s,
+                                  bool force_simple = false) {
   const int nbm = (m + 127) / 128, nbn = (n + 127) / 128;
-  const bool fast = (m % 128 == 0) && (n % 128 == 0) && (k % IBK == 0) && (lda % 16 == 0) &&
-                    (ldb % 4 == 0) && (ldc % 4 == 0) &&
+  dim3 grid((unsigned)(nbm * nbn)), block(256);
+  const bool shape_ok = (m % 128 == 0) && (n % 128 == 0);
+  const bool a4 = (lda % 4 == 0) && (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 3) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(B) & 3) == 0);
+  const size_t lim = (1ull << 31) - 4096;
+  const bool window_ok = ((size_t)128 * lda + k) < lim && ((size_t)k * ldb + 128) < lim;
+  if (a4 && window_ok && !force_simple) {
+    constexpr size_t lds = 4 * ITILE;   // 64 KiB
+    const bool fast = shape_ok && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    if (fast)
+      hipLaunchKernelGGL(igemm_s8_kernel<false>, grid, block, lds, s, m, n, k, A, lda, B, ldb, C, ldc,
+                         acc, nbm, nbn);
+    else
+      hipLaunchKernelGGL(igemm_s8_kernel<true>, grid, block, lds, s, m, n, k, A, lda, B, ldb, C, ldc,
+                         acc, nbm, nbn);
+    return hipGetLastError();
+  }
+  const bool fast = shape_ok && (k % IBK == 0) && (lda % 16 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) &&
                     ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(B) & 3) == 0) &&
                     ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-  dim3 grid((unsigned)(nbm * nbn)), block(256);
   if (fast)
-    hipLaunchKernelGGL(igemm_s8_kernel<false>, grid, block, 0, s, m, n, k, A, lda, B, ldb, C, ldc,
-                       acc, nbm, nbn);
+    hipLaunchKernelGGL(igemm_s8_simple_kernel<false>, grid, block, 0, s, m, n, k, A, lda, B, ldb, C,
+                       ldc, acc, nbm, nbn);
   else
-    hipLaunchKernelGGL(igemm_s8_kernel<true>, grid, block, 0, s, m, n, k, A, lda, B, ldb, C, ldc,
-                       acc, nbm, nbn);
+    hipLaunchKernelGGL(igemm_s8_simple_kernel<true>, grid, block, 0, s, m, n, k, A, lda, B, ldb, C,
+                       ldc, acc, nbm, nbn);
+  return hipGetLastError();
 }
 
 }  // namespace mmh

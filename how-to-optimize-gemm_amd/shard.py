@@ -24,14 +24,14 @@ class RowPanelShard:
         self.row0, self.rows = api.shard_rows(m, world, rank)
 
     # -- the single exchange step ---------------------------------------------
-    def broadcast_b(self, b, src: int = 0, chunks: int = 1):
+    def broadcast_b(self, b, src: int = 0, chunks: int = 1, always: bool = False):
         """Replicate B (k x n) from `src` to every rank, in place.  `b` must be an
         allocated (k, n) tensor on every rank (contents only matter on src).
         chunks > 1 splits the broadcast along k so that a caller can overlap the
         first GEMM K-slices with the tail of the transfer; the default is the
         single collective the design calls for."""
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not always:     # `always`: exercise the collective on one rank (tests)
             return b
         if chunks <= 1:
             dist.broadcast(b, src=src)

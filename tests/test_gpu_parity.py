@@ -316,7 +316,8 @@ def test_int8_bit_exact(mm, oracle):
     integer triple loop."""
     import torch
     rng = np.random.default_rng(2026)
-    for (m, n, k) in [(128, 128, 64), (256, 384, 512), (100, 90, 70), (129, 130, 131), (1024, 1024, 1024)]:
+    for (m, n, k) in [(128, 128, 64), (256, 384, 512), (100, 92, 72), (129, 132, 136), (100, 90, 70),
+                      (129, 130, 131), (128, 128, 128), (384, 256, 1000), (1024, 1024, 1024)]:
         a = rng.integers(-127, 128, (m, k), dtype=np.int8)
         b = rng.integers(-127, 128, (k, n), dtype=np.int8)
         got = mm.igemm_s8(dev(a), dev(b)).cpu().numpy()
