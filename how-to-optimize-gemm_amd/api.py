@@ -28,7 +28,7 @@ KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_256, KERNEL_NAIVE, KERNEL_MFM
 OPT_STREAMK, OPT_STREAMK_TIMEOUTS = 1, 2
 KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
-           "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_small": KERNEL_MFMA_SMALL, "mfma_tiles": 10}
+           "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_small": KERNEL_MFMA_SMALL, "mfma_tiles": 10, "mfma_128x64": 8}
 
 # every symbol include/mmult_hip.h declares (tests assert the .so exports them all)
 EXPORTS = [
@@ -36,7 +36,8 @@ EXPORTS = [
     "mmh_create", "mmh_destroy", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name",
     "mmh_set_option", "mmh_get_option",
     "mmh_sgemm", "mmh_sgemm_host", "mmh_igemm_s8", "mmh_sgemm_rocblas", "mmh_shard_rows",
-    "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_probe_mfma_f32", "mmh_probe_hbm_copy",
+    "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
+    "mmh_probe_hbm_copy",
 ]
 
 
@@ -110,6 +111,7 @@ def lib() -> C.CDLL:
                                     vp, C.c_int, C.c_int, fp]
     L.mmh_time_sgemm.argtypes = gemm + [C.c_int, C.c_int, vp, fp]
     L.mmh_probe_mfma_f32.argtypes = [vp, fp]
+    L.mmh_probe_mfma_i8.argtypes = [vp, fp]
     L.mmh_probe_hbm_copy.argtypes = [vp, C.c_size_t, fp]
     _lib = L
     return L
@@ -155,7 +157,7 @@ class MMult:
     """One handle = one device + the selected kernel variant (the reference's
     cublasHandle_t lifetime, cuda/test_MMult.cpp:43-44,142)."""
 
-    def __init__(self, device: int = 0, kernel="mfma"):
+    def __init__(self, device: int = 0, kernel="auto"):
         self._h = C.c_void_p(None)
         _check(lib().mmh_create(C.byref(self._h), device), "mmh_create")
         self.device = device
@@ -320,6 +322,11 @@ class MMult:
     def probe_mfma_f32(self) -> float:
         v = C.c_float(0)
         _check(lib().mmh_probe_mfma_f32(self._h, C.byref(v)), "mmh_probe_mfma_f32")
+        return v.value
+
+    def probe_mfma_i8(self) -> float:
+        v = C.c_float(0)
+        _check(lib().mmh_probe_mfma_i8(self._h, C.byref(v)), "mmh_probe_mfma_i8")
         return v.value
 
     def probe_hbm_copy(self, nbytes: int = 1 << 30) -> float:

@@ -185,6 +185,16 @@ igemm_s8_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[0][t], fb[0][u], acc[t][u], 0, 0, 0);
+    // Pipeline description for the scheduler (as in K2): the 8 fragment reads of
+    // step 1 up front, then the 20 LDS stores and 8 global loads dealt out between
+    // the 16 MFMAs instead of in bursts.
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // DS read
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // MFMA
+      if (MORE && i < 10) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);               // DS write
+      if (MORE2 && i >= 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // VMEM read
+    }
     // hand-over: step 1's fragments are in registers; barrier; prefetch the next
     // slice's step 0; step 1's MFMAs cover that LDS latency
     __builtin_amdgcn_sched_barrier(0);

@@ -65,7 +65,7 @@ struct DevBuf {
 
 struct mmh_context {
   int device = 0;
-  int kernel = MMH_KERNEL_MFMA;
+  int kernel = MMH_KERNEL_AUTO;
   int cu_count = 0;
   DevBuf a, b, c;          // staging for the host-pointer flavour
   DevBuf flags;            // stream-K per-tile hand-off flags (+1 error word)
@@ -94,14 +94,14 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // SIMPLE: the un-pipelined rung.  SCHED / BUFLD / ABL: see sgemm_mfma.hpp.  The
 // buffer-descriptor path needs every byte offset inside a 2 GiB window; larger
 // operands fall back to 64-bit global addressing (same kernel, BUFLD = false).
-template <int BM, int BN, bool SIMPLE = false, int SCHED = 4, int ABL = 0, bool BUFLD = true>
+template <int BM, int BN, bool SIMPLE = false, int SCHED = 4, int ABL = 0, bool BUFLD = true, int WTN = 4>
 int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, int ldb,
                 float *C, int ldc, int acc, hipStream_t s) {
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
   const bool fast = (m % BM == 0) && (n % BN == 0) && (k % mmh::BK == 0) && (lda % 4 == 0) &&
                     (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(A) && aligned16(B) &&
                     aligned16(C);
-  constexpr int threads = BM * BN / (64 * 64) * 64;
+  constexpr int threads = (BM / 64) * (BN / (16 * WTN)) * 64;
   constexpr size_t lds = lds_bytes(BM, BN);
   dim3 grid((unsigned)(nbm * nbn)), block(threads);
   const size_t lim = (1ull << 31) - 4096;
@@ -119,24 +119,24 @@ int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, in
   } else if (!fast) {
     // guarded launch: buffer descriptors bound the reads (any alignment >= 4 B);
     // operands larger than the descriptor window use the per-element path
-    if (BUFLD && window_ok) MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, true>));
-    else                    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, false>));
+    if (BUFLD && window_ok) MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, true, WTN>));
+    else                    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, false, WTN>));
   } else if (BUFLD && window_ok) {
-    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, BUFLD>));
+    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, BUFLD, WTN>));
   } else {
-    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, false>));
+    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, false, WTN>));
   }
 #undef MMH_LAUNCH
   HIP_TRY(hipGetLastError());
   return MMH_OK;
 }
 
-// Persistent chained stream-K launch of the 128x128 kernel (sgemm_mfma.hpp, K2p).
-// Returns MMH_OK if it launched, 1 if the shape does not qualify (caller then
-// uses the plain one-tile-per-workgroup launch).
+// Persistent chained stream-K launch (sgemm_mfma.hpp, K2p) of tile config
+// <BM, BN, WTN>.  Returns MMH_OK if it launched, 1 if the shape does not qualify
+// (caller then uses the plain one-tile-per-workgroup launch).
+template <int BM, int BN, int WTN>
 int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, int lda,
                        const float *B, int ldb, float *C, int ldc, int acc, hipStream_t s) {
-  constexpr int BM = 128, BN = 128;
   if (!ctx || !ctx->streamk) return 1;
   if ((m % BM) || (n % BN) || (k % mmh::BK) || (lda % 4) || (ldb % 4) || !aligned16(A) || !aligned16(B))
     return 1;
@@ -148,9 +148,21 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
   const int nbm = m / BM, nbn = n / BN;
   const long tiles = (long)nbm * nbn;
   const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+  auto kern = mmh::sgemm_mfma_streamk_kernel<BM, BN, false, WTN>;
+  constexpr size_t lds = lds_bytes(BM, BN);
+  constexpr int threads = (BM / 64) * (BN / (16 * WTN)) * 64;
+  // resident workgroups per CU: what the runtime reports, never more than LDS allows
+  static int per_cu = [&] {
+    int v = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, threads, lds) != hipSuccess || v < 1) v = 1;
+    const int by_lds = (int)((160 * 1024) / lds);
+    return v < by_lds ? v : by_lds;
+  }();
+  // the largest grid (whole CUs' worth of workgroups) that still gives every
+  // workgroup at least one full tile, so that chains never stall
   int grid = 0;
-  if (tiles >= 2L * cus) grid = 2 * cus;      // two workgroups per CU (64 KiB LDS each)
-  else if (tiles >= cus) grid = cus;          // one per CU
+  for (int w = per_cu; w >= 1; --w)
+    if (tiles >= (long)w * cus) { grid = w * cus; break; }
   if (grid == 0 || tiles % grid == 0) return 1;   // too few tiles, or already balanced
   if (tiles > (1L << 24)) return 1;
   int rc = ctx->flags.reserve((size_t)(tiles + 1) * sizeof(int));
@@ -158,9 +170,7 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
   int *flags = static_cast<int *>(ctx->flags.p);
   ctx->flags_tiles = tiles;
   HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(tiles + 1) * sizeof(int), s));
-  auto kern = mmh::sgemm_mfma_streamk_kernel<BM, BN, false>;
-  constexpr size_t lds = lds_bytes(BM, BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
                      acc, nbm, nbn, flags, flags + tiles);
   HIP_TRY(hipGetLastError());
   return MMH_OK;
@@ -254,23 +264,34 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
     case MMH_KERNEL_MFMA_SMALL:
       return launch_mfma_small(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case MMH_KERNEL_AUTO: {
-      // fewer 128x128 tiles than a quarter of the CUs: the 64x64 kernel fills more of the chip
+      // Tile choice by how well the shape fills 256 CUs (measured, tools/misc_bench.py
+      // tiles): with fewer 128x128 tiles than ~0.8 per CU the 128x64 configuration
+      // (twice the workgroups, 94 % of the per-tile efficiency) wins; with fewer than 64
+      // of those the 64x64 kernel; everything else is K2 (+ stream-K when ragged).
+      const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
       const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
-      if (tiles128 <= 64) return launch_mfma_small(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      const long tiles128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);
+      if (tiles128x64 < 64) return launch_mfma_small(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (tiles128 * 10 < cus * 8) {
+        const int sk = try_launch_streamk<128, 64, 2>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+        if (sk <= 0) return sk;
+        return launch_mfma<128, 64, false, 4, 0, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      }
     }  // fall through
     case MMH_KERNEL_MFMA: {
       // ragged tile counts go to the persistent stream-K launch (same arithmetic,
       // same bits); everything else is one workgroup per tile
-      const int sk = try_launch_streamk(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      const int sk = try_launch_streamk<128, 128, 4>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
       if (sk <= 0) return sk;
       return launch_mfma<128, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     }
     case MMH_KERNEL_MFMA_TILES:   // K2 without stream-K (one workgroup per tile, always)
       return launch_mfma<128, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
-    case 8:   // 128x64 tile, 2 waves
-      return launch_mfma<128, 64>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
-    case 9:   // 64x64 tile, 1 wave
-      return launch_mfma<64, 64>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_MFMA_128X64: {   // 128x64 tile, 4 waves of 64x32
+      const int sk = try_launch_streamk<128, 64, 2>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      return launch_mfma<128, 64, false, 4, 0, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    }
     // Ablation builds of the shipping kernel (TIMING ONLY -- results are wrong):
     // 32 no global loads, 33 + no LDS stores, 34 + no barrier, 35 + no fragment reads.
     case 32:
@@ -422,8 +443,7 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_PIPE: return "MMult_hip_mfma_pipe";
     case MMH_KERNEL_MFMA_SMALL: return "MMult_hip_mfma_small";
     case MMH_KERNEL_MFMA_TILES: return "MMult_hip_mfma_tiles";
-    case 8: return "MMult_hip_mfma_128x64";
-    case 9: return "MMult_hip_mfma_64x64";
+    case MMH_KERNEL_MFMA_128X64: return "MMult_hip_mfma_128x64";
     case 32: return "ablate_no_gload";
     case 33: return "ablate_no_gload_no_ldswrite";
     case 34: return "ablate_no_gload_no_ldswrite_no_barrier";
@@ -566,6 +586,12 @@ int mmh_probe_mfma_f32(mmh_handle_t h, float *tflops) {
   if (!h || !tflops) return MMH_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
   return mmh::probe_mfma_f32(h->cu_count, tflops, &g_last_error);
+}
+
+int mmh_probe_mfma_i8(mmh_handle_t h, float *tops) {
+  if (!h || !tops) return MMH_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  return mmh::probe_mfma_i8(h->cu_count, tops, &g_last_error);
 }
 
 int mmh_probe_hbm_copy(mmh_handle_t h, size_t bytes, float *gbps) {

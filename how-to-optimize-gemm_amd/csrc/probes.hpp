@@ -72,6 +72,47 @@ inline int probe_mfma_f32(int cu_count, float *tflops, std::string *err) {
   return MMH_OK;
 }
 
+// int8 twin: v_mfma_i32_16x16x64_i8 only (what K3 issues), 8 accumulators per wave
+typedef int pi32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) probe_mfma_i8_kernel(int *out, int iters, int seed) {
+  pi32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = pi32x4{seed, seed, seed, seed};
+  const pi32x4 a = {seed + (int)threadIdx.x, seed, 1, 2}, b = {seed, 3, (int)threadIdx.x, 4};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[i], 0, 0, 0);
+  }
+  pi32x4 s = acc[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) s += acc[i];
+  if (s[0] + s[1] + s[2] + s[3] == 123456789) out[0] = s[0];
+}
+
+inline int probe_mfma_i8(int cu_count, float *tops, std::string *err) {
+  if (cu_count <= 0) cu_count = 256;
+  int *d = nullptr;
+  MMH_HIP_TRY(hipMalloc(&d, 64), err);
+  const int iters = 40000, blocks = cu_count * 2;
+  hipEvent_t t0, t1;
+  MMH_HIP_TRY(hipEventCreate(&t0), err);
+  MMH_HIP_TRY(hipEventCreate(&t1), err);
+  hipLaunchKernelGGL(probe_mfma_i8_kernel, dim3(blocks), dim3(256), 0, 0, d, 4000, 1);
+  MMH_HIP_TRY(hipEventRecord(t0, 0), err);
+  hipLaunchKernelGGL(probe_mfma_i8_kernel, dim3(blocks), dim3(256), 0, 0, d, iters, 1);
+  MMH_HIP_TRY(hipEventRecord(t1, 0), err);
+  MMH_HIP_TRY(hipEventSynchronize(t1), err);
+  float ms = 0.f;
+  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
+  const double ops = (double)blocks * 4 * iters * 8.0 * (2.0 * 16 * 16 * 64);
+  *tops = (float)(ops / (ms * 1e-3) / 1e12);
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  (void)hipFree(d);
+  return MMH_OK;
+}
+
 // -------------------------------------------------------------- HBM probe --
 __global__ void __launch_bounds__(256) probe_copy_kernel(const f32x4 *__restrict__ src,
                                                          f32x4 *__restrict__ dst, size_t n) {

@@ -163,7 +163,7 @@ sgemm_mfma_simple_kernel(int m, int n, int k, const float *__restrict__ A, int l
 // Arithmetic order per C element is unchanged (ascending k), so the result is
 // bit-identical to the simple kernel and to the fmaf-chain oracle.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool EDGE, int SCHED, int ABL, bool BUFLD>
+template <int BM, int BN, bool EDGE, int SCHED, int ABL, bool BUFLD, int WTN = 4>
 __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int k,
                                                   const float *__restrict__ A, int lda,
                                                   const float *__restrict__ B, int ldb,
@@ -172,10 +172,16 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   // One C tile (tm, tn), K-slices [kb, ke) of it.  init_from_c: the accumulators
   // start from C's current value (accumulate mode, or the continuation of a
   // chain another workgroup began -- stream-K below); the tile is stored at the end.
-  constexpr int WAVES_N = BN / 64;
-  constexpr int THREADS = BM * BN / (64 * 64) * 64;
+  // WTN = MFMA tiles per wave along n: 4 -> 64x64 wave tiles (16-byte B fragments),
+  // 2 -> 64x32 wave tiles (8-byte B fragments, twice the waves per block tile)
+  static_assert(WTN == 4 || WTN == 2, "wave tile is 64x64 or 64x32");
+  constexpr int WAVES_N = BN / (16 * WTN);
+  constexpr int THREADS = (BM / 64) * WAVES_N * 64;
   constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * BN, BUF = A_FLOATS + B_FLOATS;
   constexpr int KS = BK / 4;
+  constexpr int MK = 4 * WTN;          // MFMAs per k-step and wave
+  using StageT = Stage<BM, BN, THREADS, WTN == 2>;
+  typedef float bfrag_t __attribute__((ext_vector_type(WTN)));
   const int row0 = tm * BM, col0 = tn * BN;
 
   const int tid = threadIdx.x;
@@ -184,46 +190,47 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 15, kq = lane >> 4;
   const int crow = row0 + wm * 64 + 16 * kq;
-  const int ccol = col0 + wn * 64 + 4 * li;
+  const int ccol = col0 + wn * 16 * WTN + WTN * li;
 
   // a guarded launch still uses 16-byte C accesses in its interior blocks; there
   // the pointer may be only 4-byte aligned, which the type must say
-  typedef float c_vec_u __attribute__((ext_vector_type(4), aligned(4)));
-  using c_vec = std::conditional_t<EDGE, c_vec_u, f32x4>;
+  typedef float c_vec_u __attribute__((ext_vector_type(WTN), aligned(4)));
+  using c_vec = std::conditional_t<EDGE, c_vec_u, bfrag_t>;
   const bool whole_c = !EDGE || (row0 + BM <= m && col0 + BN <= n);
-  f32x4 acc[4][4];
+  f32x4 acc[4][WTN];
   if (init_from_c) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = crow + 4 * r + t;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        bfrag_t v = {};
         if (whole_c) {
           v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
         } else if (row < m) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < WTN; ++u)
             if (ccol + u < n) v[u] = C[(size_t)row * ldc + ccol + u];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[t][u][r] = v[u];
+        for (int u = 0; u < WTN; ++u) acc[t][u][r] = v[u];
       }
   } else {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < WTN; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  Stage<BM, BN, THREADS> st;
+  StageT st;
   const int nk = (k + BK - 1) / BK;
   const int a_slot = wm * 16 + li;
-  const int b_off = A_FLOATS + kq * BN + wn * 64 + 4 * li;
+  const int b_off = A_FLOATS + kq * BN + wn * 64 + 4 * li;   // WTN == 4
+  const int b_slot = wn * 8 + (li >> 1);                        // WTN == 2
 
   // buffer descriptors (BUFLD): wave-uniform bases, 4 GiB window each
   __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
-  uint32_t voff_a[Stage<BM, BN, THREADS>::A_BLKS], voff_b = 0;
+  uint32_t voff_a[StageT::A_BLKS], voff_b = 0;
   // EDGE + BUFLD: the descriptors' extents end at the last valid element of this
   // block's A rows / B columns, so the hardware's per-dword range check zeroes
   // rows >= m of A and rows >= k of B for free (probed on gfx950:
@@ -257,10 +264,16 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
     return *reinterpret_cast<const f32x4 *>(buf + (4 * ks + kq) * BM + 4 * (a_slot ^ swz_slot(ks)));
   };
   auto frag_b = [&](const float *buf, int ks) {
-    return *reinterpret_cast<const f32x4 *>(buf + b_off + 4 * ks * BN);
+    if constexpr (WTN == 4) {
+      return *reinterpret_cast<const bfrag_t *>(buf + b_off + 4 * ks * BN);
+    } else {
+      return *reinterpret_cast<const bfrag_t *>(buf + A_FLOATS + (4 * ks + kq) * BN +
+                                                4 * (b_slot ^ ((kq & 1) << 3)) + 2 * (li & 1));
+    }
   };
 
-  f32x4 fa[2], fb[2];
+  f32x4 fa[2];
+  bfrag_t fb[2];
   if (ke > kb) {
     stage_load(kb);
     st.store(lds, lds + A_FLOATS, tid);
@@ -304,7 +317,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      constexpr int NMEM = Stage<BM, BN, THREADS>::A_BLKS * 4 + Stage<BM, BN, THREADS>::B_VECS;
+      constexpr int NMEM = StageT::A_BLKS * 4 + StageT::B_VECS;
       static_assert(8 + 2 * NMEM <= 56, "staging ops do not fit in the pre-barrier MFMA shadow");
       constexpr bool HAVE_STORE = MORE && !(ABL & 2), HAVE_LOAD = MORE2 && !(ABL & 1);
       // source position of the staging ops: stores at k-step 1; loads where their
@@ -312,11 +325,12 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
       constexpr int KS_LOAD = SCHED == 4 ? (8 + NMEM) / 8 : (SCHED == 2 ? 4 : 2);
       if (ks == 1 && HAVE_STORE) st.store(nxt, nxt + A_FLOATS, tid);
       if (ks == KS_LOAD && HAVE_LOAD) stage_load((ABL & 16) ? (kt & 1) : kt + 2);
-      const f32x4 a = fa[ks & 1], b = fb[ks & 1];
+      const f32x4 a = fa[ks & 1];
+      const bfrag_t b = fb[ks & 1];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < WTN; ++u)
           acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
       // SCHED 1..3: pin the k-step order (reads for ks+1 and the shadow memory
       // ops stay inside the k-step whose 16 MFMAs cover them)
@@ -332,14 +346,14 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
 #pragma unroll
           for (int jp = 0; jp < 8; ++jp) {
             const int pr = 8 * ks + jp;
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                       // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, MK / 8, 0);                  // MFMA
             if (HAVE_STORE && pr >= 8 && pr < 8 + NMEM)
               __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                     // DS write
             if (HAVE_LOAD && pr >= 8 + NMEM && pr < 8 + 2 * NMEM)
               __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // VMEM read
           }
         } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MK, 0);
         }
       }
     };
@@ -366,12 +380,14 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = crow + 4 * r + t;
-      f32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+      bfrag_t v;
+#pragma unroll
+      for (int u = 0; u < WTN; ++u) v[u] = acc[t][u][r];
       if (whole_c) {
         *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + ccol) = v;
       } else if (row < m) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < WTN; ++u)
           if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
       }
     }
@@ -379,15 +395,15 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
 
 
 // The shipping kernel: one workgroup per C tile (XCD-aware block -> tile map).
-template <int BM, int BN, bool EDGE, int SCHED = 0, int ABL = 0, bool BUFLD = false>
-__global__ void __launch_bounds__(BM * BN / (64 * 64) * 64, 2)  // 2 waves/SIMD: <= 256 VGPR+AGPR
+template <int BM, int BN, bool EDGE, int SCHED = 0, int ABL = 0, bool BUFLD = false, int WTN = 4>
+__global__ void __launch_bounds__((BM / 64) * (BN / (16 * WTN)) * 64, 2)  // >= 2 waves/SIMD
 sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                   const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                   int accumulate, int nbm, int nbn) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int tm, tn;
   block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
-  mfma_tile_segment<BM, BN, EDGE, SCHED, ABL, BUFLD>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0,
+  mfma_tile_segment<BM, BN, EDGE, SCHED, ABL, BUFLD, WTN>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0,
                                                      (k + BK - 1) / BK, accumulate != 0);
 }
 
@@ -411,8 +427,8 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 // relaxed flag store; consumer = one lane relaxed poll (bounded), agent-scope
 // acquire fence, barrier, plain loads.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool EDGE>
-__global__ void __launch_bounds__(BM * BN / (64 * 64) * 64, 2)
+template <int BM, int BN, bool EDGE, int WTN = 4>
+__global__ void __launch_bounds__((BM / 64) * (BN / (16 * WTN)) * 64, 2)
 sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                           const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                           int accumulate, int nbm, int nbn, int *__restrict__ flags,
@@ -441,7 +457,7 @@ sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
     int tm, tn;
     tile_of(t, tm, tn);
     __syncthreads();   // LDS is reused from segment to segment
-    mfma_tile_segment<BM, BN, EDGE, 4, 0, true>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke,
+    mfma_tile_segment<BM, BN, EDGE, 4, 0, true, WTN>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke,
                                                 from_c);
   };
   const bool has_tail = k_first != 0;                       // tile t_first, slices [k_first, nk)

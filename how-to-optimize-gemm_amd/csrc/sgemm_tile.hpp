@@ -68,7 +68,10 @@ __device__ __forceinline__ void block_to_tile(int bid, int nblk, int nbm, int nb
 // THREADS threads.  Each thread owns A_BLKS 4x4 blocks of A and B_VECS float4
 // of B.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int THREADS>
+// B_HALFSWAP: the B image is read with 8-byte fragments (64x32 wave tiles); odd
+// k-rows then store their two 32-float halves swapped (slot bit 3 flipped) so that
+// the kq = 0 and kq = 1 lanes of a ds_read_b64 half hit different banks.
+template <int BM, int BN, int THREADS, bool B_HALFSWAP = false>
 struct Stage {
   static constexpr int A_BLKS = (BM / 4) * (BK / 4) / THREADS;  // 4x4 blocks per thread
   static constexpr int B_VECS = BK * (BN / 4) / THREADS;        // float4 per thread
@@ -197,8 +200,11 @@ struct Stage {
     const int cb = tid % (BN / 4);
     const int kr = tid / (BN / 4);
 #pragma unroll
-    for (int v = 0; v < B_VECS; ++v)
-      *reinterpret_cast<f32x4 *>(Bs + (kr + v * B_ROWS_PER_PASS) * BN + 4 * cb) = b[v];
+    for (int v = 0; v < B_VECS; ++v) {
+      const int row = kr + v * B_ROWS_PER_PASS;
+      const int slot = B_HALFSWAP ? (cb ^ ((row & 1) << 3)) : cb;
+      *reinterpret_cast<f32x4 *>(Bs + row * BN + 4 * slot) = b[v];
+    }
   }
 };
 

@@ -73,6 +73,7 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_PIPE 6   /* K2b': + K-slice hand-over pipelined across the barrier, but
                                     compiler-scheduled staging and 64-bit global loads      */
 #define MMH_KERNEL_MFMA_TILES 10 /* K2 always as one workgroup per tile (no stream-K), for A/B      */
+#define MMH_KERNEL_MFMA_128X64 8 /* K2 with a 128x64 block tile, 4 waves of 64x32                   */
 #define MMH_KERNEL_MFMA_SMALL 7  /* K2s: 64x64 block tile, 4 waves of 32x32, for small problems   */
 /* ids >= 32 are timing-only ablation builds (tools/ab_bench.py); their results are invalid. */
 
@@ -160,6 +161,7 @@ int mmh_time_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, in
 /* Peak probes: sustained fp32 MFMA TFLOP/s (v_mfma_f32_16x16x4_f32 only, no
  * memory traffic) and HBM copy GB/s (float4 stream copy, read+write bytes). */
 int mmh_probe_mfma_f32(mmh_handle_t handle, float *tflops);
+int mmh_probe_mfma_i8(mmh_handle_t handle, float *tops);   /* v_mfma_i32_16x16x64_i8 only */
 int mmh_probe_hbm_copy(mmh_handle_t handle, size_t bytes, float *gbps);
 
 #ifdef __cplusplus

@@ -19,7 +19,7 @@ from conftest import golden_cases, load_golden
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["mfma", "mfma256", "mfma_small", "auto", "mfma_pipe", "mfma_simple", "valu", "naive"]
+KERNELS = ["mfma", "mfma256", "mfma_128x64", "mfma_small", "auto", "mfma_pipe", "mfma_simple", "valu", "naive"]
 
 
 def tol(k):
@@ -77,7 +77,7 @@ SHAPES = [(256, 256, 256), (384, 640, 1024), (128, 128, 32), (128, 256, 4096), (
           (130, 129, 37), (3, 5, 7), (257, 255, 513), (512, 128, 2048), (1024, 1024, 1024)]
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_small", "valu"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_128x64", "mfma_small", "valu"])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_seeded_inputs_vs_oracle(mm, oracle, shape, kernel):
     m, n, k = shape
@@ -253,7 +253,7 @@ def test_unaligned_pointers_take_the_guarded_path(mm, oracle):
     assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_small"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_128x64", "mfma_small"])
 def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
     """Every operand only 4-byte aligned, odd lda/ldb/ldc, ragged m/n/k, with
     poison around the matrices: the descriptor-bounded path must neither read

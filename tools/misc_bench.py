@@ -65,6 +65,7 @@ def time_i8(m, n, k, reps=20):
 ramp()
 what = sys.argv[1:] or ["i8", "edge", "sweep"]
 if "i8" in what:
+    print(f"int8 MFMA-only probe: {mm.probe_mfma_i8():8.1f} TOPS")
     for n in (1024, 2048, 4096, 8192):
         print(f"int8 N={n}: {time_i8(n, n, n):8.1f} TOPS")
 if "edge" in what:
@@ -76,7 +77,7 @@ if "sweep" in what:
         print(f"fp32 N={n}: mfma {time_f32(n, n, n):7.1f}  mfma256 {time_f32(n, n, n, 'mfma256'):7.1f}  "
               f"valu {time_f32(n, n, n, 'valu'):7.1f} TFLOP/s")
 if "tiles" in what:
-    ks = ["mfma", "mfma256", "mfma_small", "auto", "rocblas"]
+    ks = ["mfma", "mfma_128x64", "mfma_small", "auto", "rocblas"]
     print("N      " + "  ".join(f"{k:>8}" for k in ks))
     for n in range(1024, 4097, 128):
         print(f"{n:5d}  " + "  ".join(f"{time_f32(n, n, n, k, reps=10):8.1f}" for k in ks), flush=True)
