@@ -86,6 +86,20 @@ def test_null_handle_is_an_error_not_a_crash():
     assert L.mmh_set_kernel(None, 2) == H.ERR_INVALID_ARG
 
 
+def test_options_and_kernel_ids_validate_without_a_device():
+    L = H.lib()
+    v = ctypes.c_int(0)
+    assert L.mmh_set_option(None, H.OPT_STREAMK, 1) == H.ERR_INVALID_ARG
+    assert L.mmh_get_option(None, H.OPT_STREAMK, ctypes.byref(v)) == H.ERR_INVALID_ARG
+    for name, kid in H.KERNELS.items():
+        assert H.kernel_name(kid) is not None, name
+    # the header's kernel ids and the Python mirror agree
+    text = open(os.path.join(REPO, "include", "mmult_hip.h")).read()
+    ids = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define MMH_KERNEL_(\w+) (\d+)", text)}
+    for name, kid in ids.items():
+        assert H.KERNELS[{"mfma_256": "mfma256"}.get(name, name)] == kid, name
+
+
 def test_no_device_fails_loudly_without_fallback():
     """On a box without a gfx950 GPU the product path must refuse, not
     compute on the CPU."""
