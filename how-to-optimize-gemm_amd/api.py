@@ -35,7 +35,8 @@ EXPORTS = [
     "mmh_strerror", "mmh_last_error", "mmh_version", "mmh_device_count", "mmh_device_info",
     "mmh_create", "mmh_destroy", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name",
     "mmh_set_option", "mmh_get_option",
-    "mmh_sgemm", "mmh_sgemm_host", "mmh_igemm_s8", "mmh_sgemm_rocblas", "mmh_shard_rows",
+    "mmh_sgemm", "mmh_sgemm_host", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
+    "mmh_sgemm_rocblas", "mmh_shard_rows",
     "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
     "mmh_probe_hbm_copy",
 ]
@@ -106,6 +107,8 @@ def lib() -> C.CDLL:
     L.mmh_sgemm_host.argtypes = gemm + [C.c_int]
     L.mmh_igemm_s8.argtypes = gemm + [C.c_int, vp]
     L.mmh_sgemm_rocblas.argtypes = gemm + [vp]
+    L.mmh_qgemm_f32.argtypes = gemm + [vp]
+    L.mmh_quantize_sym_s8.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp]
     L.mmh_shard_rows.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
     L.mmh_sgemm_sharded.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int,
                                     vp, C.c_int, C.c_int, fp]
@@ -293,6 +296,32 @@ class MMult:
         stream = torch.cuda.current_stream(a.device).cuda_stream
         _check(lib().mmh_igemm_s8(self._h, m, n, k, pa, lda, pb, ldb, pc, ldc, int(accumulate), stream),
                "mmh_igemm_s8")
+        return out
+
+    def quantize_sym_s8(self, x):
+        """fp32 CUDA tensor -> (int8 tensor in [-127,127], scale as a 1-element CUDA tensor)."""
+        import torch
+        rows, cols = x.shape
+        q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
+        scale = torch.empty(1, dtype=torch.float32, device=x.device)
+        px, ldx = self._tensor_args(x, rows, cols, "quantize(X)")
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(lib().mmh_quantize_sym_s8(self._h, rows, cols, px, ldx, q.data_ptr(), max(cols, 1),
+                                         scale.data_ptr(), stream), "mmh_quantize_sym_s8")
+        return q, scale
+
+    def qgemm(self, a, b, out=None):
+        """C_f32 = dequantise(quantise(A) @ quantise(B)): chgemm-style symmetric int8 GEMM."""
+        import torch
+        m, k = a.shape
+        _, n = b.shape
+        if out is None:
+            out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        pa, lda = self._tensor_args(a, m, k, "qgemm(A)")
+        pb, ldb = self._tensor_args(b, k, n, "qgemm(B)")
+        pc, ldc = self._tensor_args(out, m, n, "qgemm(C)")
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        _check(lib().mmh_qgemm_f32(self._h, m, n, k, pa, lda, pb, ldb, pc, ldc, stream), "mmh_qgemm_f32")
         return out
 
     def matmul_rocblas(self, a, b, out=None):

@@ -107,8 +107,11 @@ igemm_s8_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
     }
 
   // ---- staging (per thread: 4 x 16 B of A, 4 x 16 B of B per slice) ----
-  const uint32_t ext_a = (uint32_t)((rows_valid - 1) * lda + k);
-  const uint32_t ext_b = (uint32_t)((k - 1) * ldb + cols_valid);
+  // extents in bytes, rounded up to whole dwords: the range check is per DWORD, so a
+  // byte-exact extent would zero the last valid bytes of the last row (lda, ldb are
+  // multiples of 4 here, so the round-up stays inside the row)
+  const uint32_t ext_a = (uint32_t)((rows_valid - 1) * lda + ((k + 3) & ~3));
+  const uint32_t ext_b = (uint32_t)((k - 1) * ldb + ((cols_valid + 3) & ~3));
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<int8_t *>(A + (size_t)row0 * lda), 0, ext_a, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b =

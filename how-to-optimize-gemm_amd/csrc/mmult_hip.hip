@@ -20,6 +20,7 @@
 
 #include "igemm_s8.hpp"
 #include "probes.hpp"
+#include "quant_s8.hpp"
 #include "sgemm_mfma.hpp"
 #include "sgemm_mfma_small.hpp"
 #include "sgemm_valu.hpp"
@@ -68,6 +69,7 @@ struct mmh_context {
   int kernel = MMH_KERNEL_AUTO;
   int cu_count = 0;
   DevBuf a, b, c;          // staging for the host-pointer flavour
+  DevBuf qa, qb, qc, qs;   // quantised GEMM workspace: int8 A, int8 B, int32 C, {amax bits, scales}
   DevBuf flags;            // stream-K per-tile hand-off flags (+1 error word)
   long flags_tiles = -1;   // where the error word of the last stream-K launch sits
   int streamk = 1;         // allow the persistent stream-K launch for ragged tile counts
@@ -292,6 +294,12 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       if (sk <= 0) return sk;
       return launch_mfma<128, 64, false, 4, 0, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     }
+    case 16:   // staging cadence A/B: one op per 3 / 4 MFMAs instead of 2
+      return launch_mfma<128, 128, false, 5>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 17:
+      return launch_mfma<128, 128, false, 6>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 18:
+      return launch_mfma<128, 128, false, 7>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     // Ablation builds of the shipping kernel (TIMING ONLY -- results are wrong):
     // 32 no global loads, 33 + no LDS stores, 34 + no barrier, 35 + no fragment reads.
     case 32:
@@ -388,6 +396,10 @@ int mmh_destroy(mmh_handle_t h) {
   h->b.release();
   h->c.release();
   h->flags.release();
+  h->qa.release();
+  h->qb.release();
+  h->qc.release();
+  h->qs.release();
   mmh::rocblas_release(h->rocblas);
   delete h;
   return MMH_OK;
@@ -444,6 +456,9 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_SMALL: return "MMult_hip_mfma_small";
     case MMH_KERNEL_MFMA_TILES: return "MMult_hip_mfma_tiles";
     case MMH_KERNEL_MFMA_128X64: return "MMult_hip_mfma_128x64";
+    case 16: return "cadence_3";
+    case 17: return "cadence_4";
+    case 18: return "cadence_1";
     case 32: return "ablate_no_gload";
     case 33: return "ablate_no_gload_no_ldswrite";
     case 34: return "ablate_no_gload_no_ldswrite_no_barrier";
@@ -505,6 +520,61 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
     return MMH_OK;
   }
   HIP_TRY(mmh::launch_igemm_s8(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
+  return MMH_OK;
+}
+
+int mmh_quantize_sym_s8(mmh_handle_t h, int rows, int cols, const float *dX, int ldx, int8_t *dQ,
+                        int ldq, float *d_scale, void *stream) {
+  if (!h || rows < 0 || cols < 0) return MMH_ERR_INVALID_ARG;
+  if (rows == 0 || cols == 0) return MMH_OK;
+  if (!dX || !dQ || !d_scale || ldx < cols || ldq < cols) return MMH_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = h->qs.reserve(64);
+  if (rc != MMH_OK) return rc;
+  unsigned *amax = static_cast<unsigned *>(h->qs.p) + 8;   // scratch word for stand-alone calls
+  HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), s));
+  const unsigned g = mmh::quant_grid((size_t)rows * cols);
+  hipLaunchKernelGGL(mmh::absmax_kernel, dim3(g), dim3(256), 0, s, dX, rows, cols, ldx, amax);
+  hipLaunchKernelGGL(mmh::quantize_kernel, dim3(g), dim3(256), 0, s, dX, rows, cols, ldx, amax, dQ, ldq,
+                     d_scale);
+  HIP_TRY(hipGetLastError());
+  return MMH_OK;
+}
+
+int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, const float *dB,
+                  int ldb, float *dC, int ldc, void *stream) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
+  if (rc != MMH_OK) return rc;
+  if (m == 0 || n == 0) return MMH_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k == 0) {
+    HIP_TRY(hipMemset2DAsync(dC, (size_t)ldc * 4, 0, (size_t)n * 4, (size_t)m, s));
+    return MMH_OK;
+  }
+  // dense, 16-byte-friendly workspace images: int8 A (m x ka), int8 B (k x nb), int32 C (m x nb)
+  const int ka = (k + 15) & ~15, nb = (n + 3) & ~3;
+  if ((rc = h->qa.reserve((size_t)m * ka)) != MMH_OK) return rc;
+  if ((rc = h->qb.reserve((size_t)k * nb)) != MMH_OK) return rc;
+  if ((rc = h->qc.reserve((size_t)m * nb * sizeof(int32_t))) != MMH_OK) return rc;
+  if ((rc = h->qs.reserve(64)) != MMH_OK) return rc;
+  int8_t *qa = static_cast<int8_t *>(h->qa.p), *qb = static_cast<int8_t *>(h->qb.p);
+  int32_t *qc = static_cast<int32_t *>(h->qc.p);
+  unsigned *amax = static_cast<unsigned *>(h->qs.p);        // [0] A, [1] B
+  float *scales = reinterpret_cast<float *>(amax + 2);      // [0] A, [1] B
+  HIP_TRY(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), s));
+  const unsigned ga = mmh::quant_grid((size_t)m * k), gb = mmh::quant_grid((size_t)k * n);
+  hipLaunchKernelGGL(mmh::absmax_kernel, dim3(ga), dim3(256), 0, s, dA, m, k, lda, amax);
+  hipLaunchKernelGGL(mmh::absmax_kernel, dim3(gb), dim3(256), 0, s, dB, k, n, ldb, amax + 1);
+  hipLaunchKernelGGL(mmh::quantize_kernel, dim3(ga), dim3(256), 0, s, dA, m, k, lda, amax, qa, ka, scales);
+  hipLaunchKernelGGL(mmh::quantize_kernel, dim3(gb), dim3(256), 0, s, dB, k, n, ldb, amax + 1, qb, nb,
+                     scales + 1);
+  HIP_TRY(mmh::launch_igemm_s8(m, n, k, qa, ka, qb, nb, qc, nb, 0, s));
+  hipLaunchKernelGGL(mmh::dequantize_kernel, dim3(mmh::quant_grid((size_t)m * n)), dim3(256), 0, s, qc, m,
+                     n, nb, scales, scales + 1, dC, ldc);
+  HIP_TRY(hipGetLastError());
   return MMH_OK;
 }
 

@@ -318,11 +318,16 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
         __builtin_amdgcn_sched_barrier(0);
       }
       constexpr int NMEM = StageT::A_BLKS * 4 + StageT::B_VECS;
-      static_assert(8 + 2 * NMEM <= 56, "staging ops do not fit in the pre-barrier MFMA shadow");
       constexpr bool HAVE_STORE = MORE && !(ABL & 2), HAVE_LOAD = MORE2 && !(ABL & 1);
       // source position of the staging ops: stores at k-step 1; loads where their
       // slots begin in the SCHED-4 pipeline (k-step 2 for the other schedules)
-      constexpr int KS_LOAD = SCHED == 4 ? (8 + NMEM) / 8 : (SCHED == 2 ? 4 : 2);
+      // SCHED >= 4: one staging op per SP MFMAs (SCHED 4 -> 2, 5 -> 3, 6 -> 4, 7 -> 1), counted
+      // in units of MK/16 MFMAs so that 64x32 wave tiles (MK = 8) keep the same cadence
+      constexpr int SP = SCHED == 5 ? 3 : (SCHED == 6 ? 4 : (SCHED == 7 ? 1 : 2));
+      constexpr int UNIT = MK / 16 > 0 ? MK / 16 : 1;     // MFMAs per scheduling unit
+      constexpr int UPK = MK / UNIT;                       // units per k-step (16, or 8 for MK = 8)
+      static_assert((2 * NMEM) * SP <= 6 * UPK, "staging ops do not fit in the pre-barrier MFMA shadow");
+      constexpr int KS_LOAD = SCHED >= 4 ? 1 + ((NMEM + 1) * SP - 1) / UPK : (SCHED == 2 ? 4 : 2);
       if (ks == 1 && HAVE_STORE) st.store(nxt, nxt + A_FLOATS, tid);
       if (ks == KS_LOAD && HAVE_LOAD) stage_load((ABL & 16) ? (kt & 1) : kt + 2);
       const f32x4 a = fa[ks & 1];
@@ -335,22 +340,24 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
       // SCHED 1..3: pin the k-step order (reads for ks+1 and the shadow memory
       // ops stay inside the k-step whose 16 MFMAs cover them)
       if (SCHED >= 1 && SCHED <= 3) __builtin_amdgcn_sched_barrier(0);
-      // SCHED 4: describe the slice to the scheduler as a pipeline.  Number the
-      // MFMA pairs of k-steps 0..6 p = 0..55: every k-step opens with its two
-      // fragment prefetches; pairs 8..8+NMEM-1 are each followed by ONE LDS store
-      // of the next slice, pairs 8+NMEM..8+2*NMEM-1 by ONE global load of the slice
-      // after next -- staging ops dealt out one per two MFMAs instead of in bursts.
-      if (SCHED == 4) {
+      // SCHED >= 4: describe the slice to the scheduler as a pipeline.  Every k-step
+      // opens with its two fragment prefetches; from k-step 1 on, every SP-th unit of
+      // MFMAs is followed by ONE staging op -- first the NMEM LDS stores of the next
+      // slice, then the NMEM global loads of the slice after next -- instead of the
+      // bursts of 6-8 the scheduler would otherwise emit.
+      if (SCHED >= 4) {
         if (ks + 1 < KS || MORE) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
         if (ks + 1 < KS) {
 #pragma unroll
-          for (int jp = 0; jp < 8; ++jp) {
-            const int pr = 8 * ks + jp;
-            __builtin_amdgcn_sched_group_barrier(0x008, MK / 8, 0);                  // MFMA
-            if (HAVE_STORE && pr >= 8 && pr < 8 + NMEM)
-              __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                     // DS write
-            if (HAVE_LOAD && pr >= 8 + NMEM && pr < 8 + 2 * NMEM)
-              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     // VMEM read
+          for (int i = 0; i < UPK; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, UNIT, 0);                    // MFMA
+            const int j = UPK * ks + i - UPK;                // unit index counted from k-step 1
+            if (j >= 0 && (j + 1) % SP == 0) {
+              const int op = (j + 1) / SP - 1;
+              if (HAVE_STORE && op < NMEM) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+              if (HAVE_LOAD && op >= NMEM && op < 2 * NMEM)
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                             // VMEM read
+            }
           }
         } else {
           __builtin_amdgcn_sched_group_barrier(0x008, MK, 0);

@@ -130,6 +130,17 @@ int mmh_igemm_s8(mmh_handle_t handle, int m, int n, int k, const int8_t *dA, int
                  const int8_t *dB, int ldb, int32_t *dC, int ldc, int accumulate,
                  void *stream);
 
+/* The callers either side of the int8 GEMM (chgemm's contract as the
+ * reference README.md:71-85 words it; parity unpinned -- no reference code):
+ *   mmh_quantize_sym_s8: q = clamp(rint(x * s), -127, 127), s = 127 / max|x| written to
+ *                        *d_scale (device float); rows x cols windows with leading dims.
+ *   mmh_qgemm_f32      : C_f32 = dequant( quant(A) * quant(B) ), per-tensor symmetric
+ *                        scales, int32 accumulation, C = acc * (1 / (sa * sb)). */
+int mmh_quantize_sym_s8(mmh_handle_t handle, int rows, int cols, const float *dX, int ldx,
+                        int8_t *dQ, int ldq, float *d_scale, void *stream);
+int mmh_qgemm_f32(mmh_handle_t handle, int m, int n, int k, const float *dA, int lda,
+                  const float *dB, int ldb, float *dC, int ldc, void *stream);
+
 /* Vendor comparator (rocBLAS sgemm, row-major via the swapped-operand trick
  * of cuda/MMult_cuBLAS_1.cpp:17-18).  MMH_ERR_UNSUPPORTED if librocblas
  * cannot be loaded. */

@@ -317,7 +317,8 @@ def test_int8_bit_exact(mm, oracle):
     import torch
     rng = np.random.default_rng(2026)
     for (m, n, k) in [(128, 128, 64), (256, 384, 512), (100, 92, 72), (129, 132, 136), (100, 90, 70),
-                      (129, 130, 131), (128, 128, 128), (384, 256, 1000), (1024, 1024, 1024)]:
+                      (129, 130, 131), (128, 128, 128), (384, 256, 1000), (200, 150, 90), (131, 258, 66),
+                      (1024, 1024, 1024)]:
         a = rng.integers(-127, 128, (m, k), dtype=np.int8)
         b = rng.integers(-127, 128, (k, n), dtype=np.int8)
         got = mm.igemm_s8(dev(a), dev(b)).cpu().numpy()
@@ -334,6 +335,30 @@ def test_int8_bit_exact(mm, oracle):
     out = dev(c0)
     mm.igemm_s8(dev(a), dev(b), out=out, accumulate=True)
     assert np.array_equal(out.cpu().numpy(), oracle.ref_igemm_s8(a, b, c0.copy()))
+
+
+def test_quantised_gemm_end_to_end(mm, oracle):
+    """quantise -> int8 GEMM -> dequantise, against the CPU restatement of the
+    same contract (parity unpinned: the reference has only prose for it)."""
+    import torch
+    rng = np.random.default_rng(77)
+    for (m, n, k) in [(128, 128, 128), (200, 150, 90), (512, 384, 1000)]:
+        a = rng.uniform(-2, 2, (m, k)).astype(np.float32)
+        b = rng.uniform(-0.5, 0.5, (k, n)).astype(np.float32)
+        qa, sa = mm.quantize_sym_s8(dev(a))
+        qa_ref, sa_ref = oracle.quantize_sym_s8(a)
+        assert float(sa) == np.float32(sa_ref)
+        assert np.array_equal(qa.cpu().numpy(), qa_ref)
+        assert int(qa.min()) >= -127 and int(qa.abs().max()) == 127
+        got = mm.qgemm(dev(a), dev(b)).cpu().numpy()
+        qb_ref, sb_ref = oracle.quantize_sym_s8(b)
+        acc = oracle.ref_igemm_s8(qa_ref, qb_ref)
+        inv = np.float32(1.0) / (np.float32(sa_ref) * np.float32(sb_ref))
+        want = acc.astype(np.float32) * inv
+        assert np.array_equal(got, want), (m, n, k)
+        # and it approximates the fp32 product to quantisation accuracy
+        exact = a.astype(np.float64) @ b.astype(np.float64)
+        assert np.abs(got - exact).max() <= 0.02 * np.abs(exact).max() + 0.05
 
 
 def test_int8_headline_4096(mm):
