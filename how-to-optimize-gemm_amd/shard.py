@@ -49,6 +49,30 @@ class RowPanelShard:
             return c_panel
         return gemm(a_panel, b, c_panel)
 
+    # -- exchange overlapped with compute ---------------------------------------------
+    def gemm_with_streamed_b(self, gemm: Callable, a_panel, b, c_panel, src: int = 0, chunks: int = 8,
+                             always: bool = False):
+        """The same product with B's broadcast hidden behind the GEMM: B travels in
+        `chunks` K-chunks (asynchronous broadcasts, RCCL's own stream) while the
+        chunks that have already landed are consumed,
+            C  = A[:, k0:k1] @ B[k0:k1]        (first chunk, overwrite)
+            C += A[:, k1:k2] @ B[k1:k2] ...    (accumulate: C's value continues each chain)
+        Every C element is still one chain over ascending k, so the result is
+        bit-identical to broadcast-then-GEMM.  `gemm(a, b, out, accumulate)`."""
+        import torch.distributed as dist
+        step = -(-self.k // max(chunks, 1))
+        step = max(32, (step + 31) // 32 * 32)             # whole K-slices per chunk
+        bounds = [(k0, min(k0 + step, self.k)) for k0 in range(0, self.k, step)]
+        works = []
+        if self.world > 1 or always:
+            works = [dist.broadcast(b[k0:k1], src=src, async_op=True) for (k0, k1) in bounds]
+        for i, (k0, k1) in enumerate(bounds):
+            if works:
+                works[i].wait()                            # orders the current stream after chunk i
+            if self.rows:
+                gemm(a_panel[:, k0:k1], b[k0:k1], c_panel, i > 0)
+        return c_panel
+
     # -- verification helper (tests / smoke only; not on the hot path) ----------
     def gather_c(self, c_panel, like):
         """Assemble the full C on every rank (all_gather of the padded panels)."""

@@ -46,7 +46,19 @@ def _worker(rank, world, port, m, n, k, chunks, q):
         sh.local_gemm(gemm, a_panel, b, c_panel)
         full = sh.gather_c(c_panel, like=b)
         want = O.ref_mmult(a, b_full, fma=True)
-        q.put((rank, bool(np.array_equal(full.numpy(), want)), sh.row0, sh.rows))
+        ok = bool(np.array_equal(full.numpy(), want))
+
+        # the streamed form: B arrives in K-chunks, consumed with accumulate
+        def gemm_acc(x, y, out, accumulate):
+            c0 = out.numpy().copy() if accumulate else None
+            out.copy_(torch.from_numpy(O.ref_mmult(np.ascontiguousarray(x.numpy()), y.numpy(), c0, fma=True)))
+            return out
+
+        b2 = torch.from_numpy(b_full.copy()) if rank == 0 else torch.full((k, n), float("nan"))
+        c2 = torch.full((sh.rows, n), float("nan"))
+        sh.gemm_with_streamed_b(gemm_acc, a_panel, b2, c2, src=0, chunks=3)
+        ok = ok and torch.equal(b2, torch.from_numpy(b_full)) and torch.equal(c2, c_panel)
+        q.put((rank, ok, sh.row0, sh.rows))
     finally:
         dist.destroy_process_group()
 
