@@ -24,11 +24,11 @@ LIB_PATH = os.path.join(PKG_DIR, "libmmult_hip.so")
 
 # status codes / kernel ids (include/mmult_hip.h)
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALLOC, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
-KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_256, KERNEL_NAIVE, KERNEL_MFMA_SIMPLE, KERNEL_MFMA_PIPE, KERNEL_MFMA_SMALL = 0, 1, 2, 3, 4, 5, 6, 7
+KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_256, KERNEL_NAIVE, KERNEL_MFMA_SIMPLE, KERNEL_MFMA_PIPE = 0, 1, 2, 3, 4, 5, 6
 OPT_STREAMK, OPT_STREAMK_TIMEOUTS = 1, 2
 KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
-           "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_small": KERNEL_MFMA_SMALL, "mfma_tiles": 10, "mfma_128x64": 8}
+           "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11}
 
 # every symbol include/mmult_hip.h declares (tests assert the .so exports them all)
 EXPORTS = [
@@ -379,6 +379,6 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
 
 
 __all__ = ["MMult", "MMultError", "lib", "device_count", "shard_rows", "kernel_name", "sgemm_sharded",
-           "KERNELS", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE", "KERNEL_MFMA_SMALL",
+           "KERNELS", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
            "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

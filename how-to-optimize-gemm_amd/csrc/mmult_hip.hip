@@ -22,7 +22,6 @@
 #include "probes.hpp"
 #include "quant_s8.hpp"
 #include "sgemm_mfma.hpp"
-#include "sgemm_mfma_small.hpp"
 #include "sgemm_valu.hpp"
 
 namespace {
@@ -78,8 +77,8 @@ struct mmh_context {
 
 namespace {
 
-constexpr size_t lds_bytes(int BM, int BN) {
-  return 2ull * (size_t)mmh::BK * (BM + BN) * sizeof(float);
+constexpr size_t lds_bytes(int BM, int BN, int KB = mmh::BK) {
+  return 2ull * (size_t)KB * (BM + BN) * sizeof(float);
 }
 
 template <typename K>
@@ -96,15 +95,16 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // SIMPLE: the un-pipelined rung.  SCHED / BUFLD / ABL: see sgemm_mfma.hpp.  The
 // buffer-descriptor path needs every byte offset inside a 2 GiB window; larger
 // operands fall back to 64-bit global addressing (same kernel, BUFLD = false).
-template <int BM, int BN, bool SIMPLE = false, int SCHED = 4, int ABL = 0, bool BUFLD = true, int WTN = 4>
+template <int BM, int BN, bool SIMPLE = false, int SCHED = 4, int ABL = 0, bool BUFLD = true, int WTN = 4,
+          int WTM = 4, int KB = mmh::BK>
 int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, int ldb,
                 float *C, int ldc, int acc, hipStream_t s) {
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
-  const bool fast = (m % BM == 0) && (n % BN == 0) && (k % mmh::BK == 0) && (lda % 4 == 0) &&
+  const bool fast = (m % BM == 0) && (n % BN == 0) && (k % KB == 0) && (lda % 4 == 0) &&
                     (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(A) && aligned16(B) &&
                     aligned16(C);
-  constexpr int threads = (BM / 64) * (BN / (16 * WTN)) * 64;
-  constexpr size_t lds = lds_bytes(BM, BN);
+  constexpr int threads = (BM / (16 * WTM)) * (BN / (16 * WTN)) * 64;
+  constexpr size_t lds = lds_bytes(BM, BN, KB);
   dim3 grid((unsigned)(nbm * nbn)), block(threads);
   const size_t lim = (1ull << 31) - 4096;
   const bool window_ok = ((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim;
@@ -121,12 +121,12 @@ int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, in
   } else if (!fast) {
     // guarded launch: buffer descriptors bound the reads (any alignment >= 4 B);
     // operands larger than the descriptor window use the per-element path
-    if (BUFLD && window_ok) MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, true, WTN>));
-    else                    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, false, WTN>));
+    if (BUFLD && window_ok) MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, true, WTN, WTM, KB>));
+    else                    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, false, WTN, WTM, KB>));
   } else if (BUFLD && window_ok) {
-    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, BUFLD, WTN>));
+    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, BUFLD, WTN, WTM, KB>));
   } else {
-    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, false, WTN>));
+    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, false, WTN, WTM, KB>));
   }
 #undef MMH_LAUNCH
   HIP_TRY(hipGetLastError());
@@ -136,11 +136,11 @@ int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, in
 // Persistent chained stream-K launch (sgemm_mfma.hpp, K2p) of tile config
 // <BM, BN, WTN>.  Returns MMH_OK if it launched, 1 if the shape does not qualify
 // (caller then uses the plain one-tile-per-workgroup launch).
-template <int BM, int BN, int WTN>
+template <int BM, int BN, int WTN, int WTM = 4, int KB = mmh::BK>
 int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, int lda,
                        const float *B, int ldb, float *C, int ldc, int acc, hipStream_t s) {
   if (!ctx || !ctx->streamk) return 1;
-  if ((m % BM) || (n % BN) || (k % mmh::BK) || (lda % 4) || (ldb % 4) || !aligned16(A) || !aligned16(B))
+  if ((m % BM) || (n % BN) || (k % KB) || (lda % 4) || (ldb % 4) || !aligned16(A) || !aligned16(B))
     return 1;
   // C tiles must own whole 128-byte lines: partial tiles travel between
   // workgroups through C and per-XCD L2s are not coherent with each other
@@ -150,9 +150,13 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
   const int nbm = m / BM, nbn = n / BN;
   const long tiles = (long)nbm * nbn;
   const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-  auto kern = mmh::sgemm_mfma_streamk_kernel<BM, BN, false, WTN>;
-  constexpr size_t lds = lds_bytes(BM, BN);
-  constexpr int threads = (BM / 64) * (BN / (16 * WTN)) * 64;
+  auto kern = mmh::sgemm_mfma_streamk_kernel<BM, BN, false, WTN, WTM, KB>;
+  constexpr size_t lds = lds_bytes(BM, BN, KB);
+  constexpr int threads = (BM / (16 * WTM)) * (BN / (16 * WTN)) * 64;
+  {
+    const int ok = allow_big_lds(kern, lds);
+    if (ok != MMH_OK) return ok;
+  }
   // resident workgroups per CU: what the runtime reports, never more than LDS allows
   static int per_cu = [&] {
     int v = 0;
@@ -174,27 +178,6 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
   HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(tiles + 1) * sizeof(int), s));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
                      acc, nbm, nbn, flags, flags + tiles);
-  HIP_TRY(hipGetLastError());
-  return MMH_OK;
-}
-
-int launch_mfma_small(int m, int n, int k, const float *A, int lda, const float *B, int ldb,
-                      float *C, int ldc, int acc, hipStream_t s) {
-  constexpr int BM = 64, BN = 64;
-  const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
-  const bool fast = (m % BM == 0) && (n % BN == 0) && (k % mmh::BK == 0) && (lda % 4 == 0) &&
-                    (ldb % 4 == 0) && (ldc % 2 == 0) && aligned16(A) && aligned16(B) &&
-                    ((reinterpret_cast<uintptr_t>(C) & 7) == 0);
-  const size_t lim = (1ull << 31) - 4096;
-  if (!(((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim))
-    return launch_mfma<128, 128>(m, n, k, A, lda, B, ldb, C, ldc, acc, s);  // 64-bit addressing lives there
-  dim3 grid((unsigned)(nbm * nbn)), block(256);
-  if (fast)
-    hipLaunchKernelGGL(mmh::sgemm_mfma_small_kernel<false>, grid, block, 0, s, m, n, k, A, lda, B, ldb,
-                       C, ldc, acc, nbm, nbn);
-  else
-    hipLaunchKernelGGL(mmh::sgemm_mfma_small_kernel<true>, grid, block, 0, s, m, n, k, A, lda, B, ldb,
-                       C, ldc, acc, nbm, nbn);
   HIP_TRY(hipGetLastError());
   return MMH_OK;
 }
@@ -263,22 +246,19 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return launch_mfma<128, 128, false, 0, 0, false>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case MMH_KERNEL_MFMA_256:
       return launch_mfma<256, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
-    case MMH_KERNEL_MFMA_SMALL:
-      return launch_mfma_small(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case MMH_KERNEL_AUTO: {
-      // Tile choice by how well the shape fills 256 CUs (measured, tools/misc_bench.py
-      // tiles): with fewer 128x128 tiles than ~0.8 per CU the 128x64 configuration
-      // (twice the workgroups, 94 % of the per-tile efficiency) wins; with fewer than 64
-      // of those the 64x64 kernel; everything else is K2 (+ stream-K when ragged).
+      // Tile choice by how well the shape fills 256 CUs (measured, profiles/r01_sweep.md):
+      // with fewer 128x128 tiles than ~0.8 per CU the 128x64 configuration (twice the
+      // workgroups, 94 % of the per-tile efficiency) wins; when even those number no more
+      // than half the CUs, the 64x64 configuration; everything else is K2.  Each choice
+      // runs as a stream-K launch when its tile count is ragged.
       const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
       const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
       const long tiles128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);
-      if (tiles128x64 < 64) return launch_mfma_small(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
-      if (tiles128 * 10 < cus * 8) {
-        const int sk = try_launch_streamk<128, 64, 2>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
-        if (sk <= 0) return sk;
-        return launch_mfma<128, 64, false, 4, 0, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
-      }
+      if (tiles128x64 * 2 <= cus)
+        return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+      if (tiles128 * 10 < cus * 8)
+        return sgemm_on(ctx, MMH_KERNEL_MFMA_128X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
     }  // fall through
     case MMH_KERNEL_MFMA: {
       // ragged tile counts go to the persistent stream-K launch (same arithmetic,
@@ -289,6 +269,11 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
     }
     case MMH_KERNEL_MFMA_TILES:   // K2 without stream-K (one workgroup per tile, always)
       return launch_mfma<128, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_MFMA_64X64: {    // 64x64 tile, 4 waves of 32x32, 128-deep K-slices
+      const int sk = try_launch_streamk<64, 64, 2, 2, 128>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      return launch_mfma<64, 64, false, 4, 0, true, 2, 2, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    }
     case MMH_KERNEL_MFMA_128X64: {   // 128x64 tile, 4 waves of 64x32
       const int sk = try_launch_streamk<128, 64, 2>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
       if (sk <= 0) return sk;
@@ -453,9 +438,9 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_NAIVE: return "MMult_hip_naive";
     case MMH_KERNEL_MFMA_SIMPLE: return "MMult_hip_mfma_simple";
     case MMH_KERNEL_MFMA_PIPE: return "MMult_hip_mfma_pipe";
-    case MMH_KERNEL_MFMA_SMALL: return "MMult_hip_mfma_small";
     case MMH_KERNEL_MFMA_TILES: return "MMult_hip_mfma_tiles";
     case MMH_KERNEL_MFMA_128X64: return "MMult_hip_mfma_128x64";
+    case MMH_KERNEL_MFMA_64X64: return "MMult_hip_mfma_64x64";
     case 16: return "cadence_3";
     case 17: return "cadence_4";
     case 18: return "cadence_1";

@@ -163,7 +163,17 @@ sgemm_mfma_simple_kernel(int m, int n, int k, const float *__restrict__ A, int l
 // Arithmetic order per C element is unchanged (ascending k), so the result is
 // bit-identical to the simple kernel and to the fmaf-chain oracle.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool EDGE, int SCHED, int ABL, bool BUFLD, int WTN = 4>
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int BM, int BN, bool EDGE, int SCHED, int ABL, bool BUFLD, int WTN = 4, int WTM = 4, int KB = BK>
 __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int k,
                                                   const float *__restrict__ A, int lda,
                                                   const float *__restrict__ B, int ldb,
@@ -174,14 +184,16 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   // chain another workgroup began -- stream-K below); the tile is stored at the end.
   // WTN = MFMA tiles per wave along n: 4 -> 64x64 wave tiles (16-byte B fragments),
   // 2 -> 64x32 wave tiles (8-byte B fragments, twice the waves per block tile)
-  static_assert(WTN == 4 || WTN == 2, "wave tile is 64x64 or 64x32");
+  // WTM likewise along m (4 -> 64 rows, 2 -> 32 rows); KB = K-slice depth per LDS buffer.
+  static_assert((WTN == 4 || WTN == 2) && (WTM == 4 || WTM == 2), "wave tile is 64|32 x 64|32");
   constexpr int WAVES_N = BN / (16 * WTN);
-  constexpr int THREADS = (BM / 64) * WAVES_N * 64;
-  constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * BN, BUF = A_FLOATS + B_FLOATS;
-  constexpr int KS = BK / 4;
-  constexpr int MK = 4 * WTN;          // MFMAs per k-step and wave
-  using StageT = Stage<BM, BN, THREADS, WTN == 2>;
+  constexpr int THREADS = (BM / (16 * WTM)) * WAVES_N * 64;
+  constexpr int A_FLOATS = KB * BM, B_FLOATS = KB * BN, BUF = A_FLOATS + B_FLOATS;
+  constexpr int KS = KB / 4;
+  constexpr int MK = WTM * WTN;        // MFMAs per k-step and wave
+  using StageT = Stage<BM, BN, THREADS, WTN == 2, WTM == 2, KB>;
   typedef float bfrag_t __attribute__((ext_vector_type(WTN)));
+  typedef float afrag_t __attribute__((ext_vector_type(WTM)));
   const int row0 = tm * BM, col0 = tn * BN;
 
   const int tid = threadIdx.x;
@@ -189,7 +201,8 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   const int wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 15, kq = lane >> 4;
-  const int crow = row0 + wm * 64 + 16 * kq;
+  // C rows/cols of this lane: row(t, r) = crow + WTM*r + t, cols ccol .. ccol+WTN-1
+  const int crow = row0 + wm * 16 * WTM + 4 * WTM * kq;
   const int ccol = col0 + wn * 16 * WTN + WTN * li;
 
   // a guarded launch still uses 16-byte C accesses in its interior blocks; there
@@ -197,13 +210,13 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   typedef float c_vec_u __attribute__((ext_vector_type(WTN), aligned(4)));
   using c_vec = std::conditional_t<EDGE, c_vec_u, bfrag_t>;
   const bool whole_c = !EDGE || (row0 + BM <= m && col0 + BN <= n);
-  f32x4 acc[4][WTN];
+  f32x4 acc[WTM][WTN];
   if (init_from_c) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < WTM; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = crow + 4 * r + t;
+        const int row = crow + WTM * r + t;
         bfrag_t v = {};
         if (whole_c) {
           v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
@@ -217,14 +230,14 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
       }
   } else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < WTM; ++t)
 #pragma unroll
       for (int u = 0; u < WTN; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   StageT st;
-  const int nk = (k + BK - 1) / BK;
-  const int a_slot = wm * 16 + li;
+  const int nk = (k + KB - 1) / KB;
+  const int a_slot = WTM == 4 ? wm * 16 + li : wm * 8 + (li >> 1);   // slot = m/4 of the fragment
   const int b_off = A_FLOATS + kq * BN + wn * 64 + 4 * li;   // WTN == 4
   const int b_slot = wn * 8 + (li >> 1);                        // WTN == 2
 
@@ -251,17 +264,22 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   }
   auto stage_load = [&](int kt) {
     if (BUFLD) {
-      st.load_buf(rsrc_a, rsrc_b, voff_a, voff_b, lda, ldb, kt * BK);
-      if (EDGE && kt == nk - 1 && (k % BK) != 0) st.mask_k_tail(k - kt * BK, tid);
+      st.load_buf(rsrc_a, rsrc_b, voff_a, voff_b, lda, ldb, kt * KB);
+      if (EDGE && kt == nk - 1 && (k % KB) != 0) st.mask_k_tail(k - kt * KB, tid);
     } else if (EDGE) {
-      st.load_edge(A, lda, B, ldb, row0, col0, kt * BK, m, n, k, tid);
+      st.load_edge(A, lda, B, ldb, row0, col0, kt * KB, m, n, k, tid);
     } else {
-      st.load(A, lda, B, ldb, row0, col0, kt * BK, tid);
+      st.load(A, lda, B, ldb, row0, col0, kt * KB, tid);
     }
   };
 
   auto frag_a = [&](const float *buf, int ks) {
-    return *reinterpret_cast<const f32x4 *>(buf + (4 * ks + kq) * BM + 4 * (a_slot ^ swz_slot(ks)));
+    if constexpr (WTM == 4) {
+      return *reinterpret_cast<const afrag_t *>(buf + (4 * ks + kq) * BM + 4 * (a_slot ^ swz_slot(ks)));
+    } else {
+      return *reinterpret_cast<const afrag_t *>(buf + (4 * ks + kq) * BM +
+                                                4 * (a_slot ^ (ks & 7) ^ ((kq & 1) << 3)) + 2 * (li & 1));
+    }
   };
   auto frag_b = [&](const float *buf, int ks) {
     if constexpr (WTN == 4) {
@@ -272,7 +290,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
     }
   };
 
-  f32x4 fa[2];
+  afrag_t fa[2];
   bfrag_t fb[2];
   if (ke > kb) {
     stage_load(kb);
@@ -318,6 +336,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
         __builtin_amdgcn_sched_barrier(0);
       }
       constexpr int NMEM = StageT::A_BLKS * 4 + StageT::B_VECS;
+      static_assert(KS >= 8, "the slice pipeline needs at least 8 k-steps");
       constexpr bool HAVE_STORE = MORE && !(ABL & 2), HAVE_LOAD = MORE2 && !(ABL & 1);
       // source position of the staging ops: stores at k-step 1; loads where their
       // slots begin in the SCHED-4 pipeline (k-step 2 for the other schedules)
@@ -326,14 +345,14 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
       constexpr int SP = SCHED == 5 ? 3 : (SCHED == 6 ? 4 : (SCHED == 7 ? 1 : 2));
       constexpr int UNIT = MK / 16 > 0 ? MK / 16 : 1;     // MFMAs per scheduling unit
       constexpr int UPK = MK / UNIT;                       // units per k-step (16, or 8 for MK = 8)
-      static_assert((2 * NMEM) * SP <= 6 * UPK, "staging ops do not fit in the pre-barrier MFMA shadow");
+      static_assert((2 * NMEM) * SP <= (KS - 2) * UPK, "staging ops do not fit in the pre-barrier MFMA shadow");
       constexpr int KS_LOAD = SCHED >= 4 ? 1 + ((NMEM + 1) * SP - 1) / UPK : (SCHED == 2 ? 4 : 2);
       if (ks == 1 && HAVE_STORE) st.store(nxt, nxt + A_FLOATS, tid);
       if (ks == KS_LOAD && HAVE_LOAD) stage_load((ABL & 16) ? (kt & 1) : kt + 2);
-      const f32x4 a = fa[ks & 1];
+      const afrag_t a = fa[ks & 1];
       const bfrag_t b = fb[ks & 1];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < WTM; ++t)
 #pragma unroll
         for (int u = 0; u < WTN; ++u)
           acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
@@ -364,15 +383,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
         }
       }
     };
-    static_assert(KS == 8, "k-steps are spelled out below");
-    kstep(std::integral_constant<int, 0>{});
-    kstep(std::integral_constant<int, 1>{});
-    kstep(std::integral_constant<int, 2>{});
-    kstep(std::integral_constant<int, 3>{});
-    kstep(std::integral_constant<int, 4>{});
-    kstep(std::integral_constant<int, 5>{});
-    kstep(std::integral_constant<int, 6>{});
-    kstep(std::integral_constant<int, 7>{});
+    static_for<KS>(kstep);
     cur ^= 1;
   };
   using T = std::true_type;
@@ -383,10 +394,10 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   if (kt < ke) slice(kt, F{}, F{});
 
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < WTM; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = crow + 4 * r + t;
+      const int row = crow + WTM * r + t;
       bfrag_t v;
 #pragma unroll
       for (int u = 0; u < WTN; ++u) v[u] = acc[t][u][r];
@@ -402,16 +413,17 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
 
 
 // The shipping kernel: one workgroup per C tile (XCD-aware block -> tile map).
-template <int BM, int BN, bool EDGE, int SCHED = 0, int ABL = 0, bool BUFLD = false, int WTN = 4>
-__global__ void __launch_bounds__((BM / 64) * (BN / (16 * WTN)) * 64, 2)  // >= 2 waves/SIMD
+template <int BM, int BN, bool EDGE, int SCHED = 0, int ABL = 0, bool BUFLD = false, int WTN = 4,
+          int WTM = 4, int KB = BK>
+__global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)  // >= 2 waves/SIMD
 sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                   const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                   int accumulate, int nbm, int nbn) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int tm, tn;
   block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
-  mfma_tile_segment<BM, BN, EDGE, SCHED, ABL, BUFLD, WTN>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0,
-                                                     (k + BK - 1) / BK, accumulate != 0);
+  mfma_tile_segment<BM, BN, EDGE, SCHED, ABL, BUFLD, WTN, WTM, KB>(
+      lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0, (k + KB - 1) / KB, accumulate != 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -434,14 +446,14 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 // relaxed flag store; consumer = one lane relaxed poll (bounded), agent-scope
 // acquire fence, barrier, plain loads.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool EDGE, int WTN = 4>
-__global__ void __launch_bounds__((BM / 64) * (BN / (16 * WTN)) * 64, 2)
+template <int BM, int BN, bool EDGE, int WTN = 4, int WTM = 4, int KB = BK>
+__global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)
 sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                           const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                           int accumulate, int nbm, int nbn, int *__restrict__ flags,
                           int *__restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int nk = (k + BK - 1) / BK;
+  const int nk = (k + KB - 1) / KB;
   const int T = nbm * nbn, G = gridDim.x;
   // XCD-contiguous ranges: workgroup p (on XCD p % 8) takes range index q
   const int xcd = blockIdx.x % NXCD, local = blockIdx.x / NXCD;
@@ -464,8 +476,8 @@ sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
     int tm, tn;
     tile_of(t, tm, tn);
     __syncthreads();   // LDS is reused from segment to segment
-    mfma_tile_segment<BM, BN, EDGE, 4, 0, true, WTN>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke,
-                                                from_c);
+    mfma_tile_segment<BM, BN, EDGE, 4, 0, true, WTN, WTM, KB>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn,
+                                                              kb, ke, from_c);
   };
   const bool has_tail = k_first != 0;                       // tile t_first, slices [k_first, nk)
   const bool has_head = k_last_end != nk && (t_last != t_first || !has_tail);

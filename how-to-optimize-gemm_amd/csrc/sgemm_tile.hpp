@@ -71,12 +71,19 @@ __device__ __forceinline__ void block_to_tile(int bid, int nblk, int nbm, int nb
 // B_HALFSWAP: the B image is read with 8-byte fragments (64x32 wave tiles); odd
 // k-rows then store their two 32-float halves swapped (slot bit 3 flipped) so that
 // the kq = 0 and kq = 1 lanes of a ds_read_b64 half hit different banks.
-template <int BM, int BN, int THREADS, bool B_HALFSWAP = false>
+// A_HALFSWAP: same for the A image when the wave tile is 32 rows high (8-byte A
+// fragments); the half flips with k & 1, i.e. with s & 1 inside a 4x4 block.
+// KB: K-slice depth staged per LDS buffer (32, or 128 for the small-tile kernel whose
+// one-wave-per-SIMD occupancy needs a longer prefetch distance).
+template <int BM, int BN, int THREADS, bool B_HALFSWAP = false, bool A_HALFSWAP = false, int KB = BK>
 struct Stage {
-  static constexpr int A_BLKS = (BM / 4) * (BK / 4) / THREADS;  // 4x4 blocks per thread
-  static constexpr int B_VECS = BK * (BN / 4) / THREADS;        // float4 per thread
+  static constexpr int CH = KB / 4;                                   // 4-float k-chunks per row
+  static constexpr int A_BLKS = (BM / 4) * CH / THREADS;              // 4x4 blocks per thread
+  static constexpr int B_VECS = KB * (BN / 4) / THREADS;              // float4 per thread
   static constexpr int B_ROWS_PER_PASS = THREADS / (BN / 4);
   static_assert(A_BLKS >= 1 && B_VECS >= 1, "tile too small for the block");
+  static_assert((BM / 4) * CH == A_BLKS * THREADS && KB * (BN / 4) == B_VECS * THREADS,
+                "tile does not divide evenly over the threads");
 
   f32x4 a[A_BLKS][4];  // a[blk][j] = A[row 4q+j][k 4c..4c+3]
   f32x4 b[B_VECS];
@@ -85,10 +92,10 @@ struct Stage {
   __device__ __forceinline__ void load(const float *__restrict__ A, int lda,
                                        const float *__restrict__ B, int ldb, int row0,
                                        int col0, int k0, int tid) {
-    const int c = tid & 7;
+    const int c = tid % CH;
 #pragma unroll
     for (int blk = 0; blk < A_BLKS; ++blk) {
-      const int q = (tid >> 3) + blk * (THREADS / 8);
+      const int q = tid / CH + blk * (THREADS / CH);
       const float *p = A + (size_t)(row0 + 4 * q) * lda + k0 + 4 * c;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -110,10 +117,10 @@ struct Stage {
   // (row0, 0), rsrc_b covers B from (0, col0); offsets must stay < 2^32.
   __device__ __forceinline__ void buf_offsets(int lda, int ldb, int tid, uint32_t (&voff_a)[A_BLKS],
                                               uint32_t &voff_b) const {
-    const int c = tid & 7;
+    const int c = tid % CH;
 #pragma unroll
     for (int blk = 0; blk < A_BLKS; ++blk) {
-      const int q = (tid >> 3) + blk * (THREADS / 8);
+      const int q = tid / CH + blk * (THREADS / CH);
       voff_a[blk] = (uint32_t)((4 * q) * lda + 4 * c) * 4u;
     }
     voff_b = (uint32_t)((tid / (BN / 4)) * ldb + 4 * (tid % (BN / 4))) * 4u;
@@ -140,7 +147,7 @@ struct Stage {
   // lanes.  (B needs nothing: its rows >= k lie beyond the descriptor's extent
   // and read as 0.)  `krem` = number of valid k in this slice.
   __device__ __forceinline__ void mask_k_tail(int krem, int tid) {
-    const int c = tid & 7;
+    const int c = tid % CH;
 #pragma unroll
     for (int blk = 0; blk < A_BLKS; ++blk)
 #pragma unroll
@@ -156,10 +163,10 @@ struct Stage {
   __device__ __forceinline__ void load_edge(const float *__restrict__ A, int lda,
                                             const float *__restrict__ B, int ldb, int row0,
                                             int col0, int k0, int m, int n, int k, int tid) {
-    const int c = tid & 7;
+    const int c = tid % CH;
 #pragma unroll
     for (int blk = 0; blk < A_BLKS; ++blk) {
-      const int q = (tid >> 3) + blk * (THREADS / 8);
+      const int q = tid / CH + blk * (THREADS / CH);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = row0 + 4 * q + j;
@@ -185,14 +192,14 @@ struct Stage {
 
   // Registers -> LDS.  As/Bs point at the destination buffer.
   __device__ __forceinline__ void store(float *As, float *Bs, int tid) const {
-    const int c = tid & 7;
-    const int g = swz_slot(c);
+    const int c = tid % CH;
+    const int g = A_HALFSWAP ? (c & 7) : swz_slot(c);
 #pragma unroll
     for (int blk = 0; blk < A_BLKS; ++blk) {
-      const int q = (tid >> 3) + blk * (THREADS / 8);
-      const int slot = q ^ g;
+      const int q = tid / CH + blk * (THREADS / CH);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        const int slot = A_HALFSWAP ? (q ^ g ^ ((s & 1) << 3)) : (q ^ g);
         f32x4 v = {a[blk][0][s], a[blk][1][s], a[blk][2][s], a[blk][3][s]};
         *reinterpret_cast<f32x4 *>(As + (4 * c + s) * BM + 4 * slot) = v;
       }

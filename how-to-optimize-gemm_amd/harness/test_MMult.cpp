@@ -18,7 +18,7 @@
 // (environment variable NAME or --NAME=value), defaults from parameters.h:
 //
 //   PFIRST PLAST PINC M N K NREPEATS LDA LDB LDC   sweep shape
-//   KERNEL=auto|mfma|mfma256|mfma_128x64|mfma_small|mfma_pipe|mfma_simple|valu|naive|rocblas
+//   KERNEL=auto|mfma|mfma256|mfma_128x64|mfma_64x64|mfma_pipe|mfma_simple|valu|naive|rocblas
 //   FLAVOUR=device|host|cpu      device: C=A*B on device pointers (cuda/ flavour)
 //                                host  : MY_MMult(m,n,k,a,lda,...) on host pointers, C+=A*B,
 //                                        best-of-NREPEATS with dclock (armv7/aarch64 flavour)
@@ -68,7 +68,7 @@ int kernel_id(const std::string &s) {
   if (s == "mfma") return MMH_KERNEL_MFMA;
   if (s == "auto") return MMH_KERNEL_AUTO;
   if (s == "mfma256") return MMH_KERNEL_MFMA_256;
-  if (s == "mfma_small") return MMH_KERNEL_MFMA_SMALL;
+  if (s == "mfma_64x64") return MMH_KERNEL_MFMA_64X64;
   if (s == "mfma_128x64") return MMH_KERNEL_MFMA_128X64;
   if (s == "mfma_pipe") return MMH_KERNEL_MFMA_PIPE;
   if (s == "mfma_simple") return MMH_KERNEL_MFMA_SIMPLE;

@@ -60,7 +60,7 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_ERR_COMM (-6)        /* RCCL call failed                             */
 
 /* kernel variants (the reference's "NEW := MMult_xxx" ladder, MI355X edition) */
-#define MMH_KERNEL_AUTO 0        /* K2 or K2s, chosen by how many 128x128 tiles the shape has */
+#define MMH_KERNEL_AUTO 0        /* 64x64 / 128x64 / 128x128 tiles chosen by how the shape fills the chip */
 #define MMH_KERNEL_VALU 1        /* K1: LDS-tiled 128x128, 8x8 per thread, VALU fma only   */
 #define MMH_KERNEL_MFMA 2        /* K2: 128x128 block tile on v_mfma_f32_16x16x4_f32; K-slice
                                     hand-over pipelined across the barrier, staging ops dealt
@@ -74,7 +74,7 @@ typedef struct mmh_context *mmh_handle_t;
                                     compiler-scheduled staging and 64-bit global loads      */
 #define MMH_KERNEL_MFMA_TILES 10 /* K2 always as one workgroup per tile (no stream-K), for A/B      */
 #define MMH_KERNEL_MFMA_128X64 8 /* K2 with a 128x64 block tile, 4 waves of 64x32                   */
-#define MMH_KERNEL_MFMA_SMALL 7  /* K2s: 64x64 block tile, 4 waves of 32x32, for small problems   */
+#define MMH_KERNEL_MFMA_64X64 11 /* K2 with a 64x64 block tile, 4 waves of 32x32, 128-deep K-slices  */
 /* ids >= 32 are timing-only ablation builds (tools/ab_bench.py); their results are invalid. */
 
 /* Library / device ------------------------------------------------------- */

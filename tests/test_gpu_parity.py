@@ -19,7 +19,7 @@ from conftest import golden_cases, load_golden
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["mfma", "mfma256", "mfma_128x64", "mfma_small", "auto", "mfma_pipe", "mfma_simple", "valu", "naive"]
+KERNELS = ["mfma", "mfma256", "mfma_128x64", "mfma_64x64", "auto", "mfma_pipe", "mfma_simple", "valu", "naive"]
 
 
 def tol(k):
@@ -77,7 +77,7 @@ SHAPES = [(256, 256, 256), (384, 640, 1024), (128, 128, 32), (128, 256, 4096), (
           (130, 129, 37), (3, 5, 7), (257, 255, 513), (512, 128, 2048), (1024, 1024, 1024)]
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_128x64", "mfma_small", "valu"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_128x64", "mfma_64x64", "valu"])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_seeded_inputs_vs_oracle(mm, oracle, shape, kernel):
     m, n, k = shape
@@ -104,7 +104,7 @@ def test_headline_size_4096(mm, oracle):
     c64 = oracle.ref_mmult_f64(a, b)
     assert np.abs(got - c64).max() <= 1.05 * np.abs(unfused - c64).max() + 1e-6
     # every kernel variant is the same chain -> identical bits
-    for kern in ("mfma256", "mfma_small", "valu"):
+    for kern in ("mfma256", "valu"):
         mm.set_kernel(kern)
         assert np.array_equal(mm.matmul(dev(a), dev(b)).cpu().numpy(), got), kern
 
@@ -253,7 +253,7 @@ def test_unaligned_pointers_take_the_guarded_path(mm, oracle):
     assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_128x64", "mfma_small"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_128x64", "mfma_64x64"])
 def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
     """Every operand only 4-byte aligned, odd lda/ldb/ldc, ragged m/n/k, with
     poison around the matrices: the descriptor-bounded path must neither read

@@ -77,7 +77,7 @@ if "sweep" in what:
         print(f"fp32 N={n}: mfma {time_f32(n, n, n):7.1f}  mfma256 {time_f32(n, n, n, 'mfma256'):7.1f}  "
               f"valu {time_f32(n, n, n, 'valu'):7.1f} TFLOP/s")
 if "tiles" in what:
-    ks = ["mfma", "mfma_128x64", "mfma_small", "auto", "rocblas"]
+    ks = ["mfma", "mfma_128x64", "mfma_64x64", "auto", "rocblas"]
     print("N      " + "  ".join(f"{k:>8}" for k in ks))
     for n in range(1024, 4097, 128):
         print(f"{n:5d}  " + "  ".join(f"{time_f32(n, n, n, k, reps=10):8.1f}" for k in ks), flush=True)
