@@ -59,7 +59,7 @@ def cpu_baseline(n: int) -> dict:
     (m=ROWS, n=k=N) -- identical per-row work to the full problem."""
     import numpy as np
     from oracle import oracle as O
-    rows = 64 if n >= 4096 else min(n, 256)
+    rows = 128 if n >= 4096 else min(n, 256)        # ~15 s of the serial triple loop at N=4096
     a, b = O.harness_inputs(rows, n, n, seed=2026)
     c = np.zeros((rows, n), dtype=np.float32)
     if O.have_ref():
