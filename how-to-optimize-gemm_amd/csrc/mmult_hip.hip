@@ -279,6 +279,17 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       if (sk <= 0) return sk;
       return launch_mfma<128, 64, false, 4, 0, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     }
+    case 19: {  // A/B: B through LDS-DMA (buffer_load ... lds)
+      const int nbm = m / 128, nbn = n / 128;
+      if ((m % 128) || (n % 128) || (k % 32) || (lda % 4) || (ldb % 4) || (ldc % 4) || !aligned16(dA) ||
+          !aligned16(dB) || !aligned16(dC))
+        return MMH_ERR_INVALID_ARG;
+      auto kern = mmh::sgemm_mfma_kernel<128, 128, false, 4, 0, true, 4, 4, 32, true>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(256), lds_bytes(128, 128), s, m, n, k, dA,
+                         lda, dB, ldb, dC, ldc, acc, nbm, nbn);
+      HIP_TRY(hipGetLastError());
+      return MMH_OK;
+    }
     case 16:   // staging cadence A/B: one op per 3 / 4 MFMAs instead of 2
       return launch_mfma<128, 128, false, 5>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case 17:
@@ -441,6 +452,7 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_TILES: return "MMult_hip_mfma_tiles";
     case MMH_KERNEL_MFMA_128X64: return "MMult_hip_mfma_128x64";
     case MMH_KERNEL_MFMA_64X64: return "MMult_hip_mfma_64x64";
+    case 19: return "exp_dma_b";
     case 16: return "cadence_3";
     case 17: return "cadence_4";
     case 18: return "cadence_1";

@@ -173,7 +173,8 @@ __device__ __forceinline__ void static_for(F &&f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int BM, int BN, bool EDGE, int SCHED, int ABL, bool BUFLD, int WTN = 4, int WTM = 4, int KB = BK>
+template <int BM, int BN, bool EDGE, int SCHED, int ABL, bool BUFLD, int WTN = 4, int WTM = 4, int KB = BK,
+          bool DMAB = false>
 __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int k,
                                                   const float *__restrict__ A, int lda,
                                                   const float *__restrict__ B, int ldb,
@@ -186,6 +187,8 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   // 2 -> 64x32 wave tiles (8-byte B fragments, twice the waves per block tile)
   // WTM likewise along m (4 -> 64 rows, 2 -> 32 rows); KB = K-slice depth per LDS buffer.
   static_assert((WTN == 4 || WTN == 2) && (WTM == 4 || WTM == 2), "wave tile is 64|32 x 64|32");
+  // DMAB: B goes global -> LDS directly (buffer_load ... lds), A still through registers
+  static_assert(!DMAB || (BUFLD && WTN == 4), "LDS-DMA needs descriptors and the linear B image");
   constexpr int WAVES_N = BN / (16 * WTN);
   constexpr int THREADS = (BM / (16 * WTM)) * WAVES_N * 64;
   constexpr int A_FLOATS = KB * BM, B_FLOATS = KB * BN, BUF = A_FLOATS + B_FLOATS;
@@ -262,8 +265,12 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
                                                0x00020000);
     st.buf_offsets(lda, ldb, tid, voff_a, voff_b);
   }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto stage_load = [&](int kt) {
-    if (BUFLD) {
+    if constexpr (DMAB) {
+      st.load_buf_a(rsrc_a, voff_a, lda, kt * KB);
+      if (EDGE && kt == nk - 1 && (k % KB) != 0) st.mask_k_tail(k - kt * KB, tid);
+    } else if (BUFLD) {
       st.load_buf(rsrc_a, rsrc_b, voff_a, voff_b, lda, ldb, kt * KB);
       if (EDGE && kt == nk - 1 && (k % KB) != 0) st.mask_k_tail(k - kt * KB, tid);
     } else if (EDGE) {
@@ -292,9 +299,18 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
 
   afrag_t fa[2];
   bfrag_t fb[2];
+  // registers -> LDS for slice `kt` (and, with DMAB, the DMA of that slice's B)
+  auto stage_store = [&](float *buf, int kt) {
+    if constexpr (DMAB) {
+      st.store_a(buf, tid);
+      st.dma_b(rsrc_b, buf + A_FLOATS, voff_b, ldb, kt * KB, wave_u);
+    } else {
+      st.store(buf, buf + A_FLOATS, tid);
+    }
+  };
   if (ke > kb) {
     stage_load(kb);
-    st.store(lds, lds + A_FLOATS, tid);
+    stage_store(lds, kb);
     if (ke > kb + 1) stage_load(kb + 1);  // the second slice rides in registers into iteration 0
   }
   __syncthreads();
@@ -335,7 +351,11 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      constexpr int NMEM = StageT::A_BLKS * 4 + StageT::B_VECS;
+      // staging ops per slice: LDS stores, then vector-memory ops (with DMAB the B
+      // DMAs of the next slice count as vector-memory ops and only A is stored)
+      constexpr int NST = DMAB ? StageT::A_BLKS * 4 : StageT::A_BLKS * 4 + StageT::B_VECS;
+      constexpr int NVM = StageT::A_BLKS * 4 + StageT::B_VECS;
+      constexpr int NMEM = (NST + NVM + 1) / 2;
       static_assert(KS >= 8, "the slice pipeline needs at least 8 k-steps");
       constexpr bool HAVE_STORE = MORE && !(ABL & 2), HAVE_LOAD = MORE2 && !(ABL & 1);
       // source position of the staging ops: stores at k-step 1; loads where their
@@ -347,7 +367,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
       constexpr int UPK = MK / UNIT;                       // units per k-step (16, or 8 for MK = 8)
       static_assert((2 * NMEM) * SP <= (KS - 2) * UPK, "staging ops do not fit in the pre-barrier MFMA shadow");
       constexpr int KS_LOAD = SCHED >= 4 ? 1 + ((NMEM + 1) * SP - 1) / UPK : (SCHED == 2 ? 4 : 2);
-      if (ks == 1 && HAVE_STORE) st.store(nxt, nxt + A_FLOATS, tid);
+      if (ks == 1 && HAVE_STORE) stage_store(nxt, kt + 1);
       if (ks == KS_LOAD && HAVE_LOAD) stage_load((ABL & 16) ? (kt & 1) : kt + 2);
       const afrag_t a = fa[ks & 1];
       const bfrag_t b = fb[ks & 1];
@@ -373,8 +393,10 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
             const int j = UPK * ks + i - UPK;                // unit index counted from k-step 1
             if (j >= 0 && (j + 1) % SP == 0) {
               const int op = (j + 1) / SP - 1;
-              if (HAVE_STORE && op < NMEM) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-              if (HAVE_LOAD && op >= NMEM && op < 2 * NMEM)
+              if (HAVE_STORE && op < NST) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // DS write
+              if (DMAB && HAVE_STORE && op >= NST && op < NST + StageT::B_VECS)
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                             // LDS-DMA
+              if (HAVE_LOAD && op >= NMEM && op < NMEM + (DMAB ? StageT::A_BLKS * 4 : NVM))
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                             // VMEM read
             }
           }
@@ -414,7 +436,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
 
 // The shipping kernel: one workgroup per C tile (XCD-aware block -> tile map).
 template <int BM, int BN, bool EDGE, int SCHED = 0, int ABL = 0, bool BUFLD = false, int WTN = 4,
-          int WTM = 4, int KB = BK>
+          int WTM = 4, int KB = BK, bool DMAB = false>
 __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)  // >= 2 waves/SIMD
 sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                   const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
@@ -422,7 +444,7 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int tm, tn;
   block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
-  mfma_tile_segment<BM, BN, EDGE, SCHED, ABL, BUFLD, WTN, WTM, KB>(
+  mfma_tile_segment<BM, BN, EDGE, SCHED, ABL, BUFLD, WTN, WTM, KB, DMAB>(
       lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0, (k + KB - 1) / KB, accumulate != 0);
 }
 

@@ -142,6 +142,50 @@ struct Stage {
                                                        (k0 + v * B_ROWS_PER_PASS) * ldb * 4, 0));
   }
 
+  // LDS-DMA form for B (buffer_load_dwordx4 ... lds): the B image is exactly the
+  // memory layout (rows of BN floats, no swizzle, 64x64 wave tiles only), and the
+  // thread -> (row, column slot) map above is lane-linear inside a wave, so each
+  // wave-instruction drops 1 KiB = 1024/(4 BN) whole k-rows straight into the
+  // image: no VGPR round trip, no ds_write.  `bs` = B image of the target buffer.
+  // Out-of-range rows (k tail, guarded launches) arrive as zeros like any
+  // descriptor-bounded load.
+  __device__ __forceinline__ void dma_b(__amdgpu_buffer_rsrc_t rsrc_b, float *bs, uint32_t voff_b,
+                                        int ldb, int k0, int wave) const {
+    static_assert(!B_HALFSWAP, "the DMA image cannot be swizzled");
+    constexpr int ROWS_PER_WAVE = 64 / (BN / 4);
+#pragma unroll
+    for (int v = 0; v < B_VECS; ++v) {
+      float *dst = bs + (wave * ROWS_PER_WAVE + v * B_ROWS_PER_PASS) * BN;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc_b, (__attribute__((address_space(3))) void *)dst, 16, voff_b,
+          (k0 + v * B_ROWS_PER_PASS) * ldb * 4, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void load_buf_a(__amdgpu_buffer_rsrc_t rsrc_a, const uint32_t (&voff_a)[A_BLKS],
+                                             int lda, int k0) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int blk = 0; blk < A_BLKS; ++blk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        a[blk][j] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[blk], (k0 + j * lda) * 4, 0));
+  }
+  __device__ __forceinline__ void store_a(float *As, int tid) const {
+    const int c = tid % CH;
+    const int g = A_HALFSWAP ? (c & 7) : swz_slot(c);
+#pragma unroll
+    for (int blk = 0; blk < A_BLKS; ++blk) {
+      const int q = tid / CH + blk * (THREADS / CH);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int slot = A_HALFSWAP ? (q ^ g ^ ((s & 1) << 3)) : (q ^ g);
+        f32x4 v = {a[blk][0][s], a[blk][1][s], a[blk][2][s], a[blk][3][s]};
+        *reinterpret_cast<f32x4 *>(As + (4 * c + s) * BM + 4 * slot) = v;
+      }
+    }
+  }
+
   // K tail of the guarded buffer path: in the last, partial K-slice the A loads
   // run past column k into the next row (or the caller's padding); zero those
   // lanes.  (B needs nothing: its rows >= k lie beyond the descriptor's extent

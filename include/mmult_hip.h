@@ -75,7 +75,9 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_TILES 10 /* K2 always as one workgroup per tile (no stream-K), for A/B      */
 #define MMH_KERNEL_MFMA_128X64 8 /* K2 with a 128x64 block tile, 4 waves of 64x32                   */
 #define MMH_KERNEL_MFMA_64X64 11 /* K2 with a 64x64 block tile, 4 waves of 32x32, 128-deep K-slices  */
-/* ids >= 32 are timing-only ablation builds (tools/ab_bench.py); their results are invalid. */
+/* ids 16-19 are A/B builds of K2 with valid results (staging cadence 3/4/1 MFMAs per op; 19 =
+ * B staged by LDS-DMA, buffer_load ... lds); ids >= 32 are timing-only ablation builds whose
+ * results are invalid.  See profiles/r01_ablation.md, tools/ab_bench.py. */
 
 /* Library / device ------------------------------------------------------- */
 const char *mmh_strerror(int status);
