@@ -452,20 +452,23 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 // K2p: persistent, chained stream-K.  For tile counts that do not divide the
 // chip (e.g. N=3072: 576 tiles for 512 workgroup slots) the plain kernel runs
 // a nearly empty last round.  Here gridDim.x resident workgroups split the
-// T * nk (tile, K-slice) units evenly.  A workgroup's range is
-//     [tail of tile a] [whole tiles ...] [head of tile b]
-// and it works through it BACK TO FRONT-ish: the head of b first (slices
-// 0..h-1; the partial accumulators are stored to C and a per-tile flag is
-// published), then the whole tiles, the tail of a last.  The tail CONTINUES the
-// chain its predecessor started: it waits for tile a's flag, starts its
-// accumulators from C and runs slices h..nk-1 -- so every C(i,j) is still one
-// fp32 fmaf chain over ascending k and the result is bit-identical to the
-// plain kernel.  The predecessor publishes its head before doing anything else
-// and a range is at least one tile long (the launcher guarantees T >= grid), so
-// the wait is over before it starts in steady state.
+// T * nk (tile, K-slice) units evenly into consecutive ranges.  A range is
+//     [a later part of tile a] [whole tiles ...] [the head of tile b]
+// and is worked through with the head of b FIRST (slices 0..h-1; the partial
+// accumulators are stored to C and the tile's part counter is published), then
+// the whole tiles, the part of a LAST.  A later part CONTINUES the chain its
+// predecessor left in C: it waits for the tile's counter to reach its part
+// index, starts its accumulators from C, runs its slices and either finishes the
+// tile or publishes the counter for the next part -- so every C(i,j) is still
+// one fp32 fmaf chain over ascending k and the result is bit-identical to the
+// plain kernel.  A workgroup publishes its head before doing anything else, so
+// with ranges of at least one tile the wait is over before it starts; with
+// shorter ranges (>= half a tile, two workgroups per CU) a waiting workgroup
+// leaves its CU to its partner, which is still better than an idle CU.
+// Dependencies only ever point to lower range indices.
 // Visibility across CUs/XCDs (cdna guide G16): producer = plain stores, every
 // wave drains vmcnt, barrier, one lane agent-scope release fence + drained
-// relaxed flag store; consumer = one lane relaxed poll (bounded), agent-scope
+// relaxed counter store; consumer = one lane relaxed poll (bounded), agent-scope
 // acquire fence, barrier, plain loads.
 // ---------------------------------------------------------------------------
 template <int BM, int BN, bool EDGE, int WTN = 4, int WTM = 4, int KB = BK>
@@ -482,7 +485,8 @@ sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
   const int gq = G / NXCD, gr = G % NXCD;
   const int q = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + local;
   const long long total = (long long)T * nk;
-  const long long u0 = total * q / G, u1 = total * (q + 1) / G;
+  auto range_start = [&](int r) { return total * r / G; };
+  const long long u0 = range_start(q), u1 = range_start(q + 1);
   if (u1 <= u0) return;
   const int t_first = (int)(u0 / nk), k_first = (int)(u0 % nk);
   const int t_last = (int)((u1 - 1) / nk), k_last_end = (int)(u1 - (long long)t_last * nk);
@@ -494,46 +498,47 @@ sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
     tm = first_m + in_group % gsize;
     tn = in_group / gsize;
   };
-  auto run = [&](int t, int kb, int ke, bool from_c) {
-    int tm, tn;
-    tile_of(t, tm, tn);
-    __syncthreads();   // LDS is reused from segment to segment
-    mfma_tile_segment<BM, BN, EDGE, 4, 0, true, WTN, WTM, KB>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn,
-                                                              kb, ke, from_c);
-  };
-  const bool has_tail = k_first != 0;                       // tile t_first, slices [k_first, nk)
-  const bool has_head = k_last_end != nk && (t_last != t_first || !has_tail);
-  // 1. head of the last tile: publish
-  if (has_head) {
-    run(t_last, 0, k_last_end, accumulate != 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&flags[t_last], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  // 2. whole tiles
-  const int w0 = has_tail ? t_first + 1 : t_first;
-  const int w1 = has_head ? t_last - 1 : t_last;
-  for (int t = w0; t <= w1; ++t) run(t, 0, nk, accumulate != 0);
-  // 3. tail of the first tile: continue the predecessor's chain
-  if (has_tail) {
-    if (threadIdx.x == 0) {
+  // slices [kb, ke) of tile t.  kb > 0: a later part -- wait for the parts before it.
+  // ke < nk: not the last part -- publish.
+  auto run = [&](int t, int kb, int ke) {
+    int part = 0;                                  // how many ranges begin inside tile t before ours
+    if (kb > 0)
+      for (int r = q; r > 0 && range_start(r) > (long long)t * nk; --r) ++part;
+    if (kb > 0 && threadIdx.x == 0) {
       long long spins = 0;
-      while (__hip_atomic_load(&flags[t_first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      while (__hip_atomic_load(&flags[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < part) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1ll << 26)) {          // ~ seconds: give up loudly rather than hang
+        if (++spins > (1ll << 26)) {               // ~ seconds: give up loudly rather than hang
           __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    const int ke = (t_first == t_last) ? k_last_end : nk;
-    run(t_first, k_first, ke, true);
+    int tm, tn;
+    tile_of(t, tm, tn);
+    __syncthreads();   // LDS is reused from segment to segment; orders the loads after the acquire
+    mfma_tile_segment<BM, BN, EDGE, 4, 0, true, WTN, WTM, KB>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn,
+                                                              kb, ke, kb > 0 || accumulate != 0);
+    if (ke < nk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&flags[t], part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if (t_first == t_last) {                         // the whole range lies in one tile
+    run(t_first, k_first, k_last_end);
+    return;
   }
+  const bool first_partial = k_first != 0, last_partial = k_last_end != nk;
+  if (last_partial) run(t_last, 0, k_last_end);                       // 1. head of the last tile
+  for (int t = t_first + (first_partial ? 1 : 0); t <= t_last - (last_partial ? 1 : 0); ++t)
+    run(t, 0, nk);                                                    // 2. whole tiles
+  if (first_partial) run(t_first, k_first, nk);                       // 3. rest of the first tile
 }
 
 }  // namespace mmh
