@@ -75,18 +75,27 @@ inline int probe_mfma_f32(int cu_count, float *tflops, std::string *err) {
 // int8 twin: v_mfma_i32_16x16x64_i8 only (what K3 issues), 8 accumulators per wave
 typedef int pi32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) probe_mfma_i8_kernel(int *out, int iters, int seed) {
-  pi32x4 acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = pi32x4{seed, seed, seed, seed};
+  // The MFMAs are spelled in inline asm: with the builtin, hipcc 7.2 allocates the eight
+  // int accumulators in overlapping AGPR windows and shuffles ~50 registers per iteration,
+  // which measures the shuffle, not the matrix pipe (2.4 instead of ~4 POPS).
+  pi32x4 acc0 = {seed, seed, seed, seed}, acc1 = acc0, acc2 = acc0, acc3 = acc0, acc4 = acc0, acc5 = acc0,
+         acc6 = acc0, acc7 = acc0;
   const pi32x4 a = {seed + (int)threadIdx.x, seed, 1, 2}, b = {seed, 3, (int)threadIdx.x, 4};
   for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[i], 0, 0, 0);
+    asm volatile(
+        "v_mfma_i32_16x16x64_i8 %0, %8, %9, %0\n\t"
+        "v_mfma_i32_16x16x64_i8 %1, %8, %9, %1\n\t"
+        "v_mfma_i32_16x16x64_i8 %2, %8, %9, %2\n\t"
+        "v_mfma_i32_16x16x64_i8 %3, %8, %9, %3\n\t"
+        "v_mfma_i32_16x16x64_i8 %4, %8, %9, %4\n\t"
+        "v_mfma_i32_16x16x64_i8 %5, %8, %9, %5\n\t"
+        "v_mfma_i32_16x16x64_i8 %6, %8, %9, %6\n\t"
+        "v_mfma_i32_16x16x64_i8 %7, %8, %9, %7"
+        : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4), "+v"(acc5), "+v"(acc6), "+v"(acc7)
+        : "v"(a), "v"(b));
   }
-  pi32x4 s = acc[0];
-#pragma unroll
-  for (int i = 1; i < 8; ++i) s += acc[i];
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU readers (no auto padding in asm)
+  pi32x4 s = acc0 + acc1 + acc2 + acc3 + acc4 + acc5 + acc6 + acc7;
   if (s[0] + s[1] + s[2] + s[3] == 123456789) out[0] = s[0];
 }
 
