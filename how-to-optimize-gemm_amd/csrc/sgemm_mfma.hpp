@@ -338,9 +338,6 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
       } else if (ks + 1 < KS) {
         fa[(ks + 1) & 1] = frag_a(buf, ks + 1);
         fb[(ks + 1) & 1] = frag_b(buf, ks + 1);
-        // SCHED 3: keep the prefetch at the TOP of the k-step (the scheduler
-        // otherwise sinks it below the MFMAs and then waits on it at once)
-        if (SCHED == 3) __builtin_amdgcn_sched_barrier(0);
       } else {
         // slice boundary: every read of `cur` has been issued; writes to `cur^1` too
         __builtin_amdgcn_sched_barrier(0);
@@ -359,14 +356,14 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
       static_assert(KS >= 8, "the slice pipeline needs at least 8 k-steps");
       constexpr bool HAVE_STORE = MORE && !(ABL & 2), HAVE_LOAD = MORE2 && !(ABL & 1);
       // source position of the staging ops: stores at k-step 1; loads where their
-      // slots begin in the SCHED-4 pipeline (k-step 2 for the other schedules)
+      // slots begin in the pipeline below (k-step 2 when the compiler schedules, SCHED 0)
       // SCHED >= 4: one staging op per SP MFMAs (SCHED 4 -> 2, 5 -> 3, 6 -> 4, 7 -> 1), counted
       // in units of MK/16 MFMAs so that 64x32 wave tiles (MK = 8) keep the same cadence
       constexpr int SP = SCHED == 5 ? 3 : (SCHED == 6 ? 4 : (SCHED == 7 ? 1 : 2));
       constexpr int UNIT = MK / 16 > 0 ? MK / 16 : 1;     // MFMAs per scheduling unit
       constexpr int UPK = MK / UNIT;                       // units per k-step (16, or 8 for MK = 8)
       static_assert((2 * NMEM) * SP <= (KS - 2) * UPK, "staging ops do not fit in the pre-barrier MFMA shadow");
-      constexpr int KS_LOAD = SCHED >= 4 ? 1 + ((NMEM + 1) * SP - 1) / UPK : (SCHED == 2 ? 4 : 2);
+      constexpr int KS_LOAD = SCHED >= 4 ? 1 + ((NMEM + 1) * SP - 1) / UPK : 2;
       if (ks == 1 && HAVE_STORE) stage_store(nxt, kt + 1);
       if (ks == KS_LOAD && HAVE_LOAD) stage_load((ABL & 16) ? (kt & 1) : kt + 2);
       const afrag_t a = fa[ks & 1];
@@ -376,9 +373,10 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
 #pragma unroll
         for (int u = 0; u < WTN; ++u)
           acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
-      // SCHED 1..3: pin the k-step order (reads for ks+1 and the shadow memory
-      // ops stay inside the k-step whose 16 MFMAs cover them)
-      if (SCHED >= 1 && SCHED <= 3) __builtin_amdgcn_sched_barrier(0);
+      // (Pinning whole k-steps with sched_barrier(0) -- with or without forcing the
+      // prefetch to the top of the k-step -- measured 2-3 % slower than letting the
+      // compiler schedule, profiles/r01_ablation.md; those variants are gone.)
+      static_assert(SCHED == 0 || SCHED >= 4, "SCHED: 0 = compiler-scheduled, 4..7 = pipeline cadences");
       // SCHED >= 4: describe the slice to the scheduler as a pipeline.  Every k-step
       // opens with its two fragment prefetches; from k-step 1 on, every SP-th unit of
       // MFMAs is followed by ONE staging op -- first the NMEM LDS stores of the next
