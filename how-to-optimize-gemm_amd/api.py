@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libmmult_hip.so")
 # status codes / kernel ids (include/mmult_hip.h)
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALLOC, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_256, KERNEL_NAIVE, KERNEL_MFMA_SIMPLE, KERNEL_MFMA_PIPE = 0, 1, 2, 3, 4, 5, 6
-OPT_STREAMK, OPT_STREAMK_TIMEOUTS = 1, 2
+OPT_STREAMK, OPT_STREAMK_TIMEOUTS, OPT_IGEMM_MODE = 1, 2, 3
 KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
            "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11}
@@ -194,6 +194,10 @@ class MMult:
 
     def set_streamk(self, on: bool) -> None:
         _check(lib().mmh_set_option(self._h, OPT_STREAMK, int(bool(on))), "mmh_set_option")
+
+    def set_igemm_mode(self, mode: int) -> None:
+        """0 packed-B + LDS-DMA (default), 1 in-kernel transpose, 2 correctness-first kernel."""
+        _check(lib().mmh_set_option(self._h, OPT_IGEMM_MODE, int(mode)), "mmh_set_option")
 
     def streamk_timeouts(self) -> int:
         """Synchronises; number of stream-K hand-off waits that timed out (must be 0)."""
@@ -380,5 +384,5 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
 
 __all__ = ["MMult", "MMultError", "lib", "device_count", "shard_rows", "kernel_name", "sgemm_sharded",
            "KERNELS", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
-           "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
+           "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OPT_IGEMM_MODE", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

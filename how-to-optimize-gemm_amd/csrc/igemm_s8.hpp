@@ -238,6 +238,209 @@ igemm_s8_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
 }
 
 // --------------------------------------------------------------------------
+// K3d: the same tile arithmetic fed entirely by LDS-DMA.
+//
+// K3 above is instruction-issue-bound: 32 MFMAs of ~17 cycles per slice against
+// 12 LDS stores, 32 v_perm_b32 and 8 VGPR loads.  Here B is packed ONCE per call
+// into Bt[n][k] (k contiguous, zero-padded to 128 x 128 -- the role packB plays
+// inside the reference's CPU MY_MMult, aarch64/MMult_4x4_13.cpp:259-441), and
+// both operands then go global -> LDS with `buffer_load_dwordx4 ... lds`: no
+// staging registers, no ds_write, no v_perm in the loop.  The DMA destination
+// is lane-linear (lane L -> bytes 16 L of a 1 KiB chunk = row L/8, slot L%8 of
+// the [row][128 B] image), so the slot swizzle of K3's images is applied on the
+// SOURCE side: lane L fetches slot (L%8) ^ ((row>>1)&7) of its row -- same
+// 128-byte line, same coalescing.  The B image keeps K3's u-major row order
+// by choosing which packed row each lane group fetches.
+// --------------------------------------------------------------------------
+
+// Bt[(n_pad)][kp] <- transpose of B[k][n] (ldb), zero padded.  One thread moves a
+// 16(k) x 4(n) byte block: 16 dword loads, four 4x4 byte transposes, four 16-byte stores.
+__global__ void __launch_bounds__(256) pack_bt_s8_kernel(const int8_t *__restrict__ B, int ldb, int k,
+                                                         int n, int8_t *__restrict__ Bt, int kp,
+                                                         int n_pad, int b_dword_ok) {
+  const int nq = threadIdx.x & 15, kq = threadIdx.x >> 4;
+  const int n0 = blockIdx.x * 64 + 4 * nq, k0 = blockIdx.y * 256 + 16 * kq;
+  if (n0 >= n_pad || k0 >= kp) return;
+  uint32_t rows[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int kk = k0 + j;
+    uint32_t w = 0;
+    if (kk < k) {
+      if (b_dword_ok && n0 + 3 < n) {
+        w = *reinterpret_cast<const uint32_t *>(B + (size_t)kk * ldb + n0);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (n0 + c < n) w |= (uint32_t)(uint8_t)B[(size_t)kk * ldb + n0 + c] << (8 * c);
+      }
+    }
+    rows[j] = w;
+  }
+  uint32_t col[4][4];   // col[c][g] = k bytes 4g..4g+3 of column n0 + c
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    uint32_t t[4];
+    transpose4x4_bytes(rows[4 * g], rows[4 * g + 1], rows[4 * g + 2], rows[4 * g + 3], t);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) col[c][g] = t[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    i32x4 v = {(int)col[c][0], (int)col[c][1], (int)col[c][2], (int)col[c][3]};
+    *reinterpret_cast<i32x4 *>(Bt + (size_t)(n0 + c) * kp + k0) = v;
+  }
+}
+
+template <bool EDGE>
+__global__ void __launch_bounds__(256, 2)
+igemm_s8_dma_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
+                    const int8_t *__restrict__ Bt, int kp, int32_t *__restrict__ C, int ldc,
+                    int accumulate, int nbm, int nbn) {
+  constexpr int BM = 128, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) int8_t ilds[];   // 2 x (A image | B image) = 64 KiB
+
+  const int tile = blockIdx.x;
+  const int tm = tile / nbn, tn = tile % nbn;
+  const int row0 = tm * BM, col0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 15, g = lane >> 4;
+
+  const int rows_valid = EDGE ? min(BM, m - row0) : BM;
+  const bool whole_c = !EDGE || (rows_valid == BM && col0 + BN <= n);
+  const int crow = row0 + wm * 64 + 4 * g;     // + 16 t + r
+  const int ccol = col0 + wn * 64 + 4 * li;    // .. +3 (u)
+  typedef int c_vec_u __attribute__((ext_vector_type(4), aligned(4)));
+  using c_vec = std::conditional_t<EDGE, c_vec_u, i32x4>;
+
+  i32x4 acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = crow + 16 * t + r;
+      i32x4 v = {0, 0, 0, 0};
+      if (accumulate) {
+        if (whole_c) {
+          v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
+        } else if (row < m) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (ccol + u < n) v[u] = C[(size_t)row * ldc + ccol + u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u][r] = v[u];
+    }
+
+  // descriptors: A bounded at the block's last valid row (rows >= m arrive as zeros;
+  // bytes past k are multiplied by Bt's zero padding); Bt is padded, so unbounded
+  const uint32_t ext_a = (uint32_t)((rows_valid - 1) * lda + ((k + 3) & ~3));
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int8_t *>(A + (size_t)row0 * lda), 0, ext_a, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int8_t *>(Bt + (size_t)col0 * kp), 0, (uint32_t)(BN * kp), 0x00020000);
+  // wave w moves chunks 4w..4w+3 (8 image rows each) of both images
+  const int dr = lane >> 3, dsl = lane & 7;
+  uint32_t voff_a[4], voff_b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int prow = 8 * (4 * wave + j) + dr;                       // image row
+    const int src_slot = dsl ^ ((prow >> 1) & 7);
+    voff_a[j] = (uint32_t)(prow * lda + 16 * src_slot);
+    const int nloc = 4 * (prow & 31) + (prow >> 5);                 // u-major image row -> column
+    voff_b[j] = (uint32_t)(nloc * kp + 16 * src_slot);
+  }
+  auto dma = [&](int8_t *buf, int kt) {
+    const int k0 = kt * IK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc_a, (__attribute__((address_space(3))) void *)(buf + 8 * (4 * wave + j) * IK), 16, voff_a[j],
+          k0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc_b, (__attribute__((address_space(3))) void *)(buf + ITILE + 8 * (4 * wave + j) * IK), 16,
+          voff_b[j], k0, 0, 0);
+  };
+  const int swz = (li >> 1) & 7;
+  auto frag_a = [&](const int8_t *buf, int s, int t) {
+    const int row = wm * 64 + 16 * t + li;
+    return *reinterpret_cast<const i32x4 *>(buf + row * IK + 16 * ((4 * s + g) ^ swz));
+  };
+  auto frag_b = [&](const int8_t *buf, int s, int u) {
+    const int prow = u * 32 + wn * 16 + li;
+    return *reinterpret_cast<const i32x4 *>(buf + ITILE + prow * IK + 16 * ((4 * s + g) ^ swz));
+  };
+
+  const int nk = (k + IK - 1) / IK;
+  i32x4 fa[2][4], fb[2][4];
+  if (nk > 0) dma(ilds, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nk > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { fa[0][t] = frag_a(ilds, 0, t); fb[0][t] = frag_b(ilds, 0, t); }
+  }
+  int cur = 0;
+  auto slice = [&](int kt, auto more_c) {
+    constexpr bool MORE = decltype(more_c)::value;
+    const int8_t *buf = ilds + cur * 2 * ITILE;
+    int8_t *nxt = ilds + (cur ^ 1) * 2 * ITILE;
+    // `nxt` was last read before the previous slice's barrier: start filling it now
+    if (MORE) dma(nxt, kt + 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { fa[1][t] = frag_a(buf, 1, t); fb[1][t] = frag_b(buf, 1, t); }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[0][t], fb[0][u], acc[t][u], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // DS read
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // MFMA
+      if (MORE && i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // LDS-DMA
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the next slice has landed
+    __syncthreads();
+    if (MORE) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { fa[0][t] = frag_a(nxt, 0, t); fb[0][t] = frag_b(nxt, 0, t); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[1][t], fb[1][u], acc[t][u], 0, 0, 0);
+    cur ^= 1;
+  };
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) slice(kt, std::true_type{});
+  if (kt < nk) slice(kt, std::false_type{});
+
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = crow + 16 * t + r;
+      i32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+      if (whole_c) {
+        *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + ccol) = v;
+      } else if (row < m) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
+      }
+    }
+}
+
+// --------------------------------------------------------------------------
 // The correctness-first kernel (any alignment).
 // --------------------------------------------------------------------------
 constexpr int IBK = 64;      // k bytes per LDS slice
@@ -359,20 +562,41 @@ igemm_s8_simple_kernel(int m, int n, int k, const int8_t *__restrict__ A, int ld
     }
 }
 
+// Workspace bytes mmh_igemm_s8 needs for the packed B of a (k x n) problem.
+inline size_t igemm_s8_pack_bytes(int n, int k) {
+  const size_t n_pad = ((size_t)n + 127) & ~(size_t)127, kp = ((size_t)k + 127) & ~(size_t)127;
+  return n_pad * kp;
+}
+
+// mode: 0 = K3d when eligible (needs `bt_ws`, >= igemm_s8_pack_bytes), else K3 / simple;
+//       1 = K3 (in-kernel transpose), 2 = the simple kernel.
 inline hipError_t launch_igemm_s8(int m, int n, int k, const int8_t *A, int lda, const int8_t *B,
                                   int ldb, int32_t *C, int ldc, int acc, hipStream_t s,
-                                  bool force_simple = false) {
+                                  int8_t *bt_ws = nullptr, int mode = 0) {
   const int nbm = (m + 127) / 128, nbn = (n + 127) / 128;
   dim3 grid((unsigned)(nbm * nbn)), block(256);
   const bool shape_ok = (m % 128 == 0) && (n % 128 == 0);
-  const bool a4 = (lda % 4 == 0) && (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 3) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(B) & 3) == 0);
+  const bool a4 = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 3) == 0);
+  const bool b4 = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 3) == 0);
   const size_t lim = (1ull << 31) - 4096;
+  const size_t kp = ((size_t)k + 127) & ~(size_t)127, n_pad = ((size_t)n + 127) & ~(size_t)127;
+  constexpr size_t lds = 4 * ITILE;   // 64 KiB
+  const bool c_fast = shape_ok && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+  if (mode == 0 && bt_ws && a4 && ((size_t)128 * lda + k) < lim && 128 * kp < lim) {
+    dim3 pgrid((unsigned)(n_pad / 64), (unsigned)((kp + 255) / 256));
+    hipLaunchKernelGGL(pack_bt_s8_kernel, pgrid, dim3(256), 0, s, B, ldb, k, n, bt_ws, (int)kp, (int)n_pad,
+                       b4 ? 1 : 0);
+    if (c_fast)
+      hipLaunchKernelGGL(igemm_s8_dma_kernel<false>, grid, block, lds, s, m, n, k, A, lda, bt_ws, (int)kp, C,
+                         ldc, acc, nbm, nbn);
+    else
+      hipLaunchKernelGGL(igemm_s8_dma_kernel<true>, grid, block, lds, s, m, n, k, A, lda, bt_ws, (int)kp, C,
+                         ldc, acc, nbm, nbn);
+    return hipGetLastError();
+  }
   const bool window_ok = ((size_t)128 * lda + k) < lim && ((size_t)k * ldb + 128) < lim;
-  if (a4 && window_ok && !force_simple) {
-    constexpr size_t lds = 4 * ITILE;   // 64 KiB
-    const bool fast = shape_ok && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-    if (fast)
+  if (mode <= 1 && a4 && b4 && window_ok) {
+    if (c_fast)
       hipLaunchKernelGGL(igemm_s8_kernel<false>, grid, block, lds, s, m, n, k, A, lda, B, ldb, C, ldc,
                          acc, nbm, nbn);
     else

@@ -68,6 +68,8 @@ struct mmh_context {
   int kernel = MMH_KERNEL_AUTO;
   int cu_count = 0;
   DevBuf a, b, c;          // staging for the host-pointer flavour
+  DevBuf bt;               // int8 GEMM: packed (transposed, padded) B
+  int igemm_mode = 0;      // 0 auto (packed-B + LDS-DMA), 1 in-kernel transpose, 2 simple
   DevBuf qa, qb, qc, qs;   // quantised GEMM workspace: int8 A, int8 B, int32 C, {amax bits, scales}
   DevBuf flags;            // stream-K per-tile hand-off flags (+1 error word)
   long flags_tiles = -1;   // where the error word of the last stream-K launch sits
@@ -395,6 +397,7 @@ int mmh_destroy(mmh_handle_t h) {
   h->b.release();
   h->c.release();
   h->flags.release();
+  h->bt.release();
   h->qa.release();
   h->qb.release();
   h->qc.release();
@@ -416,6 +419,10 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
     h->streamk = value ? 1 : 0;
     return MMH_OK;
   }
+  if (option == MMH_OPT_IGEMM_MODE && value >= 0 && value <= 2) {
+    h->igemm_mode = value;
+    return MMH_OK;
+  }
   return MMH_ERR_INVALID_ARG;
 }
 
@@ -423,6 +430,10 @@ int mmh_get_option(mmh_handle_t h, int option, int *value) {
   if (!h || !value) return MMH_ERR_INVALID_ARG;
   if (option == MMH_OPT_STREAMK) {
     *value = h->streamk;
+    return MMH_OK;
+  }
+  if (option == MMH_OPT_IGEMM_MODE) {
+    *value = h->igemm_mode;
     return MMH_OK;
   }
   if (option == MMH_OPT_STREAMK_TIMEOUTS) {
@@ -519,7 +530,10 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
       HIP_TRY(hipMemset2DAsync(dC, (size_t)ldc * 4, 0, (size_t)n * 4, (size_t)m, s));
     return MMH_OK;
   }
-  HIP_TRY(mmh::launch_igemm_s8(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
+  int8_t *bt = nullptr;
+  if (h->igemm_mode == 0 && h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
+    bt = static_cast<int8_t *>(h->bt.p);
+  HIP_TRY(mmh::launch_igemm_s8(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s, bt, h->igemm_mode));
   return MMH_OK;
 }
 
@@ -571,7 +585,10 @@ int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
   hipLaunchKernelGGL(mmh::quantize_kernel, dim3(ga), dim3(256), 0, s, dA, m, k, lda, amax, qa, ka, scales);
   hipLaunchKernelGGL(mmh::quantize_kernel, dim3(gb), dim3(256), 0, s, dB, k, n, ldb, amax + 1, qb, nb,
                      scales + 1);
-  HIP_TRY(mmh::launch_igemm_s8(m, n, k, qa, ka, qb, nb, qc, nb, 0, s));
+  int8_t *bt = nullptr;
+  if (h->igemm_mode == 0 && h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
+    bt = static_cast<int8_t *>(h->bt.p);
+  HIP_TRY(mmh::launch_igemm_s8(m, n, k, qa, ka, qb, nb, qc, nb, 0, s, bt, h->igemm_mode));
   hipLaunchKernelGGL(mmh::dequantize_kernel, dim3(mmh::quant_grid((size_t)m * n)), dim3(256), 0, s, qc, m,
                      n, nb, scales, scales + 1, dC, ldc);
   HIP_TRY(hipGetLastError());

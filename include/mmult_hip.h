@@ -103,6 +103,9 @@ const char *mmh_kernel_name(int kernel);
  * something is badly wrong; a timed-out launch produced wrong results). */
 #define MMH_OPT_STREAMK 1
 #define MMH_OPT_STREAMK_TIMEOUTS 2
+/* MMH_OPT_IGEMM_MODE: 0 (default) pack B once per call and feed both operands by LDS-DMA,
+ * 1 transpose B inside the GEMM kernel, 2 the correctness-first kernel (A/B switch). */
+#define MMH_OPT_IGEMM_MODE 3
 int mmh_set_option(mmh_handle_t handle, int option, int value);
 int mmh_get_option(mmh_handle_t handle, int option, int *value);
 
@@ -127,7 +130,9 @@ int mmh_sgemm_host(mmh_handle_t handle, int m, int n, int k, const float *A, int
                    const float *B, int ldb, float *C, int ldc, int accumulate);
 
 /* int8 x int8 -> int32, C = A*B (+ C), row-major, inputs expected in
- * [-127,127]; bit-exact integer arithmetic on v_mfma_i32_16x16x64_i8. */
+ * [-127,127]; bit-exact integer arithmetic on v_mfma_i32_16x16x64_i8.  B is packed
+ * (transposed, zero-padded) into a handle-owned workspace on every call -- one handle
+ * per stream. */
 int mmh_igemm_s8(mmh_handle_t handle, int m, int n, int k, const int8_t *dA, int lda,
                  const int8_t *dB, int ldb, int32_t *dC, int ldc, int accumulate,
                  void *stream);
