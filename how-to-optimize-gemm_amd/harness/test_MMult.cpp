@@ -19,11 +19,15 @@
 //
 //   PFIRST PLAST PINC M N K NREPEATS LDA LDB LDC   sweep shape
 //   KERNEL=auto|mfma|mfma256|mfma_128x64|mfma_64x64|mfma_pipe|mfma_simple|valu|naive|rocblas
-//   FLAVOUR=device|host|cpu      device: C=A*B on device pointers (cuda/ flavour)
+//   FLAVOUR=device|host|cpu|sharded
+//                                device: C=A*B on device pointers (cuda/ flavour)
 //                                host  : MY_MMult(m,n,k,a,lda,...) on host pointers, C+=A*B,
 //                                        best-of-NREPEATS with dclock (armv7/aarch64 flavour)
 //                                cpu   : MY_MMult := the serial triple loop, no GPU at all
 //                                        (BASELINE.json config 1, plumbing check: diff = 0)
+//                                sharded: C row panels over NGPUS devices of this process, B by
+//                                        one ncclBroadcast (BASELINE.json config 4); GFLOPS from
+//                                        the GEMM phase, EXTENDED adds h2d/bcast/gemm/d2h ms
 //   INPUT=drand48|seed:<n>|mod3|mod2|ones           (cuda/random_matrix.cpp:9-15 variants)
 //   REF=threads|serial|skip    how cref is produced (skip: diff column is -1)
 //   WARMUP=<n>                 untimed launches before the timed loop (reference: 0)
@@ -47,7 +51,7 @@ namespace {
 
 struct Options {
   int pfirst = PFIRST, plast = PLAST, pinc = PINC, m = M, n = N, k = K, nrepeats = NREPEATS;
-  int lda = LDA, ldb = LDB, ldc = LDC, warmup = 0, extended = 0;
+  int lda = LDA, ldb = LDB, ldc = LDC, warmup = 0, extended = 0, ngpus = 1;
   std::string kernel = "auto", flavour = "device", input = "drand48", ref = "threads";
 };
 
@@ -99,6 +103,7 @@ int main(int argc, char **argv) {
   opt_int(argc, argv, "LDA", o.lda);        opt_int(argc, argv, "LDB", o.ldb);
   opt_int(argc, argv, "LDC", o.ldc);        opt_int(argc, argv, "WARMUP", o.warmup);
   opt_int(argc, argv, "EXTENDED", o.extended);
+  opt_int(argc, argv, "NGPUS", o.ngpus);
   opt_str(argc, argv, "KERNEL", o.kernel);  opt_str(argc, argv, "FLAVOUR", o.flavour);
   opt_str(argc, argv, "INPUT", o.input);    opt_str(argc, argv, "REF", o.ref);
   if (o.pinc <= 0 || o.nrepeats <= 0) { std::fprintf(stderr, "bad PINC/NREPEATS\n"); return 2; }
@@ -106,6 +111,7 @@ int main(int argc, char **argv) {
 
   const bool cpu_only = o.flavour == "cpu";
   const bool host_flavour = o.flavour == "host";
+  const bool sharded = o.flavour == "sharded";
   mmh_handle_t handle = nullptr;
   hipEvent_t start{}, stop{};
   const int kid = kernel_id(o.kernel);
@@ -160,7 +166,17 @@ int main(int argc, char **argv) {
     }
 
     double seconds = 0.0;
-    if (cpu_only) {
+    float phase_ms[4] = {0, 0, 0, 0};
+    if (sharded) {
+      double best = 0.0;
+      for (int rep = 0; rep < o.nrepeats + o.warmup; ++rep) {
+        float t[4];
+        MMH_CHECK(mmh_sgemm_sharded(o.ngpus, m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc,
+                                    kid >= 0 ? kid : MMH_KERNEL_AUTO, t));
+        if (rep == 0 || t[2] < best) { best = t[2]; std::copy(t, t + 4, phase_ms); }
+      }
+      seconds = best * 1e-3;
+    } else if (cpu_only) {
       double best = 0.0;
       for (int rep = 0; rep < o.nrepeats; ++rep) {
         std::fill(cold.begin(), cold.end(), 0.f);
@@ -217,7 +233,11 @@ int main(int argc, char **argv) {
         return -1;
       }
     }
-    if (o.extended)
+    if (o.extended && sharded)
+      std::printf("%d %.2f %le %.2f %.3f %.3f %.3f %.3f \n", p, gflops, diff,
+                  100.0 * gflops / (o.ngpus * kPeakTflops * 1e3), phase_ms[0], phase_ms[1], phase_ms[2],
+                  phase_ms[3]);
+    else if (o.extended)
       std::printf("%d %.2f %le %.2f %.3f %d \n", p, gflops, diff,
                   100.0 * gflops / (kPeakTflops * 1e3), ref_gflops, ref_cores);
     else

@@ -189,6 +189,44 @@ def test_stream_k_is_bit_identical(mm, oracle, shape):
     mm.set_streamk(True)
 
 
+@pytest.mark.parametrize("kernel", ["mfma", "mfma_128x64", "mfma_64x64", "valu"])
+def test_subnormals_and_nonfinite_values_follow_the_chain(mm, oracle, kernel):
+    """Edge values the reference loop would produce on the CPU must come out of the
+    GPU chain the same way: subnormal products and sums are not flushed (the f32 MFMA
+    keeps them, cdna guide section 3), infinities propagate, inf - inf / 0 * inf give NaN
+    in exactly the same elements."""
+    import torch
+    mm.set_kernel(kernel)
+    m, n, k = 128, 192, 96
+    a, b = oracle.harness_inputs(m, n, k, seed=99)
+    # subnormal territory: |a*b| ~ 1e-42, sums stay subnormal
+    a_s, b_s = (a * np.float32(1e-21)).astype(np.float32), (b * np.float32(1e-21)).astype(np.float32)
+    got = mm.matmul(dev(a_s), dev(b_s)).cpu().numpy()
+    want = oracle.ref_mmult(a_s, b_s, fma=True)
+    assert np.array_equal(got, want)
+    assert np.any((want != 0) & (np.abs(want) < np.finfo(np.float32).tiny)), "test must reach subnormals"
+    # huge values: overflow to +-inf happens at the same partial sum
+    a_h, b_h = (a * np.float32(3e19)).astype(np.float32), (b * np.float32(3e19)).astype(np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        want = oracle.ref_mmult(a_h, b_h, fma=True)
+    got = mm.matmul(dev(a_h), dev(b_h)).cpu().numpy()
+    assert np.isinf(want).any()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[~np.isnan(want)], want[~np.isnan(want)])
+    # planted inf / nan in the operands
+    a_p, b_p = a.copy(), b.copy()
+    a_p[3, 5] = np.inf
+    a_p[70, 10] = -np.inf
+    b_p[5, 7] = 0.0          # inf * 0 -> nan at C[3, 7]
+    b_p[20, 100] = np.nan
+    with np.errstate(invalid="ignore"):
+        want = oracle.ref_mmult(a_p, b_p, fma=True)
+    got = mm.matmul(dev(a_p), dev(b_p)).cpu().numpy()
+    assert np.isnan(want[3, 7]) and np.isnan(want[:, 100]).all()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[~np.isnan(want)], want[~np.isnan(want)])
+
+
 def test_accumulate_and_overwrite_semantics(mm, oracle):
     import torch
     a, b = oracle.harness_inputs(256, 384, 128, seed=31)

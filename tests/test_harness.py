@@ -105,6 +105,18 @@ def test_host_flavour_on_gpu():
 
 
 @pytest.mark.gpu
+def test_sharded_flavour_single_process_on_gpu():
+    """BASELINE config 4 through the C++ harness: mmh_sgemm_sharded with NGPUS=1 here (the
+    RCCL broadcast is skipped for one device); exact on the known-answer inputs."""
+    build()
+    rc, out, err = run({"FLAVOUR": "sharded", "NGPUS": 1, "PFIRST": 512, "PLAST": 1024, "PINC": 512,
+                        "INPUT": "mod3", "NREPEATS": 2})
+    assert rc == 0, err
+    rows = parse(out)
+    assert [r[0] for r in rows] == [512, 1024] and all(r[2] == 0.0 for r in rows)
+
+
+@pytest.mark.gpu
 def test_reference_driver_linked_against_our_MY_MMult():
     """The reference's own armv7/test_MMult.c + REF_MMult.c + compare_matrices.c
     (object code built from /root/reference by oracle/Makefile) with ONLY
