@@ -86,6 +86,11 @@ if "small" in what:
     print("N      " + "  ".join(f"{k:>11}" for k in ks))
     for n in list(range(512, 1024, 128)) + list(range(1024, 2945, 128)):
         print(f"{n:5d}  " + "  ".join(f"{time_f32(n, n, n, k, reps=10):11.1f}" for k in ks), flush=True)
+if "mid" in what:
+    ks = ["mfma", "mfma_tiles", "rocblas"]
+    print("N      " + "  ".join(f"{k:>11}" for k in ks))
+    for n in range(1920, 3201, 128):
+        print(f"{n:5d}  " + "  ".join(f"{time_f32(n, n, n, k, reps=10):11.1f}" for k in ks), flush=True)
 if "big" in what:
     for n in (8192, 16384):
         print(f"fp32 N={n}: mfma {time_f32(n, n, n, reps=5):7.1f}  mfma256 {time_f32(n, n, n, 'mfma256', reps=5):7.1f}")
