@@ -1,23 +1,24 @@
 // parameters.h -- sweep defaults of the MI355X harness.
 //
-// Same knobs as the reference's cuda/parameters.h:5-24 (PFIRST/PLAST/PINC,
-// M/N/K = -1 binds the dimension to p, NREPEATS) and armv7/parameters.h:38-46
-// (LDA/LDB/LDC = -1 binds the leading dimension to the row length), but they
-// are DEFAULTS: every one can be overridden at run time by an environment
-// variable of the same name or a --name=value argument, so one binary covers
-// all five BASELINE.json configurations.
+// The knobs are the reference's (cuda/parameters.h:5-24: first/last/increment of the square
+// size p, optional fixed m/n/k, repeat count; armv7/parameters.h:38-46: optional fixed leading
+// dimensions), but here they are DEFAULTS of run-time options, not compile-time macros: every
+// one can be overridden by an environment variable (PFIRST, PLAST, PINC, M, N, K, NREPEATS,
+// LDA, LDB, LDC) or a --NAME=value argument, so one binary covers all BASELINE.json configs.
 #pragma once
 
-#define PFIRST 1024
-#define PLAST 4096
-#define PINC 128
+namespace sweep_defaults {
 
-#define M -1
-#define N -1
-#define K -1
+constexpr int kFirstSize = 1024;   // p runs kFirstSize, kFirstSize + kStep, ... <= kLastSize
+constexpr int kLastSize = 4096;
+constexpr int kStep = 128;
 
-#define NREPEATS 20
+constexpr int kBoundToP = -1;      // a dimension set to this follows p (the reference's "-1")
+constexpr int kM = kBoundToP, kN = kBoundToP, kK = kBoundToP;
 
-#define LDA -1
-#define LDB -1
-#define LDC -1
+constexpr int kRepeats = 20;       // timed back-to-back calls per size
+
+// leading dimensions; kBoundToP = dense (lda = k, ldb = n, ldc = n)
+constexpr int kLda = kBoundToP, kLdb = kBoundToP, kLdc = kBoundToP;
+
+}  // namespace sweep_defaults

@@ -50,8 +50,11 @@ void MY_MMult(mmh_handle_t, int, int, int, float *, int, float *, int, float *, 
 namespace {
 
 struct Options {
-  int pfirst = PFIRST, plast = PLAST, pinc = PINC, m = M, n = N, k = K, nrepeats = NREPEATS;
-  int lda = LDA, ldb = LDB, ldc = LDC, warmup = 0, extended = 0, ngpus = 1;
+  int pfirst = sweep_defaults::kFirstSize, plast = sweep_defaults::kLastSize, pinc = sweep_defaults::kStep;
+  int m = sweep_defaults::kM, n = sweep_defaults::kN, k = sweep_defaults::kK;
+  int nrepeats = sweep_defaults::kRepeats;
+  int lda = sweep_defaults::kLda, ldb = sweep_defaults::kLdb, ldc = sweep_defaults::kLdc;
+  int warmup = 0, extended = 0, ngpus = 1;
   std::string kernel = "auto", flavour = "device", input = "drand48", ref = "threads";
 };
 
