@@ -98,6 +98,11 @@ def pmc_traffic(n: int):
 
 def main():
     args = parse_args()
+    # Rank 0 must print ONE JSON line on stdout, but RCCL writes its version banner to the
+    # process's stdout at communicator creation: park fd 1 on stderr until the line is ready.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import how_to_optimize_gemm_amd as H
 
@@ -311,8 +316,11 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
