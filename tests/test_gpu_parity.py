@@ -455,6 +455,30 @@ def test_row_panel_shard_reassembles_full_product(mm, oracle):
         assert torch.equal(out, full)
 
 
+def test_config4_panel_at_full_size_sampled_rows(mm, oracle):
+    """BASELINE configs[3] at its real size: one rank's share of the N=16384 problem
+    (rows mmh_shard_rows(16384, 8, r) of A, all of B = 1 GiB).  The full oracle would take
+    minutes, so a deterministic sample of rows (first, last, tile edges) is checked
+    bit-exactly against the fused chain, plus the size-independent sub-problem property."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    n = 16384
+    r0, rows = H.shard_rows(n, 8, 3)
+    assert (r0, rows) == (6144, 2048)
+    g = torch.Generator(device="cuda").manual_seed(16384)
+    a = torch.rand((rows, n), device="cuda", generator=g) * 2 - 1
+    b = torch.rand((n, n), device="cuda", generator=g) * 2 - 1
+    mm.set_kernel("auto")
+    c = mm.matmul(a, b)
+    sample = [0, 1, 127, 128, 1000, 2047]
+    want = oracle.ref_mmult(a[sample].cpu().numpy(), b.cpu().numpy(), fma=True)
+    assert np.array_equal(c[sample].cpu().numpy(), want)
+    # a 128-row slab of the panel computed on its own gives the same bits
+    assert torch.equal(mm.matmul(a[512:640], b), c[512:640])
+    del a, b, c
+    torch.cuda.empty_cache()
+
+
 def test_peak_probes_are_sane(mm):
     tf = mm.probe_mfma_f32()
     assert 100.0 < tf < 165.0, tf          # 157.3 TFLOP/s is the fp32 MFMA peak
