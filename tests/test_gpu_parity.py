@@ -479,6 +479,21 @@ def test_config4_panel_at_full_size_sampled_rows(mm, oracle):
     torch.cuda.empty_cache()
 
 
+def test_differential_fuzz_and_stream_k_stress():
+    """tools/fuzz.py: random shapes / leading dimensions / misaligned bases / accumulate flags,
+    every kernel variant bit-equal to the naive kernel and nothing written outside C's window;
+    then repeated stream-K launches on ragged tile counts against the plain launch."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz.py"), "80", "15", "2026"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "fuzz: 80 cases x 8 variants, 0 failures" in r.stdout
+    assert "stream-K stress: 0 failures" in r.stdout
+
+
 def test_peak_probes_are_sane(mm):
     tf = mm.probe_mfma_f32()
     assert 100.0 < tf < 165.0, tf          # 157.3 TFLOP/s is the fp32 MFMA peak
