@@ -28,11 +28,11 @@ KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_256, KERNEL_NAIVE, KERNEL_MFM
 OPT_STREAMK, OPT_STREAMK_TIMEOUTS, OPT_IGEMM_MODE = 1, 2, 3
 KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
-           "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11}
+           "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11, "mfma_256x256": 12}
 
 # every symbol include/mmult_hip.h declares (tests assert the .so exports them all)
 EXPORTS = [
-    "mmh_strerror", "mmh_last_error", "mmh_version", "mmh_device_count", "mmh_device_info",
+    "mmh_strerror", "mmh_last_error", "mmh_last_launch", "mmh_version", "mmh_device_count", "mmh_device_info",
     "mmh_create", "mmh_destroy", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name",
     "mmh_set_option", "mmh_get_option",
     "mmh_sgemm", "mmh_sgemm_host", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
     L.mmh_strerror.argtypes = [C.c_int]
     L.mmh_strerror.restype = C.c_char_p
     L.mmh_last_error.restype = C.c_char_p
+    L.mmh_last_launch.restype = C.c_char_p
     L.mmh_version.restype = C.c_int
     L.mmh_device_count.argtypes = [ip]
     L.mmh_device_info.argtypes = [C.c_int, C.c_char_p, ip, ip]
@@ -139,6 +140,11 @@ def shard_rows(m: int, nranks: int, rank: int) -> tuple[int, int]:
     r0, nr = C.c_int(0), C.c_int(0)
     _check(lib().mmh_shard_rows(m, nranks, rank, C.byref(r0), C.byref(nr)), "mmh_shard_rows")
     return r0.value, nr.value
+
+
+def last_launch() -> str:
+    """Which kernel configuration the last sgemm call on this thread launched."""
+    return lib().mmh_last_launch().decode()
 
 
 def kernel_name(kernel: int) -> Optional[str]:
@@ -382,7 +388,7 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
     return c, dict(zip(("h2d", "bcast", "gemm", "d2h"), list(t)))
 
 
-__all__ = ["MMult", "MMultError", "lib", "device_count", "shard_rows", "kernel_name", "sgemm_sharded",
+__all__ = ["MMult", "MMultError", "lib", "device_count", "shard_rows", "kernel_name", "last_launch", "sgemm_sharded",
            "KERNELS", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
            "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OPT_IGEMM_MODE", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

@@ -27,6 +27,7 @@
 namespace {
 
 thread_local std::string g_last_error;
+thread_local std::string g_last_launch;   // which kernel configuration the last sgemm call ran
 
 int hip_fail(hipError_t e, const char *what) {
   g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -117,7 +118,7 @@ int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, in
     if (ok != MMH_OK) return ok;                                                           \
     hipLaunchKernelGGL(kern, grid, block, lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm, nbn); \
   } while (0)
-  if (SIMPLE) {
+  if constexpr (SIMPLE) {
     if (fast) MMH_LAUNCH((mmh::sgemm_mfma_simple_kernel<BM, BN, false>));
     else      MMH_LAUNCH((mmh::sgemm_mfma_simple_kernel<BM, BN, true>));
   } else if (!fast) {
@@ -132,6 +133,13 @@ int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, in
   }
 #undef MMH_LAUNCH
   HIP_TRY(hipGetLastError());
+  {
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s<%d,%d> wave tile %dx%d, K-slice %d, %s%d workgroups of %d threads",
+             SIMPLE ? "sgemm_mfma_simple_kernel" : "sgemm_mfma_kernel", BM, BN, 16 * WTM, 16 * WTN, KB,
+             fast ? "" : "guarded, ", nbm * nbn, threads);
+    g_last_launch = buf;
+  }
   return MMH_OK;
 }
 
@@ -184,6 +192,13 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
                      acc, nbm, nbn, flags, flags + tiles);
   HIP_TRY(hipGetLastError());
+  {
+    char buf[160];
+    snprintf(buf, sizeof buf,
+             "sgemm_mfma_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d, %ld tiles on %d persistent workgroups",
+             BM, BN, 16 * WTM, 16 * WTN, KB, tiles, grid);
+    g_last_launch = buf;
+  }
   return MMH_OK;
 }
 
@@ -203,6 +218,7 @@ int launch_valu(int m, int n, int k, const float *A, int lda, const float *B, in
     hipLaunchKernelGGL(mmh::sgemm_valu_kernel<true>, grid, block, lds, s, m, n, k, A, lda, B, ldb,
                        C, ldc, acc, nbm, nbn);
   HIP_TRY(hipGetLastError());
+  g_last_launch = "sgemm_valu_kernel<128,128>";
   return MMH_OK;
 }
 
@@ -260,6 +276,9 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
       const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
       const long tiles128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);
+      const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
+      if (tiles256 >= cus)      // at least one 256x256 tile per CU: the big tile (fewest staging ops per MFMA)
+        return sgemm_on(ctx, MMH_KERNEL_MFMA_256X256, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
       if (tiles128x64 * 2 <= cus)
         return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
       if (tiles128 * 10 < cus * 8)
@@ -274,6 +293,11 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
     }
     case MMH_KERNEL_MFMA_TILES:   // K2 without stream-K (one workgroup per tile, always)
       return launch_mfma<128, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_MFMA_256X256: {  // 256x256 tile, 8 waves of 128x64 (one workgroup per CU)
+      const int sk = try_launch_streamk<256, 256, 4, 8, 32>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      return launch_mfma<256, 256, false, 4, 0, true, 4, 8, 32>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    }
     case MMH_KERNEL_MFMA_64X64: {    // 64x64 tile, 4 waves of 32x32, 128-deep K-slices
       const int sk = try_launch_streamk<64, 64, 2, 2, 128>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
       if (sk <= 0) return sk;
@@ -342,6 +366,8 @@ const char *mmh_strerror(int status) {
 }
 
 const char *mmh_last_error(void) { return g_last_error.c_str(); }
+
+const char *mmh_last_launch(void) { return g_last_launch.c_str(); }
 
 int mmh_version(void) { return 100; }
 
@@ -466,6 +492,7 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_TILES: return "MMult_hip_mfma_tiles";
     case MMH_KERNEL_MFMA_128X64: return "MMult_hip_mfma_128x64";
     case MMH_KERNEL_MFMA_64X64: return "MMult_hip_mfma_64x64";
+    case MMH_KERNEL_MFMA_256X256: return "MMult_hip_mfma_256x256";
     case 19: return "exp_dma_b";
     case 16: return "cadence_3";
     case 17: return "cadence_4";

@@ -185,8 +185,9 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   // chain another workgroup began -- stream-K below); the tile is stored at the end.
   // WTN = MFMA tiles per wave along n: 4 -> 64x64 wave tiles (16-byte B fragments),
   // 2 -> 64x32 wave tiles (8-byte B fragments, twice the waves per block tile)
-  // WTM likewise along m (4 -> 64 rows, 2 -> 32 rows); KB = K-slice depth per LDS buffer.
-  static_assert((WTN == 4 || WTN == 2) && (WTM == 4 || WTM == 2), "wave tile is 64|32 x 64|32");
+  // WTM likewise along m (4 -> 64 rows, 2 -> 32 rows, 8 -> 128 rows = two 64-row halves, each
+  // read with its own ds_read_b128); KB = K-slice depth per LDS buffer.
+  static_assert((WTN == 4 || WTN == 2) && (WTM == 8 || WTM == 4 || WTM == 2), "wave tile is 128|64|32 x 64|32");
   // DMAB: B goes global -> LDS directly (buffer_load ... lds), A still through registers
   static_assert(!DMAB || (BUFLD && WTN == 4), "LDS-DMA needs descriptors and the linear B image");
   constexpr int WAVES_N = BN / (16 * WTN);
@@ -204,8 +205,11 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   const int wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 15, kq = lane >> 4;
-  // C rows/cols of this lane: row(t, r) = crow + WTM*r + t, cols ccol .. ccol+WTN-1
-  const int crow = row0 + wm * 16 * WTM + 4 * WTM * kq;
+  // C rows/cols of this lane: row(t, r) = crow + RT*r + (t % RT) + 64*(t / RT) with RT = min(WTM, 4)
+  // rows interleaved per 64-row half; cols ccol .. ccol+WTN-1
+  constexpr int RT = WTM < 4 ? WTM : 4;
+  const int crow = row0 + wm * 16 * WTM + 4 * RT * kq;
+  auto c_row = [&](int t, int r) { return crow + RT * r + (t % RT) + 64 * (t / RT); };
   const int ccol = col0 + wn * 16 * WTN + WTN * li;
 
   // a guarded launch still uses 16-byte C accesses in its interior blocks; there
@@ -219,7 +223,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
     for (int t = 0; t < WTM; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = crow + WTM * r + t;
+        const int row = c_row(t, r);
         bfrag_t v = {};
         if (whole_c) {
           v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
@@ -240,7 +244,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
 
   StageT st;
   const int nk = (k + KB - 1) / KB;
-  const int a_slot = WTM == 4 ? wm * 16 + li : wm * 8 + (li >> 1);   // slot = m/4 of the fragment
+  const int a_slot = WTM == 2 ? wm * 8 + (li >> 1) : wm * 4 * WTM + li;   // slot = m/4 of the fragment
   const int b_off = A_FLOATS + kq * BN + wn * 64 + 4 * li;   // WTN == 4
   const int b_slot = wn * 8 + (li >> 1);                        // WTN == 2
 
@@ -281,7 +285,12 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   };
 
   auto frag_a = [&](const float *buf, int ks) {
-    if constexpr (WTM == 4) {
+    if constexpr (WTM == 8) {
+      const float *p = buf + (4 * ks + kq) * BM;
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(p + 4 * (a_slot ^ swz_slot(ks)));
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(p + 4 * ((a_slot + 16) ^ swz_slot(ks)));
+      return afrag_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else if constexpr (WTM == 4) {
       return *reinterpret_cast<const afrag_t *>(buf + (4 * ks + kq) * BM + 4 * (a_slot ^ swz_slot(ks)));
     } else {
       return *reinterpret_cast<const afrag_t *>(buf + (4 * ks + kq) * BM +
@@ -383,7 +392,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
       // slice, then the NMEM global loads of the slice after next -- instead of the
       // bursts of 6-8 the scheduler would otherwise emit.
       if (SCHED >= 4) {
-        if (ks + 1 < KS || MORE) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+        if (ks + 1 < KS || MORE) __builtin_amdgcn_sched_group_barrier(0x100, WTM == 8 ? 3 : 2, 0);  // DS read
         if (ks + 1 < KS) {
 #pragma unroll
           for (int i = 0; i < UPK; ++i) {
@@ -417,7 +426,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   for (int t = 0; t < WTM; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = crow + WTM * r + t;
+      const int row = c_row(t, r);
       bfrag_t v;
 #pragma unroll
       for (int u = 0; u < WTN; ++u) v[u] = acc[t][u][r];

@@ -12,7 +12,7 @@
 // (cuda/test_MMult.cpp:13-14: leading handle argument, C = A*B, asynchronous).
 //
 // Kernel variant: environment variable MMULT_KERNEL = auto (default) | mfma | mfma256 |
-// mfma_128x64 | mfma_64x64 | mfma_pipe | mfma_simple | valu | naive (the run-time form of the reference's
+// mfma_256x256 | mfma_128x64 | mfma_64x64 | mfma_pipe | mfma_simple | valu | naive (the run-time form of the reference's
 // `NEW := MMult_xxx`, cuda/makefile:3).
 #include <cstdio>
 #include <cstdlib>
@@ -26,7 +26,7 @@ int kernel_from_env() {
   const char *e = std::getenv("MMULT_KERNEL");
   if (!e || !*e) return MMH_KERNEL_AUTO;
   struct { const char *name; int id; } table[] = {
-      {"mfma", MMH_KERNEL_MFMA}, {"mfma256", MMH_KERNEL_MFMA_256}, {"mfma_64x64", MMH_KERNEL_MFMA_64X64}, {"mfma_128x64", MMH_KERNEL_MFMA_128X64}, {"mfma_pipe", MMH_KERNEL_MFMA_PIPE},
+      {"mfma", MMH_KERNEL_MFMA}, {"mfma256", MMH_KERNEL_MFMA_256}, {"mfma_64x64", MMH_KERNEL_MFMA_64X64}, {"mfma_256x256", MMH_KERNEL_MFMA_256X256}, {"mfma_128x64", MMH_KERNEL_MFMA_128X64}, {"mfma_pipe", MMH_KERNEL_MFMA_PIPE},
       {"mfma_simple", MMH_KERNEL_MFMA_SIMPLE}, {"valu", MMH_KERNEL_VALU}, {"naive", MMH_KERNEL_NAIVE},
       {"auto", MMH_KERNEL_AUTO}};
   for (auto &t : table)

@@ -18,7 +18,7 @@
 // (environment variable NAME or --NAME=value), defaults from parameters.h:
 //
 //   PFIRST PLAST PINC M N K NREPEATS LDA LDB LDC   sweep shape
-//   KERNEL=auto|mfma|mfma256|mfma_128x64|mfma_64x64|mfma_pipe|mfma_simple|valu|naive|rocblas
+//   KERNEL=auto|mfma|mfma256|mfma_256x256|mfma_128x64|mfma_64x64|mfma_pipe|mfma_simple|valu|naive|rocblas
 //   FLAVOUR=device|host|cpu|sharded
 //                                device: C=A*B on device pointers (cuda/ flavour)
 //                                host  : MY_MMult(m,n,k,a,lda,...) on host pointers, C+=A*B,
@@ -76,6 +76,7 @@ int kernel_id(const std::string &s) {
   if (s == "auto") return MMH_KERNEL_AUTO;
   if (s == "mfma256") return MMH_KERNEL_MFMA_256;
   if (s == "mfma_64x64") return MMH_KERNEL_MFMA_64X64;
+  if (s == "mfma_256x256") return MMH_KERNEL_MFMA_256X256;
   if (s == "mfma_128x64") return MMH_KERNEL_MFMA_128X64;
   if (s == "mfma_pipe") return MMH_KERNEL_MFMA_PIPE;
   if (s == "mfma_simple") return MMH_KERNEL_MFMA_SIMPLE;

@@ -60,7 +60,7 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_ERR_COMM (-6)        /* RCCL call failed                             */
 
 /* kernel variants (the reference's "NEW := MMult_xxx" ladder, MI355X edition) */
-#define MMH_KERNEL_AUTO 0        /* 64x64 / 128x64 / 128x128 tiles chosen by how the shape fills the chip */
+#define MMH_KERNEL_AUTO 0        /* 64x64 / 128x64 / 128x128 / 256x256 tiles chosen by how the shape fills the chip */
 #define MMH_KERNEL_VALU 1        /* K1: LDS-tiled 128x128, 8x8 per thread, VALU fma only   */
 #define MMH_KERNEL_MFMA 2        /* K2: 128x128 block tile on v_mfma_f32_16x16x4_f32; K-slice
                                     hand-over pipelined across the barrier, staging ops dealt
@@ -74,6 +74,7 @@ typedef struct mmh_context *mmh_handle_t;
                                     compiler-scheduled staging and 64-bit global loads      */
 #define MMH_KERNEL_MFMA_TILES 10 /* K2 always as one workgroup per tile (no stream-K), for A/B      */
 #define MMH_KERNEL_MFMA_128X64 8 /* K2 with a 128x64 block tile, 4 waves of 64x32                   */
+#define MMH_KERNEL_MFMA_256X256 12 /* K2 with a 256x256 block tile, 8 waves of 128x64 (1 WG/CU)       */
 #define MMH_KERNEL_MFMA_64X64 11 /* K2 with a 64x64 block tile, 4 waves of 32x32, 128-deep K-slices  */
 /* ids 16-19 are A/B builds of K2 with valid results (staging cadence 3/4/1 MFMAs per op; 19 =
  * B staged by LDS-DMA, buffer_load ... lds); ids >= 32 are timing-only ablation builds whose
@@ -83,6 +84,9 @@ typedef struct mmh_context *mmh_handle_t;
 const char *mmh_strerror(int status);
 /* Text of the last HIP/RCCL error seen on this thread ("" if none). */
 const char *mmh_last_error(void);
+/* Which kernel configuration the last mmh_sgemm on this thread launched (tile, wave tile,
+ * grid, plain / stream-K / guarded) -- what MMH_KERNEL_AUTO chose. */
+const char *mmh_last_launch(void);
 int mmh_version(void);                 /* 100*major + minor */
 int mmh_device_count(int *count);
 /* name must hold >= 256 bytes; cu_count / clock_mhz may be NULL. */

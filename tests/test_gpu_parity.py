@@ -19,7 +19,7 @@ from conftest import golden_cases, load_golden
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["mfma", "mfma256", "mfma_128x64", "mfma_64x64", "auto", "mfma_pipe", "mfma_simple", "valu", "naive"]
+KERNELS = ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "auto", "mfma_pipe", "mfma_simple", "valu", "naive"]
 
 
 def tol(k):
@@ -77,7 +77,7 @@ SHAPES = [(256, 256, 256), (384, 640, 1024), (128, 128, 32), (128, 256, 4096), (
           (130, 129, 37), (3, 5, 7), (257, 255, 513), (512, 128, 2048), (1024, 1024, 1024)]
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_128x64", "mfma_64x64", "valu"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "valu"])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_seeded_inputs_vs_oracle(mm, oracle, shape, kernel):
     m, n, k = shape
@@ -189,7 +189,7 @@ def test_stream_k_is_bit_identical(mm, oracle, shape):
     mm.set_streamk(True)
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma_128x64", "mfma_64x64", "valu"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma_256x256", "mfma_128x64", "mfma_64x64", "valu"])
 def test_subnormals_and_nonfinite_values_follow_the_chain(mm, oracle, kernel):
     """Edge values the reference loop would produce on the CPU must come out of the
     GPU chain the same way: subnormal products and sums are not flushed (the f32 MFMA
@@ -291,7 +291,7 @@ def test_unaligned_pointers_take_the_guarded_path(mm, oracle):
     assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_128x64", "mfma_64x64"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64"])
 def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
     """Every operand only 4-byte aligned, odd lda/ldb/ldc, ragged m/n/k, with
     poison around the matrices: the descriptor-bounded path must neither read
@@ -490,7 +490,7 @@ def test_differential_fuzz_and_stream_k_stress():
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz.py"), "80", "15", "2026"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "fuzz: 80 cases x 8 variants, 0 failures" in r.stdout
+    assert "fuzz: 80 cases x 9 variants, 0 failures" in r.stdout
     assert "stream-K stress: 0 failures" in r.stdout
 
 

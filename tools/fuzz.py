@@ -18,7 +18,7 @@ seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rng = np.random.default_rng(seed)
 mm = H.MMult(0)
 stream = torch.cuda.current_stream().cuda_stream
-VARIANTS = ["auto", "mfma", "mfma256", "mfma_128x64", "mfma_64x64", "mfma_pipe", "mfma_simple", "valu"]
+VARIANTS = ["auto", "mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "mfma_pipe", "mfma_simple", "valu"]
 
 
 def strided(rows, cols, ld, off, fill=None):
@@ -69,12 +69,12 @@ print(f"fuzz: {cases} cases x {len(VARIANTS)} variants, {bad} failures")
 
 # stream-K stress
 sk_bad = 0
-for n in (2176, 2432, 2944, 3072, 3456, 3712):
+for n in (2176, 2432, 2944, 3072, 3456, 3712, 4352, 4608):
     a = torch.rand((n, n), device="cuda") * 2 - 1
     b = torch.rand((n, n), device="cuda") * 2 - 1
     mm.set_kernel("mfma_tiles")
     ref = mm.matmul(a, b)
-    mm.set_kernel("mfma")
+    mm.set_kernel("auto" if n > 4096 else "mfma")     # > 4096: the 256x256 tile under stream-K
     c = torch.empty_like(ref)
     for rep in range(stress):
         c.fill_(float("nan"))
