@@ -38,7 +38,7 @@ EXPORTS = [
     "mmh_sgemm", "mmh_sgemm_host", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
     "mmh_sgemm_rocblas", "mmh_shard_rows",
     "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
-    "mmh_probe_hbm_copy",
+    "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy",
 ]
 
 
@@ -116,6 +116,7 @@ def lib() -> C.CDLL:
     L.mmh_time_sgemm.argtypes = gemm + [C.c_int, C.c_int, vp, fp]
     L.mmh_probe_mfma_f32.argtypes = [vp, fp]
     L.mmh_probe_mfma_i8.argtypes = [vp, fp]
+    L.mmh_probe_mfma_i8_sustained.argtypes = [vp, C.c_int, C.c_float, fp]
     L.mmh_probe_hbm_copy.argtypes = [vp, C.c_size_t, fp]
     _lib = L
     return L
@@ -202,7 +203,9 @@ class MMult:
         _check(lib().mmh_set_option(self._h, OPT_STREAMK, int(bool(on))), "mmh_set_option")
 
     def set_igemm_mode(self, mode: int) -> None:
-        """0 packed-B + LDS-DMA (default), 1 in-kernel transpose, 2 correctness-first kernel."""
+        """0 packed-B + LDS-DMA, tile picked by size (default); 1 in-kernel transpose; 2 correctness-first
+        kernel; 3 / 4 packed-B + LDS-DMA with 128x128 / 256x256 tiles forced; 10..13 timing-only
+        ablations (wrong results)."""
         _check(lib().mmh_set_option(self._h, OPT_IGEMM_MODE, int(mode)), "mmh_set_option")
 
     def streamk_timeouts(self) -> int:
@@ -366,6 +369,15 @@ class MMult:
     def probe_mfma_i8(self) -> float:
         v = C.c_float(0)
         _check(lib().mmh_probe_mfma_i8(self._h, C.byref(v)), "mmh_probe_mfma_i8")
+        return v.value
+
+    def probe_mfma_i8_sustained(self, random_operands: bool = True, min_ms: float = 50.0) -> float:
+        """int8 MFMA-only rate of the LAST 2.3 ms launch after `min_ms` of back-to-back launches,
+        with per-MFMA pseudo-random operands (what the power manager sustains on real data) or
+        with constant ones."""
+        v = C.c_float(0)
+        _check(lib().mmh_probe_mfma_i8_sustained(self._h, int(bool(random_operands)), float(min_ms), C.byref(v)),
+               "mmh_probe_mfma_i8_sustained")
         return v.value
 
     def probe_hbm_copy(self, nbytes: int = 1 << 30) -> float:

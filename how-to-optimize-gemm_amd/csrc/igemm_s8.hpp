@@ -39,6 +39,8 @@
 
 #include <type_traits>
 
+#include "sgemm_tile.hpp"   // block_to_tile, static_for
+
 namespace mmh {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -292,32 +294,68 @@ __global__ void __launch_bounds__(256) pack_bt_s8_kernel(const int8_t *__restric
   }
 }
 
-template <bool EDGE>
-__global__ void __launch_bounds__(256, 2)
-igemm_s8_dma_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
-                    const int8_t *__restrict__ Bt, int kp, int32_t *__restrict__ C, int ldc,
-                    int accumulate, int nbm, int nbn) {
-  constexpr int BM = 128, BN = 128;
-  extern __shared__ __attribute__((aligned(16))) int8_t ilds[];   // 2 x (A image | B image) = 64 KiB
+// N consecutive 1 KiB LDS-DMA chunks (8 image rows each): lane L's 16 bytes land at dst + 1024 j + 16 L.
+// (Members of class templates, as Stage's loaders are: hipcc's host pass rejects
+// __amdgpu_buffer_rsrc_t in the signature of a function TEMPLATE and in dependent lambdas of a
+// __global__ template, and then silently drops the kernel's launch stub.)
+template <int N>
+struct LdsDma {
+  static __device__ __forceinline__ void chunks(__amdgpu_buffer_rsrc_t rsrc, int8_t *dst, const uint32_t (&voff)[N],
+                                                int k0) {
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + 8 * j * IK),
+                                               16, voff[j], k0, 0, 0);
+  }
+};
+// One template, two configurations <BM, BN, TM> (wave tile = 16 TM rows x 64 columns):
+//   <128,128,4>: 4 waves x (64x64), 64 KiB LDS, two workgroups per CU;
+//   <256,256,8>: 8 waves x (128x64), 128 KiB LDS, one workgroup per CU.
+// int8 MFMAs retire 8x the bytes per cycle of the fp32 ones, so it is operand delivery that
+// bounds this kernel: a 128x128 tile needs 64 B/clk/CU from L2 at MFMA peak and 16
+// ds_read_b128 per 32 MFMAs per wave; the 256x256 tile halves the former and needs 12.
+// Each 128-byte slice is two 64-deep MFMA steps; the fragments of a step are read during the
+// previous step, the barrier sits between the two steps of a slice (step 1's fragments are in
+// registers by then), and right after it the slice after next is requested into the buffer
+// just released -- a whole slice ahead of the barrier that needs it.  The slice loop is
+// unrolled by two so that the LDS buffer index is a compile-time constant and no address
+// arithmetic is left between the MFMAs.
+// ABLATE: 0 the kernel; 1..4 timing-only ablations with WRONG results (1 no DMA in the loop,
+// 2 no fragment reads in the loop, 3 neither, 4 no C store) -- profiles/r01_ablation.md.
+template <int BM, int BN, int TM, bool EDGE, int ABLATE>
+__device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int8_t *__restrict__ A, int lda,
+                                                  const int8_t *__restrict__ Bt, int kp, int n_pad,
+                                                  int32_t *__restrict__ C, int ldc, int accumulate, int nbm,
+                                                  int nbn) {
+  constexpr int ABL = ABLATE;
+  constexpr bool DMA_ON = ABL != 1 && ABL != 3, READS_ON = ABL != 2 && ABL != 3;
+  constexpr int TN = 4;                                           // 16-column MFMA tiles per wave
+  constexpr int WAVES_N = BN / 64, WAVES = BM / (16 * TM) * WAVES_N;
+  constexpr int A_IMG = BM * IK, B_IMG = BN * IK, STAGE = A_IMG + B_IMG;
+  constexpr int CA = BM / 8 / WAVES, CB = BN / 8 / WAVES;   // 1 KiB DMA chunks per wave per image
+  constexpr int NM = TM * TN, NR = TM + TN, ND = CA + CB;   // MFMAs, fragment reads per step; DMAs per slice
+  static_assert(BM % (16 * TM) == 0 && BN % 64 == 0, "wave tile");
+  static_assert((BM / 8) % WAVES == 0 && (BN / 8) % WAVES == 0, "DMA chunks per wave");
+  extern __shared__ __attribute__((aligned(16))) int8_t ilds[];   // 2 x (A image | B image)
 
-  const int tile = blockIdx.x;
-  const int tm = tile / nbn, tn = tile % nbn;
+  int tm, tn;
+  block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
   const int row0 = tm * BM, col0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 15, g = lane >> 4;
 
   const int rows_valid = EDGE ? min(BM, m - row0) : BM;
   const bool whole_c = !EDGE || (rows_valid == BM && col0 + BN <= n);
-  const int crow = row0 + wm * 64 + 4 * g;     // + 16 t + r
-  const int ccol = col0 + wn * 64 + 4 * li;    // .. +3 (u)
+  const int crow = row0 + wm * 16 * TM + 4 * g;          // + 16 t + r
+  const int ccol = col0 + wn * 64 + 4 * li;              // + u: column-interleaved tiles {ccol + u}
   typedef int c_vec_u __attribute__((ext_vector_type(4), aligned(4)));
   using c_vec = std::conditional_t<EDGE, c_vec_u, i32x4>;
 
-  i32x4 acc[4][4];
+  i32x4 acc[TM][TN];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < TM; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = crow + 16 * t + r;
@@ -335,101 +373,132 @@ igemm_s8_dma_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
       for (int u = 0; u < 4; ++u) acc[t][u][r] = v[u];
     }
 
+  const int nk = 2 * ((k + 2 * IK - 1) / (2 * IK));   // slices, rounded up to even (k > 0)
   // descriptors: A bounded at the block's last valid row (rows >= m arrive as zeros;
-  // bytes past k are multiplied by Bt's zero padding); Bt is padded, so unbounded
+  // bytes past k are multiplied by Bt's zero padding); Bt is zero-padded to n_pad rows,
+  // rows past that (a 256-wide tile over a 128-padded Bt) are cut off by the extent
   const uint32_t ext_a = (uint32_t)((rows_valid - 1) * lda + ((k + 3) & ~3));
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<int8_t *>(A + (size_t)row0 * lda), 0, ext_a, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int8_t *>(Bt + (size_t)col0 * kp), 0, (uint32_t)(BN * kp), 0x00020000);
-  // wave w moves chunks 4w..4w+3 (8 image rows each) of both images
+      const_cast<int8_t *>(Bt + (size_t)col0 * kp), 0, (uint32_t)(min(BN, n_pad - col0) * kp), 0x00020000);
+  // wave w moves chunks CA w .. CA w + CA-1 of the A image and likewise of the B image
   const int dr = lane >> 3, dsl = lane & 7;
-  uint32_t voff_a[4], voff_b[4];
+  uint32_t voff_a[CA], voff_b[CB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int prow = 8 * (4 * wave + j) + dr;                       // image row
-    const int src_slot = dsl ^ ((prow >> 1) & 7);
-    voff_a[j] = (uint32_t)(prow * lda + 16 * src_slot);
-    const int nloc = 4 * (prow & 31) + (prow >> 5);                 // u-major image row -> column
-    voff_b[j] = (uint32_t)(nloc * kp + 16 * src_slot);
+  for (int j = 0; j < CA; ++j) {
+    const int prow = 8 * (CA * wave + j) + dr;                      // image row
+    voff_a[j] = (uint32_t)(prow * lda + 16 * (dsl ^ ((prow >> 1) & 7)));
   }
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const int prow = 8 * (CB * wave + j) + dr;
+    const int nloc = 4 * (prow % (BN / 4)) + prow / (BN / 4);       // u-major image row -> column
+    voff_b[j] = (uint32_t)(nloc * kp + 16 * (dsl ^ ((prow >> 1) & 7)));
+  }
+  // past the last slice the same instructions run against zero-length descriptors: every lane is
+  // out of range, zeros land in LDS, nothing is fetched
+  const __amdgpu_buffer_rsrc_t null_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(A), 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t null_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(Bt), 0, 0, 0x00020000);
   auto dma = [&](int8_t *buf, int kt) {
-    const int k0 = kt * IK;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrc_a, (__attribute__((address_space(3))) void *)(buf + 8 * (4 * wave + j) * IK), 16, voff_a[j],
-          k0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrc_b, (__attribute__((address_space(3))) void *)(buf + ITILE + 8 * (4 * wave + j) * IK), 16,
-          voff_b[j], k0, 0, 0);
+    const bool live = kt < nk;
+    LdsDma<CA>::chunks(live ? rsrc_a : null_a, buf + 8 * CA * wave * IK, voff_a, kt * IK);
+    LdsDma<CB>::chunks(live ? rsrc_b : null_b, buf + A_IMG + 8 * CB * wave * IK, voff_b, kt * IK);
   };
+  // fragment addresses: everything that depends on the lane, per (buffer, MFMA step); tile
+  // indices add compile-time constants that fit the ds_read offset field
   const int swz = (li >> 1) & 7;
-  auto frag_a = [&](const int8_t *buf, int s, int t) {
-    const int row = wm * 64 + 16 * t + li;
-    return *reinterpret_cast<const i32x4 *>(buf + row * IK + 16 * ((4 * s + g) ^ swz));
+  uint32_t a_off[2][2], b_off[2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      a_off[c][st] = (uint32_t)(c * STAGE + (wm * 16 * TM + li) * IK + 16 * ((4 * st + g) ^ swz));
+      b_off[c][st] = (uint32_t)(c * STAGE + A_IMG + (wn * 16 + li) * IK + 16 * ((4 * st + g) ^ swz));
+    }
+  i32x4 fa[2][TM], fb[2][TN];
+  // all fragments of MFMA step `st` of buffer `c` into register set `set`
+  auto read_frags = [&](auto set_c, auto c_c, auto st_c) {
+    constexpr int SET = decltype(set_c)::value, CB_ = decltype(c_c)::value, ST = decltype(st_c)::value;
+#pragma unroll
+    for (int ju = 0; ju < TN; ++ju)
+      fb[SET][ju] = *reinterpret_cast<const i32x4 *>(ilds + b_off[CB_][ST] +
+                                                     ju * (BN / 4) * IK);
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+      fa[SET][t] = *reinterpret_cast<const i32x4 *>(ilds + a_off[CB_][ST] + 16 * t * IK);
   };
-  auto frag_b = [&](const int8_t *buf, int s, int u) {
-    const int prow = u * 32 + wn * 16 + li;
-    return *reinterpret_cast<const i32x4 *>(buf + ITILE + prow * IK + 16 * ((4 * s + g) ^ swz));
+  auto mfma_step = [&](auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int ju = 0; ju < TN; ++ju)
+        acc[t][ju] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[SET][t], fb[SET][ju], acc[t][ju], 0, 0, 0);
   };
+  constexpr std::integral_constant<int, 0> i0{};
+  constexpr std::integral_constant<int, 1> i1{};
 
-  const int nk = (k + IK - 1) / IK;
-  i32x4 fa[2][4], fb[2][4];
-  if (nk > 0) dma(ilds, 0);
+  dma(ilds, 0);
+  dma(ilds + STAGE, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (nk > 0) {
+  read_frags(i0, i0, i0);
+
+  // One slice.  Every slice runs the same code (no peeled tail: the compiler spills the 256
+  // accumulators around peeled copies): the slice count is rounded up to even -- Bt is
+  // zero-padded to a multiple of 256 k's and whatever A's descriptor returns there is
+  // multiplied by those zeros -- and past the end the DMAs run against zero-length
+  // descriptors, which costs the instructions but no memory traffic.
+  //   step 0 : MFMAs on fragment set 0, reading step 1's fragments (set 1) underneath;
+  //   barrier: every wave has finished reading this buffer, slice kt + 1 has landed in the other;
+  //   step 1 : MFMAs on set 1; underneath, slice kt + 2 is requested into THIS buffer -- a
+  //            whole slice ahead of the barrier that needs it -- and slice kt + 1's first
+  //            fragments are read from the other one.
+  auto slice = [&](int kt, auto cur_c) {
+    constexpr int CUR = decltype(cur_c)::value;
+    constexpr std::integral_constant<int, CUR> cur{};
+    constexpr std::integral_constant<int, CUR ^ 1> oth{};
+    if (READS_ON) read_frags(i1, cur, i1);
+    mfma_step(i0);
+    {
+      constexpr int nr = READS_ON ? NR : 0;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { fa[0][t] = frag_a(ilds, 0, t); fb[0][t] = frag_b(ilds, 0, t); }
-  }
-  int cur = 0;
-  auto slice = [&](int kt, auto more_c) {
-    constexpr bool MORE = decltype(more_c)::value;
-    const int8_t *buf = ilds + cur * 2 * ITILE;
-    int8_t *nxt = ilds + (cur ^ 1) * 2 * ITILE;
-    // `nxt` was last read before the previous slice's barrier: start filling it now
-    if (MORE) dma(nxt, kt + 1);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { fa[1][t] = frag_a(buf, 1, t); fb[1][t] = frag_b(buf, 1, t); }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[0][t], fb[0][u], acc[t][u], 0, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // DS read
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // MFMA
-      if (MORE && i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // LDS-DMA
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    // MFMA
+        if ((i + 1) * nr / NM > i * nr / NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the next slice has landed
-    __syncthreads();
-    if (MORE) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (DMA_ON) dma(ilds + CUR * STAGE, kt + 2);
+    if (READS_ON) read_frags(i0, oth, i0);
+    mfma_step(i1);
+    {
+      constexpr int nr = READS_ON ? NR : 0, nd = DMA_ON ? ND : 0;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { fa[0][t] = frag_a(nxt, 0, t); fb[0][t] = frag_b(nxt, 0, t); }
+      for (int i = 0; i < NM; ++i) {
+        if ((i + 1) * nd / NM > i * nd / NM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // LDS-DMA
+        if ((i + 1) * nr / NM > i * nr / NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    // MFMA
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[1][t], fb[1][u], acc[t][u], 0, 0, 0);
-    cur ^= 1;
   };
-  int kt = 0;
-  for (; kt + 1 < nk; ++kt) slice(kt, std::true_type{});
-  if (kt < nk) slice(kt, std::false_type{});
+  for (int kt = 0; kt < nk; kt += 2) {
+    slice(kt, i0);
+    slice(kt + 1, i1);
+  }
 
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < TM; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = crow + 16 * t + r;
       i32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+      if (ABL == 4 && (v[0] ^ v[1] ^ v[2] ^ v[3]) != 0x7ffffff1) continue;
       if (whole_c) {
         *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + ccol) = v;
       } else if (row < m) {
@@ -438,6 +507,15 @@ igemm_s8_dma_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
           if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
       }
     }
+}
+
+// The kernel proper is a thin shell around the __device__ template (see LdsDma above).
+template <int BM, int BN, int TM, bool EDGE, int ABLATE>
+__global__ void __launch_bounds__(BM / (16 * TM) * (BN / 64) * 64, (BM == 128 && BN == 128) ? 2 : 1)
+igemm_s8_dma_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
+                    const int8_t *__restrict__ Bt, int kp, int n_pad, int32_t *__restrict__ C, int ldc,
+                    int accumulate, int nbm, int nbn) {
+  igemm_s8_dma_tile<BM, BN, TM, EDGE, ABLATE>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, accumulate, nbm, nbn);
 }
 
 // --------------------------------------------------------------------------
@@ -564,35 +642,81 @@ igemm_s8_simple_kernel(int m, int n, int k, const int8_t *__restrict__ A, int ld
 
 // Workspace bytes mmh_igemm_s8 needs for the packed B of a (k x n) problem.
 inline size_t igemm_s8_pack_bytes(int n, int k) {
-  const size_t n_pad = ((size_t)n + 127) & ~(size_t)127, kp = ((size_t)k + 127) & ~(size_t)127;
+  const size_t n_pad = ((size_t)n + 127) & ~(size_t)127, kp = ((size_t)k + 255) & ~(size_t)255;
   return n_pad * kp;
 }
 
-// mode: 0 = K3d when eligible (needs `bt_ws`, >= igemm_s8_pack_bytes), else K3 / simple;
-//       1 = K3 (in-kernel transpose), 2 = the simple kernel.
+// mode: 0 = K3d when eligible (needs `bt_ws`, >= igemm_s8_pack_bytes; 256x256 tiles when there
+//           is at least one per CU, else 128x128), else K3 / simple;
+//       1 = K3 (in-kernel transpose), 2 = the simple kernel,
+//       3 / 4 = K3d with 128x128 / 256x256 tiles forced (A/B switch).
+template <int BM, int BN, int TM, bool EDGE, int ABLATE>
+inline hipError_t launch_igemm_s8_dma_edge(int m, int n, int k, const int8_t *A, int lda, const int8_t *Bt,
+                                           int kp, int n_pad, int32_t *C, int ldc, int acc, hipStream_t s) {
+  const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
+  constexpr int threads = BM / (16 * TM) * (BN / 64) * 64;
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * IK;
+  if (lds > 64 * 1024) {   // > 64 KiB of dynamic LDS must be opted into
+    const hipError_t e =
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_s8_dma_kernel<BM, BN, TM, EDGE, ABLATE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((igemm_s8_dma_kernel<BM, BN, TM, EDGE, ABLATE>), dim3((unsigned)(nbm * nbn)), dim3(threads),
+                     lds, s, m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, nbm, nbn);
+  return hipGetLastError();
+}
+
+template <int BM, int BN, int TM>
+inline hipError_t launch_igemm_s8_dma(int m, int n, int k, const int8_t *A, int lda, const int8_t *Bt, int kp,
+                                      int n_pad, int32_t *C, int ldc, int acc, hipStream_t s) {
+  const bool c_fast = (m % BM == 0) && (n % BN == 0) && (ldc % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+  return c_fast ? launch_igemm_s8_dma_edge<BM, BN, TM, false, 0>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, s)
+                : launch_igemm_s8_dma_edge<BM, BN, TM, true, 0>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, s);
+}
+
+// mode: 0 = K3d when eligible (needs `bt_ws`, >= igemm_s8_pack_bytes): 256x256 tiles from two
+//           rounds of them up (>= 2 per CU), else 128x128 -- whose two co-resident workgroups
+//           per CU overlap one tile's C store with the other's MFMAs, which matters while a
+//           launch is only a round or two long; else K3 / simple;
+//       1 = K3 (in-kernel transpose), 2 = the simple kernel,
+//       3 / 4 = K3d with 128x128 / 256x256 tiles forced (A/B switches),
+//       10..13 = timing-only ablations of the 256x256 kernel (WRONG results; needs m, n
+//       multiples of 256): no DMA / no fragment reads / neither / no C store.
 inline hipError_t launch_igemm_s8(int m, int n, int k, const int8_t *A, int lda, const int8_t *B,
                                   int ldb, int32_t *C, int ldc, int acc, hipStream_t s,
-                                  int8_t *bt_ws = nullptr, int mode = 0) {
+                                  int8_t *bt_ws = nullptr, int mode = 0, int num_cus = 256) {
   const int nbm = (m + 127) / 128, nbn = (n + 127) / 128;
   dim3 grid((unsigned)(nbm * nbn)), block(256);
   const bool shape_ok = (m % 128 == 0) && (n % 128 == 0);
   const bool a4 = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 3) == 0);
   const bool b4 = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 3) == 0);
   const size_t lim = (1ull << 31) - 4096;
-  const size_t kp = ((size_t)k + 127) & ~(size_t)127, n_pad = ((size_t)n + 127) & ~(size_t)127;
+  const size_t kp = ((size_t)k + 255) & ~(size_t)255, n_pad = ((size_t)n + 127) & ~(size_t)127;
   constexpr size_t lds = 4 * ITILE;   // 64 KiB
   const bool c_fast = shape_ok && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-  if (mode == 0 && bt_ws && a4 && ((size_t)128 * lda + k) < lim && 128 * kp < lim) {
+  if ((mode == 0 || mode >= 3) && bt_ws && a4 && ((size_t)256 * lda + k) < lim && 256 * kp < lim) {
     dim3 pgrid((unsigned)(n_pad / 64), (unsigned)((kp + 255) / 256));
     hipLaunchKernelGGL(pack_bt_s8_kernel, pgrid, dim3(256), 0, s, B, ldb, k, n, bt_ws, (int)kp, (int)n_pad,
                        b4 ? 1 : 0);
-    if (c_fast)
-      hipLaunchKernelGGL(igemm_s8_dma_kernel<false>, grid, block, lds, s, m, n, k, A, lda, bt_ws, (int)kp, C,
-                         ldc, acc, nbm, nbn);
-    else
-      hipLaunchKernelGGL(igemm_s8_dma_kernel<true>, grid, block, lds, s, m, n, k, A, lda, bt_ws, (int)kp, C,
-                         ldc, acc, nbm, nbn);
-    return hipGetLastError();
+    const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
+    const int kpi = (int)kp, npi = (int)n_pad;
+    const bool whole256 = (m % 256 == 0) && (n % 256 == 0) && (ldc % 4 == 0) &&
+                          ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    if (mode >= 10 && !whole256) return hipErrorInvalidValue;
+    switch (mode) {
+      case 3: return launch_igemm_s8_dma<128, 128, 4>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+      case 4: return launch_igemm_s8_dma<256, 256, 8>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+      case 10: return launch_igemm_s8_dma_edge<256, 256, 8, false, 1>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+      case 11: return launch_igemm_s8_dma_edge<256, 256, 8, false, 2>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+      case 12: return launch_igemm_s8_dma_edge<256, 256, 8, false, 3>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+      case 13: return launch_igemm_s8_dma_edge<256, 256, 8, false, 4>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+      default: break;
+    }
+    if (tiles256 >= 2L * num_cus)
+      return launch_igemm_s8_dma<256, 256, 8>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+    return launch_igemm_s8_dma<128, 128, 4>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
   }
   const bool window_ok = ((size_t)128 * lda + k) < lim && ((size_t)k * ldb + 128) < lim;
   if (mode <= 1 && a4 && b4 && window_ok) {

@@ -445,7 +445,7 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
     h->streamk = value ? 1 : 0;
     return MMH_OK;
   }
-  if (option == MMH_OPT_IGEMM_MODE && value >= 0 && value <= 2) {
+  if (option == MMH_OPT_IGEMM_MODE && ((value >= 0 && value <= 4) || (value >= 10 && value <= 13))) {
     h->igemm_mode = value;
     return MMH_OK;
   }
@@ -558,9 +558,10 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
     return MMH_OK;
   }
   int8_t *bt = nullptr;
-  if (h->igemm_mode == 0 && h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
+  if (h->igemm_mode != 1 && h->igemm_mode != 2 && h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
     bt = static_cast<int8_t *>(h->bt.p);
-  HIP_TRY(mmh::launch_igemm_s8(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s, bt, h->igemm_mode));
+  HIP_TRY(mmh::launch_igemm_s8(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s, bt, h->igemm_mode,
+                               h->cu_count > 0 ? h->cu_count : 256));
   return MMH_OK;
 }
 
@@ -613,9 +614,10 @@ int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
   hipLaunchKernelGGL(mmh::quantize_kernel, dim3(gb), dim3(256), 0, s, dB, k, n, ldb, amax + 1, qb, nb,
                      scales + 1);
   int8_t *bt = nullptr;
-  if (h->igemm_mode == 0 && h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
+  if (h->igemm_mode != 1 && h->igemm_mode != 2 && h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
     bt = static_cast<int8_t *>(h->bt.p);
-  HIP_TRY(mmh::launch_igemm_s8(m, n, k, qa, ka, qb, nb, qc, nb, 0, s, bt, h->igemm_mode));
+  HIP_TRY(mmh::launch_igemm_s8(m, n, k, qa, ka, qb, nb, qc, nb, 0, s, bt, h->igemm_mode,
+                               h->cu_count > 0 ? h->cu_count : 256));
   hipLaunchKernelGGL(mmh::dequantize_kernel, dim3(mmh::quant_grid((size_t)m * n)), dim3(256), 0, s, qc, m,
                      n, nb, scales, scales + 1, dC, ldc);
   HIP_TRY(hipGetLastError());
@@ -706,6 +708,12 @@ int mmh_probe_mfma_i8(mmh_handle_t h, float *tops) {
   if (!h || !tops) return MMH_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->device));
   return mmh::probe_mfma_i8(h->cu_count, tops, &g_last_error);
+}
+
+int mmh_probe_mfma_i8_sustained(mmh_handle_t h, int random_operands, float min_ms, float *tops) {
+  if (!h || !tops || min_ms < 0.f || min_ms > 2000.f) return MMH_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->device));
+  return mmh::probe_mfma_i8(h->cu_count, tops, &g_last_error, random_operands ? 1 : 0, min_ms);
 }
 
 int mmh_probe_hbm_copy(mmh_handle_t h, size_t bytes, float *gbps) {

@@ -99,7 +99,44 @@ __global__ void __launch_bounds__(256) probe_mfma_i8_kernel(int *out, int iters,
   if (s[0] + s[1] + s[2] + s[3] == 123456789) out[0] = s[0];
 }
 
-inline int probe_mfma_i8(int cu_count, float *tops, std::string *err) {
+// Same loop with four different pseudo-random A and B operands per wave (every MFMA sees new
+// bits on its inputs, as a GEMM on random data does): the sustained, power-managed rate.
+__global__ void __launch_bounds__(256) probe_mfma_i8_random_kernel(int *out, int iters, int seed) {
+  pi32x4 acc0 = {seed, seed, seed, seed}, acc1 = acc0, acc2 = acc0, acc3 = acc0, acc4 = acc0, acc5 = acc0,
+         acc6 = acc0, acc7 = acc0;
+  pi32x4 a[4], b[4];
+  unsigned x = (unsigned)seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x * 9973u + 12345u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x = x * 1664525u + 1013904223u;
+      a[i][j] = (int)(x ^ (x >> 15));
+      x = x * 1664525u + 1013904223u;
+      b[i][j] = (int)(x ^ (x >> 13));
+    }
+  for (int it = 0; it < iters; ++it) {
+    asm volatile(
+        "v_mfma_i32_16x16x64_i8 %0, %8, %12, %0\n\t"
+        "v_mfma_i32_16x16x64_i8 %1, %9, %13, %1\n\t"
+        "v_mfma_i32_16x16x64_i8 %2, %10, %14, %2\n\t"
+        "v_mfma_i32_16x16x64_i8 %3, %11, %15, %3\n\t"
+        "v_mfma_i32_16x16x64_i8 %4, %8, %13, %4\n\t"
+        "v_mfma_i32_16x16x64_i8 %5, %9, %14, %5\n\t"
+        "v_mfma_i32_16x16x64_i8 %6, %10, %15, %6\n\t"
+        "v_mfma_i32_16x16x64_i8 %7, %11, %12, %7"
+        : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4), "+v"(acc5), "+v"(acc6), "+v"(acc7)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  pi32x4 s = acc0 + acc1 + acc2 + acc3 + acc4 + acc5 + acc6 + acc7;
+  if (s[0] + s[1] + s[2] + s[3] == 123456789) out[0] = s[0];
+}
+
+// random_operands: 0 = the constant-operand loop, 1 = the random-operand loop; the timed launch is
+// repeated until `min_ms` have passed and the LAST launch's rate is returned (sustained clock).
+inline int probe_mfma_i8(int cu_count, float *tops, std::string *err, int random_operands = 0,
+                         float min_ms = 0.f) {
   if (cu_count <= 0) cu_count = 256;
   int *d = nullptr;
   MMH_HIP_TRY(hipMalloc(&d, 64), err);
@@ -107,13 +144,20 @@ inline int probe_mfma_i8(int cu_count, float *tops, std::string *err) {
   hipEvent_t t0, t1;
   MMH_HIP_TRY(hipEventCreate(&t0), err);
   MMH_HIP_TRY(hipEventCreate(&t1), err);
-  hipLaunchKernelGGL(probe_mfma_i8_kernel, dim3(blocks), dim3(256), 0, 0, d, 4000, 1);
-  MMH_HIP_TRY(hipEventRecord(t0, 0), err);
-  hipLaunchKernelGGL(probe_mfma_i8_kernel, dim3(blocks), dim3(256), 0, 0, d, iters, 1);
-  MMH_HIP_TRY(hipEventRecord(t1, 0), err);
-  MMH_HIP_TRY(hipEventSynchronize(t1), err);
-  float ms = 0.f;
-  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
+  auto launch = [&](int n) {
+    if (random_operands) hipLaunchKernelGGL(probe_mfma_i8_random_kernel, dim3(blocks), dim3(256), 0, 0, d, n, 1);
+    else hipLaunchKernelGGL(probe_mfma_i8_kernel, dim3(blocks), dim3(256), 0, 0, d, n, 1);
+  };
+  launch(4000);
+  float ms = 0.f, total = 0.f;
+  do {
+    MMH_HIP_TRY(hipEventRecord(t0, 0), err);
+    launch(iters);
+    MMH_HIP_TRY(hipEventRecord(t1, 0), err);
+    MMH_HIP_TRY(hipEventSynchronize(t1), err);
+    MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
+    total += ms;
+  } while (total < min_ms);
   const double ops = (double)blocks * 4 * iters * 8.0 * (2.0 * 16 * 16 * 64);
   *tops = (float)(ops / (ms * 1e-3) / 1e12);
   (void)hipEventDestroy(t0);

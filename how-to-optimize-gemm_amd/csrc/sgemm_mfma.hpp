@@ -163,15 +163,6 @@ sgemm_mfma_simple_kernel(int m, int n, int k, const float *__restrict__ A, int l
 // Arithmetic order per C element is unchanged (ascending k), so the result is
 // bit-identical to the simple kernel and to the fmaf-chain oracle.
 // ---------------------------------------------------------------------------
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
 
 template <int BM, int BN, bool EDGE, int SCHED, int ABL, bool BUFLD, int WTN = 4, int WTM = 4, int KB = BK,
           bool DMAB = false>

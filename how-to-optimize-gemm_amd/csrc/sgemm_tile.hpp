@@ -35,6 +35,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace mmh {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -44,6 +47,16 @@ constexpr int NXCD = 8;      // XCDs on MI355X; block b is observed on XCD b % 8
 constexpr int GROUP_M = 8;   // tile-rows per rasterisation group (L2 reuse)
 
 __device__ __forceinline__ int swz_slot(int c) { return (c & 7) | ((c & 4) << 1); }
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // Bijective remap of the 1-D block id so that each XCD (private 4 MiB L2)
 // works on a contiguous run of C tiles, then a grouped raster inside the run

@@ -107,8 +107,11 @@ const char *mmh_kernel_name(int kernel);
  * something is badly wrong; a timed-out launch produced wrong results). */
 #define MMH_OPT_STREAMK 1
 #define MMH_OPT_STREAMK_TIMEOUTS 2
-/* MMH_OPT_IGEMM_MODE: 0 (default) pack B once per call and feed both operands by LDS-DMA,
- * 1 transpose B inside the GEMM kernel, 2 the correctness-first kernel (A/B switch). */
+/* MMH_OPT_IGEMM_MODE: 0 (default) pack B once per call and feed both operands by LDS-DMA
+ * (256x256 tiles from two rounds of them up, else 128x128), 1 transpose B inside the GEMM
+ * kernel, 2 the correctness-first kernel, 3 / 4 force the 128x128 / 256x256 packed-B kernel
+ * (A/B switches); 10..13 timing-only ablations of the 256x256 kernel with WRONG results
+ * (no DMA / no fragment reads / neither / no C store; m, n multiples of 256 only). */
 #define MMH_OPT_IGEMM_MODE 3
 int mmh_set_option(mmh_handle_t handle, int option, int value);
 int mmh_get_option(mmh_handle_t handle, int option, int *value);
@@ -184,6 +187,10 @@ int mmh_time_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, in
  * memory traffic) and HBM copy GB/s (float4 stream copy, read+write bytes). */
 int mmh_probe_mfma_f32(mmh_handle_t handle, float *tflops);
 int mmh_probe_mfma_i8(mmh_handle_t handle, float *tops);   /* v_mfma_i32_16x16x64_i8 only */
+/* The same loop run back to back for at least `min_ms` (0..2000), reporting the last 2.3 ms launch:
+ * random_operands != 0 gives every MFMA different pseudo-random inputs (the rate the power
+ * manager sustains on real data), 0 keeps the constant operands of mmh_probe_mfma_i8. */
+int mmh_probe_mfma_i8_sustained(mmh_handle_t handle, int random_operands, float min_ms, float *tops);
 int mmh_probe_hbm_copy(mmh_handle_t handle, size_t bytes, float *gbps);
 
 #ifdef __cplusplus

@@ -375,6 +375,31 @@ def test_int8_bit_exact(mm, oracle):
     assert np.array_equal(out.cpu().numpy(), oracle.ref_igemm_s8(a, b, c0.copy()))
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_int8_every_kernel_bit_exact(mm, oracle, mode):
+    """Each int8 kernel forced in turn (MMH_OPT_IGEMM_MODE: 1 in-kernel transpose, 2 simple,
+    3 / 4 packed-B LDS-DMA with 128x128 / 256x256 tiles) on whole, ragged and tiny shapes, odd and
+    even slice counts (k around multiples of 128 and 256)."""
+    rng = np.random.default_rng(900 + mode)
+    mm.set_igemm_mode(mode)
+    try:
+        for (m, n, k) in [(256, 256, 128), (512, 768, 640), (100, 92, 72), (257, 255, 129), (300, 700, 1000),
+                          (1, 1, 1), (3, 260, 5), (640, 128, 4096), (1280, 1024, 384), (256, 512, 127),
+                          (256, 256, 257), (512, 256, 513), (130, 70, 255)]:
+            a = rng.integers(-127, 128, (m, k), dtype=np.int8)
+            b = rng.integers(-127, 128, (k, n), dtype=np.int8)
+            got = mm.igemm_s8(dev(a), dev(b)).cpu().numpy()
+            assert np.array_equal(got, oracle.ref_igemm_s8(a, b)), (mode, m, n, k)
+        c0 = rng.integers(-1000, 1000, (300, 520), dtype=np.int32)
+        a = rng.integers(-127, 128, (300, 200), dtype=np.int8)
+        b = rng.integers(-127, 128, (200, 520), dtype=np.int8)
+        out = dev(c0)
+        mm.igemm_s8(dev(a), dev(b), out=out, accumulate=True)
+        assert np.array_equal(out.cpu().numpy(), oracle.ref_igemm_s8(a, b, c0.copy())), mode
+    finally:
+        mm.set_igemm_mode(0)
+
+
 def test_quantised_gemm_end_to_end(mm, oracle):
     """quantise -> int8 GEMM -> dequantise, against the CPU restatement of the
     same contract (parity unpinned: the reference has only prose for it)."""
@@ -413,6 +438,13 @@ def test_int8_headline_4096(mm):
     cols = torch.tensor([0, 63, 64, 4095], device="cuda")
     want = a.double() @ b[:, cols].double()
     assert torch.equal(got[:, cols].double(), want)
+    # and every kernel produces the same 4096 x 4096 integers
+    try:
+        for mode in (1, 3, 4):
+            mm.set_igemm_mode(mode)
+            assert torch.equal(mm.igemm_s8(a, b), got), mode
+    finally:
+        mm.set_igemm_mode(0)
 
 
 def test_rocblas_comparator_agrees(mm, oracle):

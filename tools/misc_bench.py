@@ -65,9 +65,19 @@ def time_i8(m, n, k, reps=20):
 ramp()
 what = sys.argv[1:] or ["i8", "edge", "sweep"]
 if "i8" in what:
-    print(f"int8 MFMA-only probe: {mm.probe_mfma_i8():8.1f} TOPS")
-    for n in (1024, 2048, 4096, 8192):
-        print(f"int8 N={n}: {time_i8(n, n, n):8.1f} TOPS")
+    print(f"int8 MFMA-only probe: {mm.probe_mfma_i8():8.1f} TOPS (constant operands, 2.3 ms)")
+    for rnd in (False, True):
+        r = [mm.probe_mfma_i8_sustained(rnd, ms) for ms in (0.0, 20.0, 100.0, 300.0)]
+        print(f"int8 MFMA-only sustained, {'random' if rnd else 'constant'} operands, after 0/20/100/300 ms: " +
+              " ".join(f"{x:7.1f}" for x in r) + " TOPS")
+    modes = [int(x) for x in os.environ.get("I8_MODES", "3,4,0").split(",")]
+    for n in (2048, 4096, 8192):
+        r = []
+        for mode in modes:
+            mm.set_igemm_mode(mode)
+            r.append(f"mode{mode} {time_i8(n, n, n):7.1f}")
+        print(f"int8 N={n}: " + "  ".join(r) + " TOPS (incl. packing B)")
+    mm.set_igemm_mode(0)
 if "edge" in what:
     for (m, n, k) in [(4096, 4096, 4096), (4000, 4000, 4000), (4097, 4095, 4099), (4096, 4096, 4100),
                       (8192, 8192, 8192), (16384, 2048, 16384), (2048, 16384, 16384)]:
