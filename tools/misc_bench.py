@@ -27,8 +27,11 @@ def time_f32(m, n, k, kernel="mfma", reps=20):
     a = torch.rand((m, k), device="cuda") * 2 - 1
     b = torch.rand((k, n), device="cuda") * 2 - 1
     c = torch.empty((m, n), device="cuda")
-    ms = mm.time_sgemm(m, n, k, a.data_ptr(), k, b.data_ptr(), n, c.data_ptr(), n, warmup=5, reps=reps,
-                       stream=stream)
+    # ~40 ms of the same launch first: the clock a measurement sees otherwise depends on what ran
+    # before it (a slow kernel leaves the next one a lower clock for tens of launches)
+    est = mm.time_sgemm(m, n, k, a.data_ptr(), k, b.data_ptr(), n, c.data_ptr(), n, warmup=1, reps=3, stream=stream)
+    ms = mm.time_sgemm(m, n, k, a.data_ptr(), k, b.data_ptr(), n, c.data_ptr(), n,
+                       warmup=max(5, min(400, int(40.0 / max(est, 1e-3)))), reps=reps, stream=stream)
     return 2.0 * m * n * k / (ms * 1e-3) / 1e12
 
 
@@ -36,9 +39,14 @@ def time_rocblas(m, n, k, reps=20):
     a = torch.rand((m, k), device="cuda") * 2 - 1
     b = torch.rand((k, n), device="cuda") * 2 - 1
     c = torch.empty((m, n), device="cuda")
-    for _ in range(5):
-        mm.matmul_rocblas(a, b, out=c)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        mm.matmul_rocblas(a, b, out=c)
+    e1.record()
+    torch.cuda.synchronize()
+    for _ in range(max(5, min(400, int(40.0 / max(e0.elapsed_time(e1) / 3, 1e-3))))):   # same ~40 ms ramp
+        mm.matmul_rocblas(a, b, out=c)
     e0.record()
     for _ in range(reps):
         mm.matmul_rocblas(a, b, out=c)
@@ -87,10 +95,11 @@ if "sweep" in what:
         print(f"fp32 N={n}: mfma {time_f32(n, n, n):7.1f}  mfma256 {time_f32(n, n, n, 'mfma256'):7.1f}  "
               f"valu {time_f32(n, n, n, 'valu'):7.1f} TFLOP/s")
 if "tiles" in what:
-    ks = ["mfma", "mfma_128x64", "mfma_64x64", "auto", "rocblas"]
-    print("N      " + "  ".join(f"{k:>8}" for k in ks))
-    for n in range(1024, 4097, 128):
-        print(f"{n:5d}  " + "  ".join(f"{time_f32(n, n, n, k, reps=10):8.1f}" for k in ks), flush=True)
+    ks = ["valu", "mfma_tiles", "mfma", "mfma_128x64", "mfma_64x64", "mfma_256x256", "auto", "rocblas"]
+    print("| N | " + " | ".join(ks) + " |")
+    print("|---|" + "---|" * len(ks))
+    for n in list(range(1024, 4097, 128)) + [4608, 5120, 6144, 8192]:
+        print(f"| {n} | " + " | ".join(f"{time_f32(n, n, n, k, reps=10):.1f}" for k in ks) + " |", flush=True)
 if "small" in what:
     ks = ["mfma", "mfma_128x64", "mfma_64x64", "rocblas"]
     print("N      " + "  ".join(f"{k:>11}" for k in ks))
