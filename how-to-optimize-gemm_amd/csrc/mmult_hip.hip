@@ -344,6 +344,17 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return launch_mfma<128, 128, false, 4, 7>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case 35:
       return launch_mfma<128, 128, false, 4, 15>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    // the same for the 128x64 configuration (36 = loads always from the first two slices, i.e. cache-hot)
+    case 36:
+      return launch_mfma<128, 64, false, 4, 16, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 37:
+      return launch_mfma<128, 64, false, 4, 1, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 38:
+      return launch_mfma<128, 64, false, 4, 3, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 39:
+      return launch_mfma<128, 64, false, 4, 7, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 40:
+      return launch_mfma<128, 64, false, 4, 15, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     default:
       g_last_error = "unknown kernel variant";
       return MMH_ERR_INVALID_ARG;
@@ -510,6 +521,11 @@ const char *mmh_kernel_name(int kernel) {
     case 33: return "ablate_no_gload_no_ldswrite";
     case 34: return "ablate_no_gload_no_ldswrite_no_barrier";
     case 35: return "ablate_mfma_only";
+    case 36: return "ablate128x64_hot_loads";
+    case 37: return "ablate128x64_no_gload";
+    case 38: return "ablate128x64_no_gload_no_ldswrite";
+    case 39: return "ablate128x64_no_gload_no_ldswrite_no_barrier";
+    case 40: return "ablate128x64_mfma_only";
     default: return nullptr;
   }
 }

@@ -100,6 +100,11 @@ if "tiles" in what:
     print("|---|" + "---|" * len(ks))
     for n in list(range(1024, 4097, 128)) + [4608, 5120, 6144, 8192]:
         print(f"| {n} | " + " | ".join(f"{time_f32(n, n, n, k, reps=10):.1f}" for k in ks) + " |", flush=True)
+if "abl64" in what:
+    ks = ["mfma_128x64", "36", "37", "38", "39", "40", "rocblas"]
+    print("N      " + "  ".join(f"{k:>11}" for k in ks))
+    for n in (1152, 1408, 1792):
+        print(f"{n:5d}  " + "  ".join(f"{time_f32(n, n, n, k, reps=10):11.1f}" for k in ks), flush=True)
 if "small" in what:
     ks = ["mfma", "mfma_128x64", "mfma_64x64", "rocblas"]
     print("N      " + "  ".join(f"{k:>11}" for k in ks))
