@@ -656,10 +656,9 @@ inline hipError_t launch_igemm_s8_dma_edge(int m, int n, int k, const int8_t *A,
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
   constexpr int threads = BM / (16 * TM) * (BN / 64) * 64;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * IK;
-  if (lds > 64 * 1024) {   // > 64 KiB of dynamic LDS must be opted into
-    const hipError_t e =
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_s8_dma_kernel<BM, BN, TM, EDGE, ABLATE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) {   // > 64 KiB of dynamic LDS must be opted into (remembered per device)
+    const hipError_t e = opt_in_big_lds(reinterpret_cast<const void *>(&igemm_s8_dma_kernel<BM, BN, TM, EDGE, ABLATE>),
+                                lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((igemm_s8_dma_kernel<BM, BN, TM, EDGE, ABLATE>), dim3((unsigned)(nbm * nbn)), dim3(threads),

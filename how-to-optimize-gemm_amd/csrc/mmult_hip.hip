@@ -16,6 +16,7 @@
 
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "igemm_s8.hpp"
@@ -86,10 +87,7 @@ constexpr size_t lds_bytes(int BM, int BN, int KB = mmh::BK) {
 
 template <typename K>
 int allow_big_lds(K kernel, size_t bytes) {
-  // > 64 KiB of dynamic LDS must be opted into (per kernel symbol, per device).
-  if (bytes <= 64 * 1024) return MMH_OK;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  HIP_TRY(mmh::opt_in_big_lds(reinterpret_cast<const void *>(kernel), bytes));
   return MMH_OK;
 }
 

@@ -35,8 +35,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 namespace mmh {
 
@@ -47,6 +49,28 @@ constexpr int NXCD = 8;      // XCDs on MI355X; block b is observed on XCD b % 8
 constexpr int GROUP_M = 8;   // tile-rows per rasterisation group (L2 reuse)
 
 __device__ __forceinline__ int swz_slot(int c) { return (c & 7) | ((c & 4) << 1); }
+
+// > 64 KiB of dynamic LDS must be opted into, per kernel symbol and per device; done once and
+// remembered, so that steady-state launches carry no attribute call (and can be captured into a
+// hipGraph after one eager warm-up call).
+inline hipError_t opt_in_big_lds(const void *kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  static std::mutex mu;
+  static std::vector<std::pair<const void *, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &d : done)
+      if (d.first == kernel && d.second == dev) return hipSuccess;
+  }
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  done.emplace_back(kernel, dev);
+  return hipSuccess;
+}
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
 template <class F, int... I>

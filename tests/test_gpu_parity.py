@@ -526,6 +526,49 @@ def test_differential_fuzz_and_stream_k_stress():
     assert "stream-K stress: 0 failures" in r.stdout
 
 
+def test_launches_capture_into_a_hip_graph(mm, oracle):
+    """mmh_sgemm / mmh_igemm_s8 only enqueue work on the caller's stream (returns before
+    completion, harness synchronises): after one eager warm-up call (workspaces allocated, LDS
+    opt-in done) a sequence of them captures into a hipGraph and replays with the same bits."""
+    import torch
+    rng = np.random.default_rng(31)
+    shapes = [(256, 384, 512), (1280, 1152, 640), (300, 200, 100)]     # plain, stream-K (ragged tiles), guarded
+    ops = []
+    for (m, n, k) in shapes:
+        a, b = oracle.harness_inputs(m, n, k, seed=m + n + k)
+        ops.append((dev(a), dev(b), torch.empty((m, n), device="cuda")))
+    qa = dev(rng.integers(-127, 128, (256, 512), dtype=np.int8))
+    qb = dev(rng.integers(-127, 128, (512, 384), dtype=np.int8))
+    qc = torch.empty((256, 384), device="cuda", dtype=torch.int32)
+    mm.set_kernel("auto")
+    eager = []
+    for (a, b, c) in ops:                 # warm-up = the eager reference
+        mm.matmul(a, b, out=c)
+        eager.append(c.clone())
+    mm.igemm_s8(qa, qb, out=qc)
+    q_eager = qc.clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for (a, b, c) in ops:
+                mm.matmul(a, b, out=c)
+            mm.igemm_s8(qa, qb, out=qc)
+    torch.cuda.current_stream().wait_stream(side)
+    for rep in range(3):
+        for (_, _, c) in ops:
+            c.fill_(float("nan"))
+        qc.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for (_, _, c), want in zip(ops, eager):
+            assert torch.equal(c, want), rep
+        assert torch.equal(qc, q_eager), rep
+    assert mm.streamk_timeouts() == 0
+
+
 def test_peak_probes_are_sane(mm):
     tf = mm.probe_mfma_f32()
     assert 100.0 < tf < 165.0, tf          # 157.3 TFLOP/s is the fp32 MFMA peak
