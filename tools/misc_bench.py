@@ -103,7 +103,7 @@ if "tiles" in what:
 if "abl64" in what:
     ks = ["mfma_128x64", "36", "37", "38", "39", "40", "rocblas"]
     print("N      " + "  ".join(f"{k:>11}" for k in ks))
-    for n in (1152, 1408, 1792):
+    for n in (1024, 1152, 1280, 1408, 1536, 1792, 2048):
         print(f"{n:5d}  " + "  ".join(f"{time_f32(n, n, n, k, reps=10):11.1f}" for k in ks), flush=True)
 if "small" in what:
     ks = ["mfma", "mfma_128x64", "mfma_64x64", "rocblas"]
