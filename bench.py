@@ -311,6 +311,26 @@ def main():
             extras["sweep_gflops"] = sweep
             extras["probe_mfma_f32_tflops"] = round(mm.probe_mfma_f32(), 1)
             extras["probe_hbm_copy_gbps"] = round(mm.probe_hbm_copy(1 << 30), 1)
+            # configs[4]: int8 x int8 -> int32 at N=4096 (end to end, packing of B included), beside
+            # what the matrix pipe sustains on constant and on random operands
+            try:
+                gq = torch.Generator(device=dev).manual_seed(7)
+                qa = torch.randint(-127, 128, (4096, 4096), device=dev, dtype=torch.int8, generator=gq)
+                qb = torch.randint(-127, 128, (4096, 4096), device=dev, dtype=torch.int8, generator=gq)
+                qc = torch.empty((4096, 4096), device=dev, dtype=torch.int32)
+                for _ in range(30):
+                    mm.igemm_s8(qa, qb, out=qc)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    mm.igemm_s8(qa, qb, out=qc)
+                e1.record()
+                torch.cuda.synchronize()
+                extras["int8_4096_tops"] = round(2.0 * 4096 ** 3 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12, 1)
+                extras["probe_mfma_i8_tops_constant_operands"] = round(mm.probe_mfma_i8_sustained(False, 50.0), 1)
+                extras["probe_mfma_i8_tops_random_operands"] = round(mm.probe_mfma_i8_sustained(True, 50.0), 1)
+            except H.MMultError:
+                pass
             out["extras"] = extras
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
