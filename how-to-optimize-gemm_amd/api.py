@@ -203,9 +203,9 @@ class MMult:
         _check(lib().mmh_set_option(self._h, OPT_STREAMK, int(bool(on))), "mmh_set_option")
 
     def set_igemm_mode(self, mode: int) -> None:
-        """0 packed-B + LDS-DMA, tile picked by size (default); 1 in-kernel transpose; 2 correctness-first
-        kernel; 3 / 4 packed-B + LDS-DMA with 128x128 / 256x256 tiles forced; 10..13 timing-only
-        ablations (wrong results)."""
+        """0 B read in place (default; packed B for unaligned operands), tile picked by size; 1 in-kernel
+        transpose; 2 correctness-first kernel; 3 / 4 packed-B + LDS-DMA with 128x128 / 256x256 tiles;
+        5 / 6 in-place B likewise; 10..13 timing-only ablations (wrong results)."""
         _check(lib().mmh_set_option(self._h, OPT_IGEMM_MODE, int(mode)), "mmh_set_option")
 
     def streamk_timeouts(self) -> int:

@@ -314,15 +314,23 @@ struct LdsDma {
 // int8 MFMAs retire 8x the bytes per cycle of the fp32 ones, so it is operand delivery that
 // bounds this kernel: a 128x128 tile needs 64 B/clk/CU from L2 at MFMA peak and 16
 // ds_read_b128 per 32 MFMAs per wave; the 256x256 tile halves the former and needs 12.
-// Each 128-byte slice is two 64-deep MFMA steps; the fragments of a step are read during the
-// previous step, the barrier sits between the two steps of a slice (step 1's fragments are in
+// Each 128-byte slice is two 64-deep MFMA steps, run as phases of 16 MFMAs whose fragments are read
+// during the phase before; the barrier sits before the last phase of a slice (its fragments are in
 // registers by then), and right after it the slice after next is requested into the buffer
 // just released -- a whole slice ahead of the barrier that needs it.  The slice loop is
 // unrolled by two so that the LDS buffer index is a compile-time constant and no address
 // arithmetic is left between the MFMAs.
 // ABLATE: 0 the kernel; 1..4 timing-only ablations with WRONG results (1 no DMA in the loop,
 // 2 no fragment reads in the loop, 3 neither, 4 no C store) -- profiles/r01_ablation.md.
-template <int BM, int BN, int TM, bool EDGE, int ABLATE>
+// BTR (K3t): no packed copy of B at all.  `Bt` is then B itself (row-major k x n, `kp` = ldb): its
+// 128 x BN byte slice goes into LDS as it lies in memory (LDS-DMA, 16-byte slots XOR-swizzled on
+// the source side) and the MFMA fragment -- 16 consecutive k of one column per lane -- is gathered
+// by two `ds_read_b64_tr_b8` (gfx950's transposing LDS read; semantics probed with
+// tools/probes/ds_read_tr8_probe.hip: within a 16-lane group lane p supplies the address of 8
+// bytes, pieces 2j and 2j+1 form row j of an 8 x 16 byte block, lane i receives column i).  The
+// MFMA operands are swapped (D = tile^T), which leaves every lane with four consecutive COLUMNS of
+// one C row: 16-byte C accesses without the column-interleave trick of the packed path.
+template <int BM, int BN, int TM, bool EDGE, int ABLATE, bool BTR = false>
 __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int8_t *__restrict__ A, int lda,
                                                   const int8_t *__restrict__ Bt, int kp, int n_pad,
                                                   int32_t *__restrict__ C, int ldc, int accumulate, int nbm,
@@ -333,7 +341,7 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
   constexpr int WAVES_N = BN / 64, WAVES = BM / (16 * TM) * WAVES_N;
   constexpr int A_IMG = BM * IK, B_IMG = BN * IK, STAGE = A_IMG + B_IMG;
   constexpr int CA = BM / 8 / WAVES, CB = BN / 8 / WAVES;   // 1 KiB DMA chunks per wave per image
-  constexpr int NM = TM * TN, NR = TM + TN, ND = CA + CB;   // MFMAs, fragment reads per step; DMAs per slice
+  constexpr int ND = CA + CB;                                     // LDS-DMA instructions per wave and slice
   static_assert(BM % (16 * TM) == 0 && BN % 64 == 0, "wave tile");
   static_assert((BM / 8) % WAVES == 0 && (BN / 8) % WAVES == 0, "DMA chunks per wave");
   extern __shared__ __attribute__((aligned(16))) int8_t ilds[];   // 2 x (A image | B image)
@@ -348,8 +356,10 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
 
   const int rows_valid = EDGE ? min(BM, m - row0) : BM;
   const bool whole_c = !EDGE || (rows_valid == BM && col0 + BN <= n);
-  const int crow = row0 + wm * 16 * TM + 4 * g;          // + 16 t + r
-  const int ccol = col0 + wn * 64 + 4 * li;              // + u: column-interleaved tiles {ccol + u}
+  // packed path: lane (li, g) holds C[crow + 16 t + r][ccol + u] (column-interleaved tiles);
+  // BTR: C[crow + 16 t][ccol + 16 u + r] (four consecutive columns, the MFMA's r index)
+  const int crow = row0 + wm * 16 * TM + (BTR ? li : 4 * g);
+  const int ccol = col0 + wn * 64 + (BTR ? 4 * g : 4 * li);
   typedef int c_vec_u __attribute__((ext_vector_type(4), aligned(4)));
   using c_vec = std::conditional_t<EDGE, c_vec_u, i32x4>;
 
@@ -357,20 +367,24 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
 #pragma unroll
   for (int t = 0; t < TM; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = crow + 16 * t + r;
+    for (int r = 0; r < 4; ++r) {   // BTR: r plays the tile index u here (one 16-byte vector per tile)
+      const int row = crow + 16 * t + (BTR ? 0 : r), col = ccol + (BTR ? 16 * r : 0);
       i32x4 v = {0, 0, 0, 0};
       if (accumulate) {
         if (whole_c) {
-          v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
+          v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + col);
         } else if (row < m) {
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            if (ccol + u < n) v[u] = C[(size_t)row * ldc + ccol + u];
+            if (col + u < n) v[u] = C[(size_t)row * ldc + col + u];
         }
       }
+      if constexpr (BTR) {
+        acc[t][r] = v;
+      } else {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[t][u][r] = v[u];
+        for (int u = 0; u < 4; ++u) acc[t][u][r] = v[u];
+      }
     }
 
   const int nk = 2 * ((k + 2 * IK - 1) / (2 * IK));   // slices, rounded up to even (k > 0)
@@ -380,8 +394,12 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
   const uint32_t ext_a = (uint32_t)((rows_valid - 1) * lda + ((k + 3) & ~3));
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<int8_t *>(A + (size_t)row0 * lda), 0, ext_a, 0x00020000);
+  // BTR: B (row-major, ldb = kp) from column col0: rows >= k lie past the extent and arrive as
+  // zeros; columns >= n read the neighbouring bytes and only feed C columns that are never stored
+  const uint32_t ext_b = BTR ? (uint32_t)((k - 1) * kp + ((min(BN, n - col0) + 3) & ~3))
+                             : (uint32_t)(min(BN, n_pad - col0) * kp);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int8_t *>(Bt + (size_t)col0 * kp), 0, (uint32_t)(min(BN, n_pad - col0) * kp), 0x00020000);
+      const_cast<int8_t *>(BTR ? Bt + col0 : Bt + (size_t)col0 * kp), 0, ext_b, 0x00020000);
   // wave w moves chunks CA w .. CA w + CA-1 of the A image and likewise of the B image
   const int dr = lane >> 3, dsl = lane & 7;
   uint32_t voff_a[CA], voff_b[CB];
@@ -390,11 +408,23 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
     const int prow = 8 * (CA * wave + j) + dr;                      // image row
     voff_a[j] = (uint32_t)(prow * lda + 16 * (dsl ^ ((prow >> 1) & 7)));
   }
+  // BTR image: [k row][BN bytes]; the 16-byte slot of row r is XORed with btr_swz(r), chosen so that
+  // the 16 + 16 pieces of the two lane groups a transposing read serves together (8 rows each,
+  // 16 rows apart) fall on 16 different slots of the 256-byte bank row
+  auto btr_swz = [](int r) {
+    return BN == 256 ? ((r & 7) | (((r >> 4) & 1) << 3)) : (((r >> 1) & 3) | (((r >> 4) & 1) << 2));
+  };
 #pragma unroll
   for (int j = 0; j < CB; ++j) {
-    const int prow = 8 * (CB * wave + j) + dr;
-    const int nloc = 4 * (prow % (BN / 4)) + prow / (BN / 4);       // u-major image row -> column
-    voff_b[j] = (uint32_t)(nloc * kp + 16 * (dsl ^ ((prow >> 1) & 7)));
+    if constexpr (BTR) {
+      constexpr int LPR = BN / 16, RPC = 1024 / BN;                 // lanes per row, rows per 1 KiB chunk
+      const int r = RPC * (CB * wave + j) + lane / LPR;             // k row inside the slice
+      voff_b[j] = (uint32_t)(r * kp + 16 * ((lane % LPR) ^ btr_swz(r)));
+    } else {
+      const int prow = 8 * (CB * wave + j) + dr;
+      const int nloc = 4 * (prow % (BN / 4)) + prow / (BN / 4);     // u-major image row -> column
+      voff_b[j] = (uint32_t)(nloc * kp + 16 * (dsl ^ ((prow >> 1) & 7)));
+    }
   }
   // past the last slice the same instructions run against zero-length descriptors: every lane is
   // out of range, zeros land in LDS, nothing is fetched
@@ -403,7 +433,8 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
   auto dma = [&](int8_t *buf, int kt) {
     const bool live = kt < nk;
     LdsDma<CA>::chunks(live ? rsrc_a : null_a, buf + 8 * CA * wave * IK, voff_a, kt * IK);
-    LdsDma<CB>::chunks(live ? rsrc_b : null_b, buf + A_IMG + 8 * CB * wave * IK, voff_b, kt * IK);
+    LdsDma<CB>::chunks(live ? rsrc_b : null_b, buf + A_IMG + 8 * CB * wave * IK, voff_b,
+                       BTR ? kt * IK * kp : kt * IK);
   };
   // fragment addresses: everything that depends on the lane, per (buffer, MFMA step); tile
   // indices add compile-time constants that fit the ds_read offset field
@@ -416,25 +447,55 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
       a_off[c][st] = (uint32_t)(c * STAGE + (wm * 16 * TM + li) * IK + 16 * ((4 * st + g) ^ swz));
       b_off[c][st] = (uint32_t)(c * STAGE + A_IMG + (wn * 16 + li) * IK + 16 * ((4 * st + g) ^ swz));
     }
-  i32x4 fa[2][TM], fb[2][TN];
-  // all fragments of MFMA step `st` of buffer `c` into register set `set`
-  auto read_frags = [&](auto set_c, auto c_c, auto st_c) {
+  // BTR: per (buffer, tile u) the address of this lane's piece of rows 16 g + (li >> 1) (+ 64 st + 8 h
+  // as an immediate): piece p = li of its group is row p >> 1, half p & 1 of the 8 x 16 block
+  uint32_t bt_off[2][TN];
+  if constexpr (BTR) {
+    const int r = 16 * g + (li >> 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int u = 0; u < TN; ++u)
+        bt_off[c][u] = (uint32_t)(c * STAGE + A_IMG + r * BN + 16 * ((4 * wn + u) ^ btr_swz(r)) + 8 * (li & 1));
+  }
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  // The K loop runs in PHASES of 16 MFMAs: 4 A tiles (one "half" of a 128-row wave tile, or all of a
+  // 64-row one) x 4 B tiles of one 64-deep step.  Two register sets each: A fragments alternate from
+  // phase to phase, B fragments from step to step.
+  constexpr int HALVES = TM / 4, PHASES = 2 * HALVES, NB = (BTR ? 2 : 1) * TN;
+  static_assert(TM % 4 == 0, "phases are four A tiles high");
+  i32x4 fa[2][4], fb[2][TN];
+  auto read_a = [&](auto set_c, auto c_c, auto st_c, auto h_c) {   // A tiles 4h .. 4h+3 of step st, buffer c
+    constexpr int SET = decltype(set_c)::value, CB_ = decltype(c_c)::value, ST = decltype(st_c)::value;
+    constexpr int H = decltype(h_c)::value;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      fa[SET][t] = *reinterpret_cast<const i32x4 *>(ilds + a_off[CB_][ST] + 16 * (4 * H + t) * IK);
+  };
+  auto read_b = [&](auto set_c, auto c_c, auto st_c) {             // the B tiles of step st, buffer c
     constexpr int SET = decltype(set_c)::value, CB_ = decltype(c_c)::value, ST = decltype(st_c)::value;
 #pragma unroll
-    for (int ju = 0; ju < TN; ++ju)
-      fb[SET][ju] = *reinterpret_cast<const i32x4 *>(ilds + b_off[CB_][ST] +
-                                                     ju * (BN / 4) * IK);
-#pragma unroll
-    for (int t = 0; t < TM; ++t)
-      fa[SET][t] = *reinterpret_cast<const i32x4 *>(ilds + a_off[CB_][ST] + 16 * t * IK);
+    for (int ju = 0; ju < TN; ++ju) {
+      if constexpr (BTR) {
+        typedef __attribute__((address_space(3))) i32x2 *lds_v2;
+        const i32x2 lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2)(ilds + bt_off[CB_][ju] + 64 * ST * BN));
+        const i32x2 hi =
+            __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2)(ilds + bt_off[CB_][ju] + (64 * ST + 8) * BN));
+        fb[SET][ju] = i32x4{lo[0], lo[1], hi[0], hi[1]};
+      } else {
+        fb[SET][ju] = *reinterpret_cast<const i32x4 *>(ilds + b_off[CB_][ST] + ju * (BN / 4) * IK);
+      }
+    }
   };
-  auto mfma_step = [&](auto set_c) {
-    constexpr int SET = decltype(set_c)::value;
+  auto mfma_phase = [&](auto aset_c, auto bset_c, auto h_c) {
+    constexpr int AS = decltype(aset_c)::value, BS = decltype(bset_c)::value, H = decltype(h_c)::value;
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int ju = 0; ju < TN; ++ju)
-        acc[t][ju] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[SET][t], fb[SET][ju], acc[t][ju], 0, 0, 0);
+        acc[4 * H + t][ju] =
+            BTR ? __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[BS][ju], fa[AS][t], acc[4 * H + t][ju], 0, 0, 0)
+                : __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[AS][t], fb[BS][ju], acc[4 * H + t][ju], 0, 0, 0);
   };
   constexpr std::integral_constant<int, 0> i0{};
   constexpr std::integral_constant<int, 1> i1{};
@@ -443,49 +504,66 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
   dma(ilds + STAGE, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  read_frags(i0, i0, i0);
+  read_a(i0, i0, i0, i0);
+  read_b(i0, i0, i0);
 
-  // One slice.  Every slice runs the same code (no peeled tail: the compiler spills the 256
+  // One slice.  Every slice runs the same code (no peeled tail: the compiler spills the
   // accumulators around peeled copies): the slice count is rounded up to even -- Bt is
-  // zero-padded to a multiple of 256 k's and whatever A's descriptor returns there is
-  // multiplied by those zeros -- and past the end the DMAs run against zero-length
-  // descriptors, which costs the instructions but no memory traffic.
-  //   step 0 : MFMAs on fragment set 0, reading step 1's fragments (set 1) underneath;
-  //   barrier: every wave has finished reading this buffer, slice kt + 1 has landed in the other;
-  //   step 1 : MFMAs on set 1; underneath, slice kt + 2 is requested into THIS buffer -- a
-  //            whole slice ahead of the barrier that needs it -- and slice kt + 1's first
-  //            fragments are read from the other one.
+  // zero-padded to a multiple of 256 k's (B's descriptor returns zeros past row k) and whatever A's
+  // descriptor returns there is multiplied by those zeros -- and past the end the DMAs run against
+  // zero-length descriptors, which costs the instructions but no memory traffic.
+  //   phases 0 .. PHASES-2: MFMAs, reading the next phase's fragments from this buffer underneath;
+  //   barrier             : every wave has finished reading this buffer, slice kt + 1 has landed
+  //                         in the other one;
+  //   last phase          : MFMAs; underneath, slice kt + 2 is requested into THIS buffer -- a whole
+  //                         slice ahead of the barrier that needs it -- and slice kt + 1's first
+  //                         fragments are read from the other one.
   auto slice = [&](int kt, auto cur_c) {
     constexpr int CUR = decltype(cur_c)::value;
     constexpr std::integral_constant<int, CUR> cur{};
     constexpr std::integral_constant<int, CUR ^ 1> oth{};
-    if (READS_ON) read_frags(i1, cur, i1);
-    mfma_step(i0);
-    {
-      constexpr int nr = READS_ON ? NR : 0;
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    // MFMA
-        if ((i + 1) * nr / NM > i * nr / NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+    static_for<PHASES>([&](auto pc) {
+      constexpr int P = decltype(pc)::value, S = P / HALVES, H = P % HALVES;
+      constexpr std::integral_constant<int, P & 1> aset{};
+      constexpr std::integral_constant<int, (P + 1) & 1> anext{};
+      constexpr std::integral_constant<int, S & 1> bset{};
+      constexpr std::integral_constant<int, H> half{};
+      if constexpr (P + 1 < PHASES) {
+        constexpr int NS = (P + 1) / HALVES, NH = (P + 1) % HALVES;      // the next phase
+        constexpr std::integral_constant<int, NS> nstep{};
+        if (READS_ON) {
+          read_a(anext, cur, nstep, std::integral_constant<int, NH>{});
+          if constexpr (NH == 0) read_b(std::integral_constant<int, NS & 1>{}, cur, nstep);
+        }
+        mfma_phase(aset, bset, half);
+        constexpr int nr = READS_ON ? 4 + (NH == 0 ? NB : 0) : 0;
+        static_for<16>([&](auto ic) {   // pipeline description: the reads dealt out between the MFMAs
+          constexpr int I = decltype(ic)::value, R = (I + 1) * nr / 16 - I * nr / 16;
+          if constexpr (R > 0) __builtin_amdgcn_sched_group_barrier(0x100, R, 0);   // DS read
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // MFMA
+        });
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();        // bare: __syncthreads() would add nothing but a second wait
+        __builtin_amdgcn_sched_barrier(0);
+        if (DMA_ON) dma(ilds + CUR * STAGE, kt + 2);
+        if (READS_ON) {
+          read_b(i0, oth, i0);
+          read_a(i0, oth, i0, i0);
+        }
+        mfma_phase(aset, bset, half);
+        constexpr int nr = READS_ON ? 4 + NB : 0, nd = DMA_ON ? ND : 0;
+        static_for<16>([&](auto ic) {
+          constexpr int I = decltype(ic)::value;
+          constexpr int D = (I + 1) * nd / 16 - I * nd / 16, R = (I + 1) * nr / 16 - I * nr / 16;
+          if constexpr (D > 0) __builtin_amdgcn_sched_group_barrier(0x020, D, 0);   // LDS-DMA
+          if constexpr (R > 0) __builtin_amdgcn_sched_group_barrier(0x100, R, 0);   // DS read
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // MFMA
+        });
+        __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (DMA_ON) dma(ilds + CUR * STAGE, kt + 2);
-    if (READS_ON) read_frags(i0, oth, i0);
-    mfma_step(i1);
-    {
-      constexpr int nr = READS_ON ? NR : 0, nd = DMA_ON ? ND : 0;
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        if ((i + 1) * nd / NM > i * nd / NM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // LDS-DMA
-        if ((i + 1) * nr / NM > i * nr / NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    // MFMA
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    });
   };
   for (int kt = 0; kt < nk; kt += 2) {
     slice(kt, i0);
@@ -496,26 +574,26 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
   for (int t = 0; t < TM; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = crow + 16 * t + r;
-      i32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+      const int row = crow + 16 * t + (BTR ? 0 : r), col = ccol + (BTR ? 16 * r : 0);
+      const i32x4 v = BTR ? acc[t][r] : i32x4{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
       if (ABL == 4 && (v[0] ^ v[1] ^ v[2] ^ v[3]) != 0x7ffffff1) continue;
       if (whole_c) {
-        *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + ccol) = v;
+        *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + col) = v;
       } else if (row < m) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
+          if (col + u < n) C[(size_t)row * ldc + col + u] = v[u];
       }
     }
 }
 
 // The kernel proper is a thin shell around the __device__ template (see LdsDma above).
-template <int BM, int BN, int TM, bool EDGE, int ABLATE>
+template <int BM, int BN, int TM, bool EDGE, int ABLATE, bool BTR = false>
 __global__ void __launch_bounds__(BM / (16 * TM) * (BN / 64) * 64, (BM == 128 && BN == 128) ? 2 : 1)
 igemm_s8_dma_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
                     const int8_t *__restrict__ Bt, int kp, int n_pad, int32_t *__restrict__ C, int ldc,
                     int accumulate, int nbm, int nbn) {
-  igemm_s8_dma_tile<BM, BN, TM, EDGE, ABLATE>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, accumulate, nbm, nbn);
+  igemm_s8_dma_tile<BM, BN, TM, EDGE, ABLATE, BTR>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, accumulate, nbm, nbn);
 }
 
 // --------------------------------------------------------------------------
@@ -650,38 +728,51 @@ inline size_t igemm_s8_pack_bytes(int n, int k) {
 //           is at least one per CU, else 128x128), else K3 / simple;
 //       1 = K3 (in-kernel transpose), 2 = the simple kernel,
 //       3 / 4 = K3d with 128x128 / 256x256 tiles forced (A/B switch).
-template <int BM, int BN, int TM, bool EDGE, int ABLATE>
+template <int BM, int BN, int TM, bool EDGE, int ABLATE, bool BTR = false>
 inline hipError_t launch_igemm_s8_dma_edge(int m, int n, int k, const int8_t *A, int lda, const int8_t *Bt,
                                            int kp, int n_pad, int32_t *C, int ldc, int acc, hipStream_t s) {
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
   constexpr int threads = BM / (16 * TM) * (BN / 64) * 64;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * IK;
   if (lds > 64 * 1024) {   // > 64 KiB of dynamic LDS must be opted into (remembered per device)
-    const hipError_t e = opt_in_big_lds(reinterpret_cast<const void *>(&igemm_s8_dma_kernel<BM, BN, TM, EDGE, ABLATE>),
+    const hipError_t e = opt_in_big_lds(reinterpret_cast<const void *>(&igemm_s8_dma_kernel<BM, BN, TM, EDGE, ABLATE, BTR>),
                                 lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((igemm_s8_dma_kernel<BM, BN, TM, EDGE, ABLATE>), dim3((unsigned)(nbm * nbn)), dim3(threads),
+  hipLaunchKernelGGL((igemm_s8_dma_kernel<BM, BN, TM, EDGE, ABLATE, BTR>), dim3((unsigned)(nbm * nbn)), dim3(threads),
                      lds, s, m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, nbm, nbn);
   return hipGetLastError();
 }
 
-template <int BM, int BN, int TM>
+template <int BM, int BN, int TM, bool BTR = false>
 inline hipError_t launch_igemm_s8_dma(int m, int n, int k, const int8_t *A, int lda, const int8_t *Bt, int kp,
                                       int n_pad, int32_t *C, int ldc, int acc, hipStream_t s) {
   const bool c_fast = (m % BM == 0) && (n % BN == 0) && (ldc % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-  return c_fast ? launch_igemm_s8_dma_edge<BM, BN, TM, false, 0>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, s)
-                : launch_igemm_s8_dma_edge<BM, BN, TM, true, 0>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, s);
+  return c_fast
+             ? launch_igemm_s8_dma_edge<BM, BN, TM, false, 0, BTR>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, s)
+             : launch_igemm_s8_dma_edge<BM, BN, TM, true, 0, BTR>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, s);
 }
 
-// mode: 0 = K3d when eligible (needs `bt_ws`, >= igemm_s8_pack_bytes): 256x256 tiles from two
-//           rounds of them up (>= 2 per CU), else 128x128 -- whose two co-resident workgroups
-//           per CU overlap one tile's C store with the other's MFMAs, which matters while a
-//           launch is only a round or two long; else K3 / simple;
+// K3t (B read in place) needs 4-byte aligned operands and byte offsets inside the descriptors' 2 GiB
+inline bool igemm_s8_inplace_ok(const int8_t *A, int lda, const int8_t *B, int ldb, int k) {
+  const size_t lim = (1ull << 31) - 4096;
+  return (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 3) == 0) && (ldb % 4 == 0) &&
+         ((reinterpret_cast<uintptr_t>(B) & 3) == 0) && ((size_t)256 * lda + k) < lim &&
+         ((size_t)(k + 256) * ldb + 256) < lim;
+}
+// does this call need the packed-B workspace (igemm_s8_pack_bytes)?
+inline bool igemm_s8_needs_pack(int mode, const int8_t *A, int lda, const int8_t *B, int ldb, int k) {
+  if (mode == 3 || mode == 4 || mode >= 10) return true;
+  return mode == 0 && !igemm_s8_inplace_ok(A, lda, B, ldb, k);
+}
+
+// mode: 0 = K3t (B read in place by transposing LDS reads; 256x256 tiles when there is at least one
+//           per CU, else 128x128) when the operands are 4-byte aligned; else K3d (packed B, needs
+//           `bt_ws` >= igemm_s8_pack_bytes), else K3 / simple;
 //       1 = K3 (in-kernel transpose), 2 = the simple kernel,
-//       3 / 4 = K3d with 128x128 / 256x256 tiles forced (A/B switches),
-//       10..13 = timing-only ablations of the 256x256 kernel (WRONG results; needs m, n
+//       3 / 4 = K3d with 128x128 / 256x256 tiles forced, 5 / 6 = K3t likewise (A/B switches),
+//       10..13 = timing-only ablations of the packed 256x256 kernel (WRONG results; needs m, n
 //       multiples of 256): no DMA / no fragment reads / neither / no C store.
 inline hipError_t launch_igemm_s8(int m, int n, int k, const int8_t *A, int lda, const int8_t *B,
                                   int ldb, int32_t *C, int ldc, int acc, hipStream_t s,
@@ -695,11 +786,18 @@ inline hipError_t launch_igemm_s8(int m, int n, int k, const int8_t *A, int lda,
   const size_t kp = ((size_t)k + 255) & ~(size_t)255, n_pad = ((size_t)n + 127) & ~(size_t)127;
   constexpr size_t lds = 4 * ITILE;   // 64 KiB
   const bool c_fast = shape_ok && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-  if ((mode == 0 || mode >= 3) && bt_ws && a4 && ((size_t)256 * lda + k) < lim && 256 * kp < lim) {
+  const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
+  if ((mode == 0 || mode == 5 || mode == 6) && igemm_s8_inplace_ok(A, lda, B, ldb, k)) {
+    // K3t: B read in place (no packing, no workspace)
+    if (mode == 6 || (mode == 0 && tiles256 >= num_cus))
+      return launch_igemm_s8_dma<256, 256, 8, true>(m, n, k, A, lda, B, ldb, n, C, ldc, acc, s);
+    return launch_igemm_s8_dma<128, 128, 4, true>(m, n, k, A, lda, B, ldb, n, C, ldc, acc, s);
+  }
+  if ((mode == 0 || mode == 3 || mode == 4 || mode >= 10) && bt_ws && a4 && ((size_t)256 * lda + k) < lim &&
+      256 * kp < lim) {
     dim3 pgrid((unsigned)(n_pad / 64), (unsigned)((kp + 255) / 256));
     hipLaunchKernelGGL(pack_bt_s8_kernel, pgrid, dim3(256), 0, s, B, ldb, k, n, bt_ws, (int)kp, (int)n_pad,
                        b4 ? 1 : 0);
-    const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
     const int kpi = (int)kp, npi = (int)n_pad;
     const bool whole256 = (m % 256 == 0) && (n % 256 == 0) && (ldc % 4 == 0) &&
                           ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
@@ -713,7 +811,7 @@ inline hipError_t launch_igemm_s8(int m, int n, int k, const int8_t *A, int lda,
       case 13: return launch_igemm_s8_dma_edge<256, 256, 8, false, 4>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
       default: break;
     }
-    if (tiles256 >= 2L * num_cus)
+    if (tiles256 >= num_cus)
       return launch_igemm_s8_dma<256, 256, 8>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
     return launch_igemm_s8_dma<128, 128, 4>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
   }

@@ -463,7 +463,7 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
     h->streamk = value ? 1 : 0;
     return MMH_OK;
   }
-  if (option == MMH_OPT_IGEMM_MODE && ((value >= 0 && value <= 4) || (value >= 10 && value <= 13))) {
+  if (option == MMH_OPT_IGEMM_MODE && ((value >= 0 && value <= 6) || (value >= 10 && value <= 13))) {
     h->igemm_mode = value;
     return MMH_OK;
   }
@@ -581,7 +581,8 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
     return MMH_OK;
   }
   int8_t *bt = nullptr;
-  if (h->igemm_mode != 1 && h->igemm_mode != 2 && h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
+  if (mmh::igemm_s8_needs_pack(h->igemm_mode, dA, lda, dB, ldb, k) &&
+      h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
     bt = static_cast<int8_t *>(h->bt.p);
   HIP_TRY(mmh::launch_igemm_s8(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s, bt, h->igemm_mode,
                                h->cu_count > 0 ? h->cu_count : 256));
@@ -637,7 +638,8 @@ int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
   hipLaunchKernelGGL(mmh::quantize_kernel, dim3(gb), dim3(256), 0, s, dB, k, n, ldb, amax + 1, qb, nb,
                      scales + 1);
   int8_t *bt = nullptr;
-  if (h->igemm_mode != 1 && h->igemm_mode != 2 && h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
+  if (mmh::igemm_s8_needs_pack(h->igemm_mode, qa, ka, qb, nb, k) &&
+      h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
     bt = static_cast<int8_t *>(h->bt.p);
   HIP_TRY(mmh::launch_igemm_s8(m, n, k, qa, ka, qb, nb, qc, nb, 0, s, bt, h->igemm_mode,
                                h->cu_count > 0 ? h->cu_count : 256));

@@ -107,11 +107,12 @@ const char *mmh_kernel_name(int kernel);
  * something is badly wrong; a timed-out launch produced wrong results). */
 #define MMH_OPT_STREAMK 1
 #define MMH_OPT_STREAMK_TIMEOUTS 2
-/* MMH_OPT_IGEMM_MODE: 0 (default) pack B once per call and feed both operands by LDS-DMA
- * (256x256 tiles from two rounds of them up, else 128x128), 1 transpose B inside the GEMM
- * kernel, 2 the correctness-first kernel, 3 / 4 force the 128x128 / 256x256 packed-B kernel
- * (A/B switches); 10..13 timing-only ablations of the 256x256 kernel with WRONG results
- * (no DMA / no fragment reads / neither / no C store; m, n multiples of 256 only). */
+/* MMH_OPT_IGEMM_MODE: 0 (default) B read in place (LDS-DMA of its row-major slices, fragments by
+ * ds_read_b64_tr_b8; 256x256 tiles from one per CU up, else 128x128) for 4-byte aligned operands,
+ * otherwise B packed once per call; 1 transpose B inside the GEMM kernel; 2 the correctness-first
+ * kernel; 3 / 4 the packed-B kernel with 128x128 / 256x256 tiles, 5 / 6 the in-place kernel
+ * likewise (A/B switches); 10..13 timing-only ablations of the packed 256x256 kernel with WRONG
+ * results (no DMA / no fragment reads / neither / no C store; m, n multiples of 256 only). */
 #define MMH_OPT_IGEMM_MODE 3
 int mmh_set_option(mmh_handle_t handle, int option, int value);
 int mmh_get_option(mmh_handle_t handle, int option, int *value);

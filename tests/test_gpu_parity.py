@@ -354,7 +354,9 @@ def test_int8_bit_exact(mm, oracle):
     integer triple loop."""
     import torch
     rng = np.random.default_rng(2026)
-    for (m, n, k) in [(128, 128, 64), (256, 384, 512), (100, 92, 72), (129, 132, 136), (100, 90, 70),
+    # (100, 90, 72): A dword-aligned but B not -> the packed-B path; (100, 90, 70): neither -> simple kernel
+    for (m, n, k) in [(128, 128, 64), (256, 384, 512), (100, 92, 72), (129, 132, 136), (100, 90, 70), (100, 90, 72),
+                      (300, 258, 264),
                       (129, 130, 131), (128, 128, 128), (384, 256, 1000), (200, 150, 90), (131, 258, 66),
                       (1024, 1024, 1024)]:
         a = rng.integers(-127, 128, (m, k), dtype=np.int8)
@@ -375,10 +377,10 @@ def test_int8_bit_exact(mm, oracle):
     assert np.array_equal(out.cpu().numpy(), oracle.ref_igemm_s8(a, b, c0.copy()))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6])
 def test_int8_every_kernel_bit_exact(mm, oracle, mode):
     """Each int8 kernel forced in turn (MMH_OPT_IGEMM_MODE: 1 in-kernel transpose, 2 simple,
-    3 / 4 packed-B LDS-DMA with 128x128 / 256x256 tiles) on whole, ragged and tiny shapes, odd and
+    3 / 4 packed-B LDS-DMA with 128x128 / 256x256 tiles, 5 / 6 B read in place likewise) on whole, ragged and tiny shapes, odd and
     even slice counts (k around multiples of 128 and 256)."""
     rng = np.random.default_rng(900 + mode)
     mm.set_igemm_mode(mode)
@@ -440,7 +442,7 @@ def test_int8_headline_4096(mm):
     assert torch.equal(got[:, cols].double(), want)
     # and every kernel produces the same 4096 x 4096 integers
     try:
-        for mode in (1, 3, 4):
+        for mode in (1, 3, 4, 5, 6):
             mm.set_igemm_mode(mode)
             assert torch.equal(mm.igemm_s8(a, b), got), mode
     finally:

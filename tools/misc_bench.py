@@ -79,7 +79,7 @@ if "i8" in what:
         print(f"int8 MFMA-only sustained, {'random' if rnd else 'constant'} operands, after 0/20/100/300 ms: " +
               " ".join(f"{x:7.1f}" for x in r) + " TOPS")
     modes = [int(x) for x in os.environ.get("I8_MODES", "3,4,0").split(",")]
-    for n in (2048, 4096, 8192):
+    for n in [int(x) for x in os.environ.get("I8_SIZES", "2048,4096,8192").split(",")]:
         r = []
         for mode in modes:
             mm.set_igemm_mode(mode)
