@@ -528,6 +528,20 @@ def test_differential_fuzz_and_stream_k_stress():
     assert "stream-K stress: 0 failures" in r.stdout
 
 
+def test_int8_differential_fuzz():
+    """tools/fuzz_i8.py: every int8 kernel mode against the correctness-first kernel (and that one
+    against fp64) on random shapes, leading dimensions, byte-misaligned bases, accumulate flags;
+    nothing written outside C's window."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_i8.py"), "60", "2026"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "int8 fuzz: 60 cases x 6 modes, 0 failures" in r.stdout
+
+
 def test_launches_capture_into_a_hip_graph(mm, oracle):
     """mmh_sgemm / mmh_igemm_s8 only enqueue work on the caller's stream (returns before
     completion, harness synchronises): after one eager warm-up call (workspaces allocated, LDS
