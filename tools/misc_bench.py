@@ -84,6 +84,20 @@ if "i8" in what:
         for mode in modes:
             mm.set_igemm_mode(mode)
             r.append(f"mode{mode} {time_i8(n, n, n):7.1f}")
+        try:    # vendor comparator: hipBLASLt through torch._int_mm
+            a8 = torch.randint(-127, 128, (n, n), device="cuda", dtype=torch.int8)
+            b8 = torch.randint(-127, 128, (n, n), device="cuda", dtype=torch.int8)
+            for _ in range(5):
+                torch._int_mm(a8, b8)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                torch._int_mm(a8, b8)
+            e1.record()
+            torch.cuda.synchronize()
+            r.append(f"hipBLASLt {2.0 * n ** 3 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12:7.1f}")
+        except Exception:
+            pass
         print(f"int8 N={n}: " + "  ".join(r) + " TOPS (incl. packing B)")
     mm.set_igemm_mode(0)
 if "edge" in what:
