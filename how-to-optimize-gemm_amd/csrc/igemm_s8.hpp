@@ -334,7 +334,9 @@ template <int BM, int BN, int TM, bool EDGE, int ABLATE, bool BTR = false>
 __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int8_t *__restrict__ A, int lda,
                                                   const int8_t *__restrict__ Bt, int kp, int n_pad,
                                                   int32_t *__restrict__ C, int ldc, int accumulate, int nbm,
-                                                  int nbn) {
+                                                  int nbn, const float *__restrict__ deq) {
+  // deq != nullptr: C receives fp32 = (float)acc * (1 / (deq[0] * deq[1])) -- the dequantisation of a
+  // symmetric-quantised GEMM (quant_s8.hpp) fused into the epilogue instead of an int32 round trip
   constexpr int ABL = ABLATE;
   constexpr bool DMA_ON = ABL != 1 && ABL != 3, READS_ON = ABL != 2 && ABL != 3;
   constexpr int TN = 4;                                           // 16-column MFMA tiles per wave
@@ -570,13 +572,19 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
     slice(kt + 1, i1);
   }
 
+  const float deq_inv = deq ? 1.0f / (deq[0] * deq[1]) : 0.0f;
 #pragma unroll
   for (int t = 0; t < TM; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = crow + 16 * t + (BTR ? 0 : r), col = ccol + (BTR ? 16 * r : 0);
-      const i32x4 v = BTR ? acc[t][r] : i32x4{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+      i32x4 v = BTR ? acc[t][r] : i32x4{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
       if (ABL == 4 && (v[0] ^ v[1] ^ v[2] ^ v[3]) != 0x7ffffff1) continue;
+      if (deq) {
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        const f32x4_t f = {(float)v[0] * deq_inv, (float)v[1] * deq_inv, (float)v[2] * deq_inv, (float)v[3] * deq_inv};
+        v = __builtin_bit_cast(i32x4, f);
+      }
       if (whole_c) {
         *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + col) = v;
       } else if (row < m) {
@@ -592,8 +600,9 @@ template <int BM, int BN, int TM, bool EDGE, int ABLATE, bool BTR = false>
 __global__ void __launch_bounds__(BM / (16 * TM) * (BN / 64) * 64, (BM == 128 && BN == 128) ? 2 : 1)
 igemm_s8_dma_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda,
                     const int8_t *__restrict__ Bt, int kp, int n_pad, int32_t *__restrict__ C, int ldc,
-                    int accumulate, int nbm, int nbn) {
-  igemm_s8_dma_tile<BM, BN, TM, EDGE, ABLATE, BTR>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, accumulate, nbm, nbn);
+                    int accumulate, int nbm, int nbn, const float *__restrict__ deq) {
+  igemm_s8_dma_tile<BM, BN, TM, EDGE, ABLATE, BTR>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, accumulate, nbm, nbn,
+                                                   deq);
 }
 
 // --------------------------------------------------------------------------
@@ -730,7 +739,8 @@ inline size_t igemm_s8_pack_bytes(int n, int k) {
 //       3 / 4 = K3d with 128x128 / 256x256 tiles forced (A/B switch).
 template <int BM, int BN, int TM, bool EDGE, int ABLATE, bool BTR = false>
 inline hipError_t launch_igemm_s8_dma_edge(int m, int n, int k, const int8_t *A, int lda, const int8_t *Bt,
-                                           int kp, int n_pad, int32_t *C, int ldc, int acc, hipStream_t s) {
+                                           int kp, int n_pad, int32_t *C, int ldc, int acc, hipStream_t s,
+                                           const float *deq = nullptr) {
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
   constexpr int threads = BM / (16 * TM) * (BN / 64) * 64;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * IK;
@@ -740,18 +750,21 @@ inline hipError_t launch_igemm_s8_dma_edge(int m, int n, int k, const int8_t *A,
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((igemm_s8_dma_kernel<BM, BN, TM, EDGE, ABLATE, BTR>), dim3((unsigned)(nbm * nbn)), dim3(threads),
-                     lds, s, m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, nbm, nbn);
+                     lds, s, m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, nbm, nbn, deq);
   return hipGetLastError();
 }
 
 template <int BM, int BN, int TM, bool BTR = false>
 inline hipError_t launch_igemm_s8_dma(int m, int n, int k, const int8_t *A, int lda, const int8_t *Bt, int kp,
-                                      int n_pad, int32_t *C, int ldc, int acc, hipStream_t s) {
+                                      int n_pad, int32_t *C, int ldc, int acc, hipStream_t s,
+                                      const float *deq = nullptr) {
   const bool c_fast = (m % BM == 0) && (n % BN == 0) && (ldc % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
   return c_fast
-             ? launch_igemm_s8_dma_edge<BM, BN, TM, false, 0, BTR>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, s)
-             : launch_igemm_s8_dma_edge<BM, BN, TM, true, 0, BTR>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, s);
+             ? launch_igemm_s8_dma_edge<BM, BN, TM, false, 0, BTR>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, s,
+                                                                  deq)
+             : launch_igemm_s8_dma_edge<BM, BN, TM, true, 0, BTR>(m, n, k, A, lda, Bt, kp, n_pad, C, ldc, acc, s,
+                                                                 deq);
 }
 
 // K3t (B read in place) needs 4-byte aligned operands and byte offsets inside the descriptors' 2 GiB
@@ -765,6 +778,17 @@ inline bool igemm_s8_inplace_ok(const int8_t *A, int lda, const int8_t *B, int l
 inline bool igemm_s8_needs_pack(int mode, const int8_t *A, int lda, const int8_t *B, int ldb, int k) {
   if (mode == 3 || mode == 4 || mode >= 10) return true;
   return mode == 0 && !igemm_s8_inplace_ok(A, lda, B, ldb, k);
+}
+
+// C_f32 = (float)(A x B) * (1 / (scales[0] * scales[1])) with the dequantisation in the epilogue; in-place
+// kernel only (the caller checks igemm_s8_inplace_ok and otherwise runs the two-pass form).
+inline hipError_t launch_igemm_s8_dequant(int m, int n, int k, const int8_t *A, int lda, const int8_t *B, int ldb,
+                                          float *C, int ldc, const float *scales, hipStream_t s, int num_cus) {
+  const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
+  int32_t *Ci = reinterpret_cast<int32_t *>(C);
+  if (tiles256 >= num_cus)
+    return launch_igemm_s8_dma<256, 256, 8, true>(m, n, k, A, lda, B, ldb, n, Ci, ldc, 0, s, scales);
+  return launch_igemm_s8_dma<128, 128, 4, true>(m, n, k, A, lda, B, ldb, n, Ci, ldc, 0, s, scales);
 }
 
 // mode: 0 = K3t (B read in place by transposing LDS reads; 256x256 tiles when there is at least one

@@ -598,11 +598,13 @@ int mmh_quantize_sym_s8(mmh_handle_t h, int rows, int cols, const float *dX, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = h->qs.reserve(64);
   if (rc != MMH_OK) return rc;
-  unsigned *amax = static_cast<unsigned *>(h->qs.p) + 8;   // scratch word for stand-alone calls
-  HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), s));
-  const unsigned g = mmh::quant_grid((size_t)rows * cols);
-  hipLaunchKernelGGL(mmh::absmax_kernel, dim3(g), dim3(256), 0, s, dX, rows, cols, ldx, amax);
-  hipLaunchKernelGGL(mmh::quantize_kernel, dim3(g), dim3(256), 0, s, dX, rows, cols, ldx, amax, dQ, ldq,
+  unsigned *amax = static_cast<unsigned *>(h->qs.p) + 8;   // scratch words for stand-alone calls
+  HIP_TRY(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), s));
+  const mmh::QuantTensor t{dX, rows, cols, ldx, dQ, ldq}, none{nullptr, 0, 0, 0, nullptr, 0};
+  const dim3 g(mmh::quant_rows_grid(rows, 0), 1), gmax(mmh::quant_rows_grid(rows, 0, 512), 1);
+  hipLaunchKernelGGL(mmh::absmax_kernel, gmax, dim3(256), 0, s, t, none, mmh::quant_vec_ok(t, false) ? 1 : 0, 0,
+                     amax);
+  hipLaunchKernelGGL(mmh::quantize_kernel, g, dim3(256), 0, s, t, none, mmh::quant_vec_ok(t, true) ? 1 : 0, 0, amax,
                      d_scale);
   HIP_TRY(hipGetLastError());
   return MMH_OK;
@@ -624,27 +626,34 @@ int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
   const int ka = (k + 15) & ~15, nb = (n + 3) & ~3;
   if ((rc = h->qa.reserve((size_t)m * ka)) != MMH_OK) return rc;
   if ((rc = h->qb.reserve((size_t)k * nb)) != MMH_OK) return rc;
-  if ((rc = h->qc.reserve((size_t)m * nb * sizeof(int32_t))) != MMH_OK) return rc;
   if ((rc = h->qs.reserve(64)) != MMH_OK) return rc;
   int8_t *qa = static_cast<int8_t *>(h->qa.p), *qb = static_cast<int8_t *>(h->qb.p);
-  int32_t *qc = static_cast<int32_t *>(h->qc.p);
   unsigned *amax = static_cast<unsigned *>(h->qs.p);        // [0] A, [1] B
   float *scales = reinterpret_cast<float *>(amax + 2);      // [0] A, [1] B
   HIP_TRY(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), s));
-  const unsigned ga = mmh::quant_grid((size_t)m * k), gb = mmh::quant_grid((size_t)k * n);
-  hipLaunchKernelGGL(mmh::absmax_kernel, dim3(ga), dim3(256), 0, s, dA, m, k, lda, amax);
-  hipLaunchKernelGGL(mmh::absmax_kernel, dim3(gb), dim3(256), 0, s, dB, k, n, ldb, amax + 1);
-  hipLaunchKernelGGL(mmh::quantize_kernel, dim3(ga), dim3(256), 0, s, dA, m, k, lda, amax, qa, ka, scales);
-  hipLaunchKernelGGL(mmh::quantize_kernel, dim3(gb), dim3(256), 0, s, dB, k, n, ldb, amax + 1, qb, nb,
-                     scales + 1);
+  // A and B share one abs-max launch and one quantisation launch (blockIdx.y picks the tensor)
+  const mmh::QuantTensor ta{dA, m, k, lda, qa, ka}, tb{dB, k, n, ldb, qb, nb};
+  const dim3 g(mmh::quant_rows_grid(m, k), 2), gmax(mmh::quant_rows_grid(m, k, 512), 2);
+  hipLaunchKernelGGL(mmh::absmax_kernel, gmax, dim3(256), 0, s, ta, tb, mmh::quant_vec_ok(ta, false) ? 1 : 0,
+                     mmh::quant_vec_ok(tb, false) ? 1 : 0, amax);
+  hipLaunchKernelGGL(mmh::quantize_kernel, g, dim3(256), 0, s, ta, tb, mmh::quant_vec_ok(ta, true) ? 1 : 0,
+                     mmh::quant_vec_ok(tb, true) ? 1 : 0, amax, scales);
+  const int cus = h->cu_count > 0 ? h->cu_count : 256;
+  if (h->igemm_mode == 0 && mmh::igemm_s8_inplace_ok(qa, ka, qb, nb, k)) {
+    // the int8 GEMM dequantises in its epilogue: no int32 image of C at all
+    HIP_TRY(mmh::launch_igemm_s8_dequant(m, n, k, qa, ka, qb, nb, dC, ldc, scales, s, cus));
+    return MMH_OK;
+  }
+  // two-pass form (A/B modes of the int8 kernel): int32 C, then the dequantisation pass
+  if ((rc = h->qc.reserve((size_t)m * nb * sizeof(int32_t))) != MMH_OK) return rc;
+  int32_t *qc = static_cast<int32_t *>(h->qc.p);
   int8_t *bt = nullptr;
   if (mmh::igemm_s8_needs_pack(h->igemm_mode, qa, ka, qb, nb, k) &&
       h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
     bt = static_cast<int8_t *>(h->bt.p);
-  HIP_TRY(mmh::launch_igemm_s8(m, n, k, qa, ka, qb, nb, qc, nb, 0, s, bt, h->igemm_mode,
-                               h->cu_count > 0 ? h->cu_count : 256));
-  hipLaunchKernelGGL(mmh::dequantize_kernel, dim3(mmh::quant_grid((size_t)m * n)), dim3(256), 0, s, qc, m,
-                     n, nb, scales, scales + 1, dC, ldc);
+  HIP_TRY(mmh::launch_igemm_s8(m, n, k, qa, ka, qb, nb, qc, nb, 0, s, bt, h->igemm_mode, cus));
+  hipLaunchKernelGGL(mmh::dequantize_kernel, dim3(mmh::quant_rows_grid(m, 0)), dim3(256), 0, s, qc, m, n, nb,
+                     scales, scales + 1, dC, ldc);
   HIP_TRY(hipGetLastError());
   return MMH_OK;
 }

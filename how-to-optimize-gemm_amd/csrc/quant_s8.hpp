@@ -6,8 +6,10 @@
 //   scale = 127 / max|x|   (1 if the tensor is all zero)
 //   q     = clamp(rint(x * scale), -127, 127)          round-half-even, never -128
 //   C_f32 = (float)acc_i32 * (1 / (scale_a * scale_b))
-// All three kernels are HBM-bound streaming passes: 16-byte loads, grid-stride,
-// one atomic per workgroup for the abs-max.
+// The kernels are HBM-bound streaming passes: rows to workgroups, 16-byte loads, one atomic per
+// workgroup for the abs-max; A and B of a quantised GEMM share one launch each.  The dequantisation
+// normally runs inside the int8 GEMM's epilogue (igemm_s8.hpp, `deq`); dequantize_kernel is the
+// stand-alone form.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,15 +19,29 @@ namespace mmh {
 typedef float qf32x4 __attribute__((ext_vector_type(4)));
 typedef int qi32x4 __attribute__((ext_vector_type(4)));
 
-// rows x cols window of a row-major matrix with leading dimension ld
-__global__ void __launch_bounds__(256) absmax_kernel(const float *__restrict__ x, int rows, int cols,
-                                                     int ld, unsigned *__restrict__ out_bits) {
+// One launch covers up to two tensors (blockIdx.y): A and B of a quantised GEMM.
+struct QuantTensor {
+  const float *x;   // rows x cols window of a row-major matrix with leading dimension ld
+  int rows, cols, ld;
+  int8_t *q;        // quantised image (quantize_kernel only), leading dimension ldq
+  int ldq;
+};
+
+// Rows are dealt out to workgroups, columns to threads: no division per element, and when the rows
+// are 16-byte aligned (`vec`: x 16-byte aligned, ld % 4 == 0) four columns per float4 load.
+__global__ void __launch_bounds__(256) absmax_kernel(QuantTensor ta, QuantTensor tb, int vec_a, int vec_b,
+                                                     unsigned *__restrict__ out_bits) {
+  const QuantTensor t = blockIdx.y ? tb : ta;
+  const bool vec = blockIdx.y ? vec_b : vec_a;
   float best = 0.0f;
-  const size_t total = (size_t)rows * cols;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = i / cols, c = i - r * cols;
-    best = fmaxf(best, fabsf(x[r * ld + c]));
+  const int c4 = vec ? t.cols / 4 : 0;
+  for (int r = blockIdx.x; r < t.rows; r += gridDim.x) {
+    const float *row = t.x + (size_t)r * t.ld;
+    for (int c = threadIdx.x; c < c4; c += 256) {
+      const qf32x4 v = *reinterpret_cast<const qf32x4 *>(row + 4 * c);
+      best = fmaxf(fmaxf(best, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (int c = 4 * c4 + threadIdx.x; c < t.cols; c += 256) best = fmaxf(best, fabsf(row[c]));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_down(best, off, 64));
@@ -34,25 +50,48 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float *__restrict__ x
   __syncthreads();
   if (threadIdx.x == 0) {
     best = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-    atomicMax(out_bits, __float_as_uint(best));     // non-negative floats order like their bits
+    atomicMax(out_bits + blockIdx.y, __float_as_uint(best));     // non-negative floats order like their bits
   }
 }
 
-__global__ void __launch_bounds__(256) quantize_kernel(const float *__restrict__ x, int rows, int cols,
-                                                       int ld, const unsigned *__restrict__ amax_bits,
-                                                       int8_t *__restrict__ q, int ldq,
+__device__ __forceinline__ int quantize_one(float x, float scale) {
+  return (int)fminf(fmaxf(rintf(x * scale), -127.0f), 127.0f);
+}
+
+// `vec`: additionally q 4-byte aligned and ldq % 4 == 0 -> one dword of four int8 per float4.
+__global__ void __launch_bounds__(256) quantize_kernel(QuantTensor ta, QuantTensor tb, int vec_a, int vec_b,
+                                                       const unsigned *__restrict__ amax_bits,
                                                        float *__restrict__ scale_out) {
-  const float amax = __uint_as_float(*amax_bits);
+  const QuantTensor t = blockIdx.y ? tb : ta;
+  const bool vec = blockIdx.y ? vec_b : vec_a;
+  const float amax = __uint_as_float(amax_bits[blockIdx.y]);
   const float scale = amax > 0.0f ? 127.0f / amax : 1.0f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = scale;
-  const size_t total = (size_t)rows * cols;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = i / cols, c = i - r * cols;
-    float v = rintf(x[r * ld + c] * scale);
-    v = fminf(fmaxf(v, -127.0f), 127.0f);
-    q[r * ldq + c] = (int8_t)v;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[blockIdx.y] = scale;
+  const int c4 = vec ? t.cols / 4 : 0;
+  for (int r = blockIdx.x; r < t.rows; r += gridDim.x) {
+    const float *row = t.x + (size_t)r * t.ld;
+    int8_t *qrow = t.q + (size_t)r * t.ldq;
+    for (int c = threadIdx.x; c < c4; c += 256) {
+      const qf32x4 v = *reinterpret_cast<const qf32x4 *>(row + 4 * c);
+      const unsigned w = (unsigned)(quantize_one(v[0], scale) & 255) | ((unsigned)(quantize_one(v[1], scale) & 255) << 8) |
+                         ((unsigned)(quantize_one(v[2], scale) & 255) << 16) |
+                         ((unsigned)(quantize_one(v[3], scale) & 255) << 24);
+      *reinterpret_cast<unsigned *>(qrow + 4 * c) = w;
+    }
+    for (int c = 4 * c4 + threadIdx.x; c < t.cols; c += 256) qrow[c] = (int8_t)quantize_one(row[c], scale);
   }
+}
+
+inline bool quant_vec_ok(const QuantTensor &t, bool with_q) {
+  return ((reinterpret_cast<uintptr_t>(t.x) & 15) == 0) && (t.ld % 4 == 0) &&
+         (!with_q || (((reinterpret_cast<uintptr_t>(t.q) & 3) == 0) && (t.ldq % 4 == 0)));
+}
+// workgroups per tensor: enough to fill the chip several times over, never more than rows.  The
+// abs-max pass ends in one atomicMax per workgroup on a single word, and 8192 of those serialise
+// into ~80 us at N = 4096: it runs with `cap` = 512.
+inline unsigned quant_rows_grid(int rows_a, int rows_b, int cap = 4096) {
+  const int r = rows_a > rows_b ? rows_a : rows_b;
+  return (unsigned)(r < 1 ? 1 : (r < cap ? r : cap));
 }
 
 __global__ void __launch_bounds__(256) dequantize_kernel(const int32_t *__restrict__ acc, int rows,
@@ -61,17 +100,9 @@ __global__ void __launch_bounds__(256) dequantize_kernel(const int32_t *__restri
                                                          const float *__restrict__ scale_b,
                                                          float *__restrict__ c, int ldc) {
   const float inv = 1.0f / (*scale_a * *scale_b);
-  const size_t total = (size_t)rows * cols;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = i / cols, col = i - r * cols;
-    c[r * ldc + col] = (float)acc[r * ldacc + col] * inv;
-  }
-}
-
-inline unsigned quant_grid(size_t total) {
-  size_t g = (total + 255) / 256;
-  return (unsigned)(g < 2048 ? (g ? g : 1) : 2048);
+  for (int r = blockIdx.x; r < rows; r += gridDim.x)
+    for (int col = threadIdx.x; col < cols; col += 256)
+      c[(size_t)r * ldc + col] = (float)acc[(size_t)r * ldacc + col] * inv;
 }
 
 }  // namespace mmh

@@ -407,7 +407,9 @@ def test_quantised_gemm_end_to_end(mm, oracle):
     same contract (parity unpinned: the reference has only prose for it)."""
     import torch
     rng = np.random.default_rng(77)
-    for (m, n, k) in [(128, 128, 128), (200, 150, 90), (512, 384, 1000)]:
+    # (4096, 4096, 192): the 256x256 kernel with the dequantisation in its epilogue; (333, 257, 129): scalar
+    # tails of the quantisation passes and ragged tiles
+    for (m, n, k) in [(128, 128, 128), (200, 150, 90), (512, 384, 1000), (333, 257, 129), (4096, 4096, 192)]:
         a = rng.uniform(-2, 2, (m, k)).astype(np.float32)
         b = rng.uniform(-0.5, 0.5, (k, n)).astype(np.float32)
         qa, sa = mm.quantize_sym_s8(dev(a))
@@ -421,6 +423,12 @@ def test_quantised_gemm_end_to_end(mm, oracle):
         inv = np.float32(1.0) / (np.float32(sa_ref) * np.float32(sb_ref))
         want = acc.astype(np.float32) * inv
         assert np.array_equal(got, want), (m, n, k)
+        # the two-pass form (int32 C, separate dequantisation; any forced int8 kernel) gives the same floats
+        mm.set_igemm_mode(3)
+        try:
+            assert np.array_equal(mm.qgemm(dev(a), dev(b)).cpu().numpy(), want), (m, n, k)
+        finally:
+            mm.set_igemm_mode(0)
         # and it approximates the fp32 product to quantisation accuracy
         exact = a.astype(np.float64) @ b.astype(np.float64)
         assert np.abs(got - exact).max() <= 0.02 * np.abs(exact).max() + 0.05

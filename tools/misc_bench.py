@@ -100,6 +100,27 @@ if "i8" in what:
             pass
         print(f"int8 N={n}: " + "  ".join(r) + " TOPS (incl. packing B)")
     mm.set_igemm_mode(0)
+if "quant" in what:
+    # the callers either side of the int8 GEMM: streaming passes, GB/s against 8 TB/s
+    def ev(fn, reps=20):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3      # us
+    for n in (2048, 4096, 8192):
+        x = torch.rand((n, n), device="cuda") * 2 - 1
+        y = torch.rand((n, n), device="cuda") * 2 - 1
+        o = torch.empty((n, n), device="cuda")
+        tq = ev(lambda: mm.quantize_sym_s8(x))
+        tg = ev(lambda: mm.qgemm(x, y, out=o))
+        # absmax reads 4 B/elt, quantise reads 4 + writes 1
+        print(f"N={n}: quantize_sym_s8 {tq:8.1f} us = {9.0 * n * n / tq / 1e3:7.1f} GB/s   "
+              f"qgemm {tg:8.1f} us = {2.0 * n ** 3 / tg / 1e6:7.1f} TOPS-equivalent")
 if "edge" in what:
     for (m, n, k) in [(4096, 4096, 4096), (4000, 4000, 4000), (4097, 4095, 4099), (4096, 4096, 4100),
                       (8192, 8192, 8192), (16384, 2048, 16384), (2048, 16384, 16384)]:
