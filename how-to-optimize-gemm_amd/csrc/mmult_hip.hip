@@ -326,6 +326,16 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       HIP_TRY(hipGetLastError());
       return MMH_OK;
     }
+    // ablation builds of the 256x256 configuration (TIMING ONLY): 21 no global loads, 22 + no LDS
+    // stores, 23 + no barrier, 24 + no fragment reads (MFMAs only)
+    case 21:
+      return launch_mfma<256, 256, false, 4, 1, true, 4, 8, 32>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 22:
+      return launch_mfma<256, 256, false, 4, 3, true, 4, 8, 32>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 23:
+      return launch_mfma<256, 256, false, 4, 7, true, 4, 8, 32>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 24:
+      return launch_mfma<256, 256, false, 4, 15, true, 4, 8, 32>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case 16:   // staging cadence A/B: one op per 3 / 4 MFMAs instead of 2
       return launch_mfma<128, 128, false, 5>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case 17:
@@ -519,6 +529,10 @@ const char *mmh_kernel_name(int kernel) {
     case 33: return "ablate_no_gload_no_ldswrite";
     case 34: return "ablate_no_gload_no_ldswrite_no_barrier";
     case 35: return "ablate_mfma_only";
+    case 21: return "ablate256_no_gload";
+    case 22: return "ablate256_no_gload_no_ldswrite";
+    case 23: return "ablate256_no_gload_no_ldswrite_no_barrier";
+    case 24: return "ablate256_mfma_only";
     case 36: return "ablate128x64_hot_loads";
     case 37: return "ablate128x64_no_gload";
     case 38: return "ablate128x64_no_gload_no_ldswrite";

@@ -77,8 +77,9 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_256X256 12 /* K2 with a 256x256 block tile, 8 waves of 128x64 (1 WG/CU)       */
 #define MMH_KERNEL_MFMA_64X64 11 /* K2 with a 64x64 block tile, 4 waves of 32x32, 128-deep K-slices  */
 /* ids 16-19 are A/B builds of K2 with valid results (staging cadence 3/4/1 MFMAs per op; 19 =
- * B staged by LDS-DMA, buffer_load ... lds); ids >= 32 are timing-only ablation builds whose
- * results are invalid.  See profiles/r01_ablation.md, tools/ab_bench.py. */
+ * B staged by LDS-DMA, buffer_load ... lds); ids 21-24 (256x256 tile), 32-35 (128x128) and 36-40
+ * (128x64) are timing-only ablation builds whose results are INVALID.  See
+ * profiles/r01_ablation.md, tools/ab_bench.py. */
 
 /* Library / device ------------------------------------------------------- */
 const char *mmh_strerror(int status);

@@ -23,6 +23,8 @@ def ramp():
 def time_f32(m, n, k, kernel="mfma", reps=20):
     if kernel == "rocblas":
         return time_rocblas(m, n, k, reps)
+    if kernel == "torch.mm":
+        return time_torch_mm(m, n, k, reps)
     H.lib().mmh_set_kernel(mm._h, H.KERNELS[kernel] if kernel in H.KERNELS else int(kernel))
     a = torch.rand((m, k), device="cuda") * 2 - 1
     b = torch.rand((k, n), device="cuda") * 2 - 1
@@ -33,6 +35,28 @@ def time_f32(m, n, k, kernel="mfma", reps=20):
     ms = mm.time_sgemm(m, n, k, a.data_ptr(), k, b.data_ptr(), n, c.data_ptr(), n,
                        warmup=max(5, min(400, int(40.0 / max(est, 1e-3)))), reps=reps, stream=stream)
     return 2.0 * m * n * k / (ms * 1e-3) / 1e12
+
+
+def time_torch_mm(m, n, k, reps=20):
+    """hipBLASLt as PyTorch calls it (fp32, TF32 off): the second vendor comparator."""
+    torch.backends.cuda.matmul.allow_tf32 = False
+    a = torch.rand((m, k), device="cuda") * 2 - 1
+    b = torch.rand((k, n), device="cuda") * 2 - 1
+    c = torch.empty((m, n), device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        torch.mm(a, b, out=c)
+    e1.record()
+    torch.cuda.synchronize()
+    for _ in range(max(5, min(400, int(40.0 / max(e0.elapsed_time(e1) / 3, 1e-3))))):
+        torch.mm(a, b, out=c)
+    e0.record()
+    for _ in range(reps):
+        torch.mm(a, b, out=c)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * m * n * k / (e0.elapsed_time(e1) / reps * 1e-3) / 1e12
 
 
 def time_rocblas(m, n, k, reps=20):
@@ -130,7 +154,7 @@ if "sweep" in what:
         print(f"fp32 N={n}: mfma {time_f32(n, n, n):7.1f}  mfma256 {time_f32(n, n, n, 'mfma256'):7.1f}  "
               f"valu {time_f32(n, n, n, 'valu'):7.1f} TFLOP/s")
 if "tiles" in what:
-    ks = ["valu", "mfma_tiles", "mfma", "mfma_128x64", "mfma_64x64", "mfma_256x256", "auto", "rocblas"]
+    ks = ["valu", "mfma_tiles", "mfma", "mfma_128x64", "mfma_64x64", "mfma_256x256", "auto", "rocblas", "torch.mm"]
     print("| N | " + " | ".join(ks) + " |")
     print("|---|" + "---|" * len(ks))
     for n in list(range(1024, 4097, 128)) + [4608, 5120, 6144, 8192]:
