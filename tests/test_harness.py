@@ -13,6 +13,7 @@ from conftest import REPO
 
 HARNESS = os.path.join(REPO, "how-to-optimize-gemm_amd", "harness")
 EXE = os.path.join(HARNESS, "test_MMult.x")
+DROPIN_AARCH64 = os.path.join(REPO, "oracle", "_ref", "test_MMult_dropin_aarch64.x")
 DROPIN = os.path.join(REPO, "oracle", "_ref", "test_MMult_dropin.x")
 ROW = re.compile(r"^(\d+) (\d+\.\d+) (-?\d\.\d+e[+-]\d+) $")          # cuda flavour: %d %.2f %le
 ROW_LE = re.compile(r"^(\d+) (\d\.\d+e[+-]\d+) (-?\d\.\d+e[+-]\d+) $")  # armv7 flavour: %d %le %le
@@ -128,4 +129,18 @@ def test_reference_driver_linked_against_our_MY_MMult():
     assert rc == 0, err
     rows = parse(out, ROW_LE)
     assert [r[0] for r in rows] == list(range(40, 701, 40))
+    assert all(r[2] == 0.0 for r in rows)
+
+
+@pytest.mark.gpu
+def test_reference_aarch64_driver_linked_against_our_MY_MMult():
+    """The reference's aarch64/test_MMult.cpp + REF_MMult.cpp + compare_matrices.cpp (row-major,
+    lda = k, all-ones inputs, C zeroed before each of its 10 calls) with ONLY MY_MMult replaced by
+    ours: every C element is exactly k, so its diff column is 0 over its sweep 48..960 step 48."""
+    if not os.path.exists(DROPIN_AARCH64):
+        pytest.skip("oracle/_ref/test_MMult_dropin_aarch64.x was not built (no /root/reference at build time)")
+    rc, out, err = run({}, exe=DROPIN_AARCH64)
+    assert rc == 0, err
+    rows = parse(out, ROW_LE)
+    assert [r[0] for r in rows] == list(range(48, 961, 48))
     assert all(r[2] == 0.0 for r in rows)
