@@ -1,4 +1,4 @@
-// igemm_s8.hpp -- K3: int8 x int8 -> int32 GEMM on v_mfma_i32_16x16x64_i8
+// igemm_s8.hpp -- K3*: int8 x int8 -> int32 GEMM on v_mfma_i32_16x16x64_i8
 // (BASELINE.json config 5).
 //
 // The reference tree has NO int8 code (aarch64-int8/ is an empty submodule;
@@ -15,8 +15,12 @@
 // and of one B column.  Because both operands use the same lane->k mapping,
 // correctness does not depend on how the hardware numbers the k's inside.
 //
-// Two kernels:
-//  * igemm_s8_kernel   (K3): 128x128 tile, 4 waves x (4x4 MFMA tiles), K-slices
+// Four kernels, in the order launch_igemm_s8 prefers them:
+//  * K3t  igemm_s8_dma_kernel<..., BTR = true>: B read in place -- both operands global -> LDS by
+//    LDS-DMA, B's row-major slices gathered into MFMA fragments by ds_read_b64_tr_b8 (below);
+//  * K3d  pack_bt_s8_kernel + igemm_s8_dma_kernel<..., BTR = false>: B packed once per call into
+//    Bt[n][k], for operands whose B is not dword-aligned;
+//  * K3   igemm_s8_kernel: 128x128 tile, 4 waves x (4x4 MFMA tiles), K-slices
 //    of 128 bytes double-buffered in LDS, global loads one slice ahead in
 //    registers, slice hand-over pipelined across the barrier (as K2 does for
 //    fp32).  A rows are k-contiguous in memory and go to LDS as they are; B is
@@ -30,9 +34,11 @@
 //    store -- still read consecutive rows.  Reads are bounded by buffer
 //    descriptors: rows >= m of A and rows >= k of B come back as 0, and
 //    garbage * 0 == 0 exactly in integers, so ANY m, n, k works unmasked.
-//    Needs lda, ldb multiples of 4 and 4-byte-aligned A, B.
+//    Needs lda, ldb multiples of 4 and 4-byte-aligned A, B.  (The first pipelined kernel of the
+//    round; kept as an A/B rung, MMH_OPT_IGEMM_MODE 1.)
 //  * igemm_s8_simple_kernel: the correctness-first version (single buffer, byte
-//    loads at the edges) kept for operands that are not 4-byte aligned.
+//    loads at the edges) kept for operands that are not 4-byte aligned, and the
+//    independent code path the differential fuzz (tools/fuzz_i8.py) compares against.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
