@@ -37,11 +37,23 @@ __global__ void __launch_bounds__(256) absmax_kernel(QuantTensor ta, QuantTensor
   const int c4 = vec ? t.cols / 4 : 0;
   for (int r = blockIdx.x; r < t.rows; r += gridDim.x) {
     const float *row = t.x + (size_t)r * t.ld;
-    for (int c = threadIdx.x; c < c4; c += 256) {
+    int c = threadIdx.x;
+    for (; c + 768 < c4; c += 1024) {   // four independent 16-byte loads in flight per thread
+      const qf32x4 v0 = *reinterpret_cast<const qf32x4 *>(row + 4 * c);
+      const qf32x4 v1 = *reinterpret_cast<const qf32x4 *>(row + 4 * (c + 256));
+      const qf32x4 v2 = *reinterpret_cast<const qf32x4 *>(row + 4 * (c + 512));
+      const qf32x4 v3 = *reinterpret_cast<const qf32x4 *>(row + 4 * (c + 768));
+      const qf32x4 a = {fmaxf(fabsf(v0[0]), fabsf(v1[0])), fmaxf(fabsf(v0[1]), fabsf(v1[1])),
+                        fmaxf(fabsf(v0[2]), fabsf(v1[2])), fmaxf(fabsf(v0[3]), fabsf(v1[3]))};
+      const qf32x4 b = {fmaxf(fabsf(v2[0]), fabsf(v3[0])), fmaxf(fabsf(v2[1]), fabsf(v3[1])),
+                        fmaxf(fabsf(v2[2]), fabsf(v3[2])), fmaxf(fabsf(v2[3]), fabsf(v3[3]))};
+      best = fmaxf(best, fmaxf(fmaxf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(fmaxf(a[2], b[2]), fmaxf(a[3], b[3]))));
+    }
+    for (; c < c4; c += 256) {
       const qf32x4 v = *reinterpret_cast<const qf32x4 *>(row + 4 * c);
       best = fmaxf(fmaxf(best, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
-    for (int c = 4 * c4 + threadIdx.x; c < t.cols; c += 256) best = fmaxf(best, fabsf(row[c]));
+    for (c = 4 * c4 + threadIdx.x; c < t.cols; c += 256) best = fmaxf(best, fabsf(row[c]));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_down(best, off, 64));
