@@ -291,61 +291,68 @@ def main():
             out["streamed_equals_plain"] = bool(streamed_equal)
         if not sharded and not args.no_extras:
             extras = {}
-            # configs[1]/[2]: the square sweep at the BASELINE sizes, LDS-tiled VALU kernel
-            # (K1), the MFMA kernel as shipped (AUTO: tile choice + stream-K) and rocBLAS
-            sweep = {}
-            for kern in ("valu", "auto", "rocblas"):
-                if kern != "rocblas":
-                    mm.set_kernel(kern)
-                for p in (1024, 2048, 3072, 4096):
-                    if p > n:
-                        continue
-                    pa, pb = a[:p, :p].contiguous(), b[:p, :p].contiguous()
-                    pc = torch.empty((p, p), device=dev)
-                    if kern == "rocblas":
-                        try:
-                            for _ in range(3):
-                                mm.matmul_rocblas(pa, pb, out=pc)
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                            for _ in range(20):
-                                mm.matmul_rocblas(pa, pb, out=pc)
-                            e1.record()
-                            torch.cuda.synchronize()
-                            ms = e0.elapsed_time(e1) / 20
-                        except H.MMultError:
-                            continue
-                    else:
-                        ms = mm.time_sgemm(p, p, p, pa.data_ptr(), p, pb.data_ptr(), p, pc.data_ptr(), p,
-                                           warmup=3, reps=20, stream=stream)
-                    sweep[f"{kern}_{p}"] = round(2.0 * p ** 3 * 1e-9 / (ms * 1e-3), 1)
-            mm.set_kernel(args.kernel)
-            extras["sweep_gflops"] = sweep
-            extras["probe_mfma_f32_tflops"] = round(mm.probe_mfma_f32(), 1)
-            extras["probe_hbm_copy_gbps"] = round(mm.probe_hbm_copy(1 << 30), 1)
-            # configs[4]: int8 x int8 -> int32 at N=4096 (end to end, packing of B included), beside
-            # what the matrix pipe sustains on constant and on random operands
             try:
-                gq = torch.Generator(device=dev).manual_seed(7)
-                qa = torch.randint(-127, 128, (4096, 4096), device=dev, dtype=torch.int8, generator=gq)
-                qb = torch.randint(-127, 128, (4096, 4096), device=dev, dtype=torch.int8, generator=gq)
-                qc = torch.empty((4096, 4096), device=dev, dtype=torch.int32)
-                for _ in range(300):      # ~20 ms: the power manager's sustained state, not a burst
-                    mm.igemm_s8(qa, qb, out=qc)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(200):
-                    mm.igemm_s8(qa, qb, out=qc)
-                e1.record()
-                torch.cuda.synchronize()
-                extras["int8_4096_tops"] = round(2.0 * 4096 ** 3 / (e0.elapsed_time(e1) / 200 * 1e-3) / 1e12, 1)
-                extras["probe_mfma_i8_tops_constant_operands"] = round(mm.probe_mfma_i8_sustained(False, 50.0), 1)
-                extras["probe_mfma_i8_tops_random_operands"] = round(mm.probe_mfma_i8_sustained(True, 50.0), 1)
-            except H.MMultError:
-                pass
+                # configs[1]/[2]: the square sweep at the BASELINE sizes, LDS-tiled VALU kernel
+                # (K1), the MFMA kernel as shipped (AUTO: tile choice + stream-K) and rocBLAS
+                sweep = {}
+                for kern in ("valu", "auto", "rocblas"):
+                    if kern != "rocblas":
+                        mm.set_kernel(kern)
+                    for p in (1024, 2048, 3072, 4096):
+                        if p > n:
+                            continue
+                        pa, pb = a[:p, :p].contiguous(), b[:p, :p].contiguous()
+                        pc = torch.empty((p, p), device=dev)
+                        if kern == "rocblas":
+                            try:
+                                for _ in range(3):
+                                    mm.matmul_rocblas(pa, pb, out=pc)
+                                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                e0.record()
+                                for _ in range(20):
+                                    mm.matmul_rocblas(pa, pb, out=pc)
+                                e1.record()
+                                torch.cuda.synchronize()
+                                ms = e0.elapsed_time(e1) / 20
+                            except H.MMultError:
+                                continue
+                        else:
+                            ms = mm.time_sgemm(p, p, p, pa.data_ptr(), p, pb.data_ptr(), p, pc.data_ptr(), p,
+                                               warmup=3, reps=20, stream=stream)
+                        sweep[f"{kern}_{p}"] = round(2.0 * p ** 3 * 1e-9 / (ms * 1e-3), 1)
+                mm.set_kernel(args.kernel)
+                extras["sweep_gflops"] = sweep
+                extras["probe_mfma_f32_tflops"] = round(mm.probe_mfma_f32(), 1)
+                extras["probe_hbm_copy_gbps"] = round(mm.probe_hbm_copy(1 << 30), 1)
+                # configs[4]: int8 x int8 -> int32 at N=4096 (end to end, packing of B included), beside
+                # what the matrix pipe sustains on constant and on random operands
+                try:
+                    gq = torch.Generator(device=dev).manual_seed(7)
+                    qa = torch.randint(-127, 128, (4096, 4096), device=dev, dtype=torch.int8, generator=gq)
+                    qb = torch.randint(-127, 128, (4096, 4096), device=dev, dtype=torch.int8, generator=gq)
+                    qc = torch.empty((4096, 4096), device=dev, dtype=torch.int32)
+                    for _ in range(300):      # ~20 ms: the power manager's sustained state, not a burst
+                        mm.igemm_s8(qa, qb, out=qc)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(200):
+                        mm.igemm_s8(qa, qb, out=qc)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    extras["int8_4096_tops"] = round(2.0 * 4096 ** 3 / (e0.elapsed_time(e1) / 200 * 1e-3) / 1e12, 1)
+                    extras["probe_mfma_i8_tops_constant_operands"] = round(mm.probe_mfma_i8_sustained(False, 50.0), 1)
+                    extras["probe_mfma_i8_tops_random_operands"] = round(mm.probe_mfma_i8_sustained(True, 50.0), 1)
+                except H.MMultError:
+                    pass
+            except Exception as e:   # extras are optional: never let them cost the run its JSON line
+                extras["error"] = f"{type(e).__name__}: {e}"[:300]
             out["extras"] = extras
         if not sharded and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n)
+            try:
+                out["cpu_baseline"] = cpu_baseline(n)
+            except Exception as e:   # reported, never fatal (the contract wants the object; say why it is missing)
+                out["cpu_baseline"] = {"value": None, "unit": "GFLOPS", "cores": 0, "kind": "reference",
+                                       "sample": f"failed: {type(e).__name__}: {e}"[:300]}
     mm.close()
     if dist:
         dist.barrier()
