@@ -295,15 +295,29 @@ def main():
                 # configs[1]/[2]: the square sweep at the BASELINE sizes, LDS-tiled VALU kernel
                 # (K1), the MFMA kernel as shipped (AUTO: tile choice + stream-K) and rocBLAS
                 sweep = {}
-                for kern in ("valu", "auto", "rocblas"):
-                    if kern != "rocblas":
+                for kern in ("valu", "auto", "rocblas", "hipblaslt"):
+                    if kern not in ("rocblas", "hipblaslt"):
                         mm.set_kernel(kern)
                     for p in (1024, 2048, 3072, 4096):
                         if p > n:
                             continue
                         pa, pb = a[:p, :p].contiguous(), b[:p, :p].contiguous()
                         pc = torch.empty((p, p), device=dev)
-                        if kern == "rocblas":
+                        if kern == "hipblaslt":      # the second vendor comparator: torch.mm, TF32 off
+                            try:
+                                torch.backends.cuda.matmul.allow_tf32 = False
+                                for _ in range(3):
+                                    torch.mm(pa, pb, out=pc)
+                                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                e0.record()
+                                for _ in range(20):
+                                    torch.mm(pa, pb, out=pc)
+                                e1.record()
+                                torch.cuda.synchronize()
+                                ms = e0.elapsed_time(e1) / 20
+                            except Exception:
+                                continue
+                        elif kern == "rocblas":
                             try:
                                 for _ in range(3):
                                     mm.matmul_rocblas(pa, pb, out=pc)
