@@ -146,9 +146,13 @@ if "quant" in what:
         print(f"N={n}: quantize_sym_s8 {tq:8.1f} us = {9.0 * n * n / tq / 1e3:7.1f} GB/s   "
               f"qgemm {tg:8.1f} us = {2.0 * n ** 3 / tg / 1e6:7.1f} TOPS-equivalent")
 if "edge" in what:
-    for (m, n, k) in [(4096, 4096, 4096), (4000, 4000, 4000), (4097, 4095, 4099), (4096, 4096, 4100),
-                      (8192, 8192, 8192), (16384, 2048, 16384), (2048, 16384, 16384)]:
-        print(f"fp32 {m}x{n}x{k}: mfma {time_f32(m, n, k):7.1f}  mfma256 {time_f32(m, n, k, 'mfma256'):7.1f} TFLOP/s")
+    print("| m x n x k | auto | rocblas | torch.mm |")
+    print("|---|---|---|---|")
+    for (m, n, k) in [(4096, 4096, 4096), (4000, 4000, 4000), (4097, 4095, 4099), (4096, 4096, 4100), (3000, 5000, 2000),
+                      (1000, 1000, 1000), (2049, 2049, 2049), (16384, 2048, 16384), (2048, 16384, 16384), (8192, 8192, 512),
+                      (512, 512, 16384)]:
+        print(f"| {m} x {n} x {k} | " + " | ".join(f"{time_f32(m, n, k, kk, reps=10):.1f}" for kk in ("auto", "rocblas", "torch.mm")) + " |",
+              flush=True)
 if "sweep" in what:
     for n in range(1024, 4097, 256):
         print(f"fp32 N={n}: mfma {time_f32(n, n, n):7.1f}  mfma256 {time_f32(n, n, n, 'mfma256'):7.1f}  "
