@@ -74,6 +74,7 @@ struct mmh_context {
   int igemm_mode = 0;      // 0 auto (packed-B + LDS-DMA), 1 in-kernel transpose, 2 simple
   DevBuf qa, qb, qc, qs;   // quantised GEMM workspace: int8 A, int8 B, int32 C, {amax bits, scales}
   DevBuf flags;            // stream-K per-tile hand-off flags (+1 error word)
+  DevBuf parts;            // stream-K partial tiles: one dense BM x BN slot per persistent workgroup
   long flags_tiles = -1;   // where the error word of the last stream-K launch sits
   int streamk = 1;         // allow the persistent stream-K launch for ragged tile counts
   void *rocblas = nullptr; // rocblas_handle, created on first use
@@ -148,27 +149,27 @@ template <int BM, int BN, int WTN, int WTM = 4, int KB = mmh::BK>
 int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, int lda,
                        const float *B, int ldb, float *C, int ldc, int acc, hipStream_t s) {
   if (!ctx || !ctx->streamk) return 1;
-  if ((m % BM) || (n % BN) || (k % KB) || (lda % 4) || (ldb % 4) || !aligned16(A) || !aligned16(B))
-    return 1;
-  // C tiles must own whole 128-byte lines: partial tiles travel between
-  // workgroups through C and per-XCD L2s are not coherent with each other
-  if ((ldc % 32) || (reinterpret_cast<uintptr_t>(C) & 127)) return 1;
   const size_t lim = (1ull << 31) - 4096;
-  if (!(((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim)) return 1;
-  const int nbm = m / BM, nbn = n / BN;
+  if (!(((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim)) return 1;   // descriptor window
+  // whole, 16-byte-aligned shapes run the unguarded kernel; everything else the guarded one (partial
+  // tiles travel through a workspace, not through C, so C's alignment and ragged edges do not matter)
+  const bool fast = (m % BM == 0) && (n % BN == 0) && (k % KB == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                    (ldc % 4 == 0) && aligned16(A) && aligned16(B) && aligned16(C);
+  const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
   const long tiles = (long)nbm * nbn;
   const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-  auto kern = mmh::sgemm_mfma_streamk_kernel<BM, BN, false, WTN, WTM, KB>;
   constexpr size_t lds = lds_bytes(BM, BN, KB);
   constexpr int threads = (BM / (16 * WTM)) * (BN / (16 * WTN)) * 64;
+  auto kern_fast = mmh::sgemm_mfma_streamk_kernel<BM, BN, false, WTN, WTM, KB>;
+  auto kern_edge = mmh::sgemm_mfma_streamk_kernel<BM, BN, true, WTN, WTM, KB>;
   {
-    const int ok = allow_big_lds(kern, lds);
+    const int ok = allow_big_lds(fast ? kern_fast : kern_edge, lds);
     if (ok != MMH_OK) return ok;
   }
   // resident workgroups per CU: what the runtime reports, never more than LDS allows
   static int per_cu = [&] {
     int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, threads, lds) != hipSuccess || v < 1) v = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern_edge, threads, lds) != hipSuccess || v < 1) v = 1;
     const int by_lds = (int)((160 * 1024) / lds);
     return v < by_lds ? v : by_lds;
   }();
@@ -184,17 +185,24 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
   if (tiles > (1L << 24)) return 1;
   int rc = ctx->flags.reserve((size_t)(tiles + 1) * sizeof(int));
   if (rc != MMH_OK) return rc;
+  rc = ctx->parts.reserve((size_t)grid * BM * BN * sizeof(float));   // one partial-tile slot per range
+  if (rc != MMH_OK) return rc;
   int *flags = static_cast<int *>(ctx->flags.p);
+  float *parts = static_cast<float *>(ctx->parts.p);
   ctx->flags_tiles = tiles;
   HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(tiles + 1) * sizeof(int), s));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
-                     acc, nbm, nbn, flags, flags + tiles);
+  if (fast)
+    hipLaunchKernelGGL(kern_fast, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
+                       acc, nbm, nbn, flags, flags + tiles, parts);
+  else
+    hipLaunchKernelGGL(kern_edge, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
+                       acc, nbm, nbn, flags, flags + tiles, parts);
   HIP_TRY(hipGetLastError());
   {
-    char buf[160];
+    char buf[176];
     snprintf(buf, sizeof buf,
-             "sgemm_mfma_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d, %ld tiles on %d persistent workgroups",
-             BM, BN, 16 * WTM, 16 * WTN, KB, tiles, grid);
+             "sgemm_mfma_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d, %s%ld tiles on %d persistent workgroups",
+             BM, BN, 16 * WTM, 16 * WTN, KB, fast ? "" : "guarded, ", tiles, grid);
     g_last_launch = buf;
   }
   return MMH_OK;
@@ -451,6 +459,7 @@ int mmh_destroy(mmh_handle_t h) {
   h->b.release();
   h->c.release();
   h->flags.release();
+  h->parts.release();
   h->bt.release();
   h->qa.release();
   h->qb.release();

@@ -170,10 +170,13 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
                                                   const float *__restrict__ A, int lda,
                                                   const float *__restrict__ B, int ldb,
                                                   float *__restrict__ C, int ldc, int tm, int tn,
-                                                  int kb, int ke, bool init_from_c) {
+                                                  int kb, int ke, bool init_from_c,
+                                                  const float *part_in = nullptr, float *part_out = nullptr) {
   // One C tile (tm, tn), K-slices [kb, ke) of it.  init_from_c: the accumulators
-  // start from C's current value (accumulate mode, or the continuation of a
-  // chain another workgroup began -- stream-K below); the tile is stored at the end.
+  // start from C's current value (accumulate mode); the tile is stored at the end.
+  // Stream-K (below) splits a tile's chain between two workgroups: the first stores its partial
+  // accumulators to `part_out` instead of C, the second starts from `part_in` instead of C/zero --
+  // dense BM x BN tile images in a workspace of their own, 16-byte vectors, never shared lines.
   // WTN = MFMA tiles per wave along n: 4 -> 64x64 wave tiles (16-byte B fragments),
   // 2 -> 64x32 wave tiles (8-byte B fragments, twice the waves per block tile)
   // WTM likewise along m (4 -> 64 rows, 2 -> 32 rows, 8 -> 128 rows = two 64-row halves, each
@@ -209,7 +212,16 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   using c_vec = std::conditional_t<EDGE, c_vec_u, bfrag_t>;
   const bool whole_c = !EDGE || (row0 + BM <= m && col0 + BN <= n);
   f32x4 acc[WTM][WTN];
-  if (init_from_c) {
+  if (part_in) {
+#pragma unroll
+    for (int t = 0; t < WTM; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bfrag_t v = *reinterpret_cast<const bfrag_t *>(part_in + (size_t)(c_row(t, r) - row0) * BN + (ccol - col0));
+#pragma unroll
+        for (int u = 0; u < WTN; ++u) acc[t][u][r] = v[u];
+      }
+  } else if (init_from_c) {
 #pragma unroll
     for (int t = 0; t < WTM; ++t)
 #pragma unroll
@@ -432,7 +444,9 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
       bfrag_t v;
 #pragma unroll
       for (int u = 0; u < WTN; ++u) v[u] = acc[t][u][r];
-      if (whole_c) {
+      if (part_out) {
+        *reinterpret_cast<bfrag_t *>(part_out + (size_t)(row - row0) * BN + (ccol - col0)) = v;
+      } else if (whole_c) {
         *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + ccol) = v;
       } else if (row < m) {
 #pragma unroll
@@ -464,11 +478,13 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 // T * nk (tile, K-slice) units evenly into consecutive ranges.  A range is
 //     [a later part of tile a] [whole tiles ...] [the head of tile b]
 // and is worked through with the head of b FIRST (slices 0..h-1; the partial
-// accumulators are stored to C and the tile's part counter is published), then
-// the whole tiles, the part of a LAST.  A later part CONTINUES the chain its
-// predecessor left in C: it waits for the tile's counter to reach its part
-// index, starts its accumulators from C, runs its slices and either finishes the
-// tile or publishes the counter for the next part -- so every C(i,j) is still
+// accumulators are stored to this workgroup's slot of a partials workspace and the
+// tile's part counter is published), then the whole tiles, the part of a LAST.  A later
+// part CONTINUES the chain its predecessor left in the workspace (the slot of the range
+// before it -- consecutive parts of a tile are consecutive ranges): it waits for the
+// tile's counter to reach its part index, starts its accumulators from that slot, runs
+// its slices and either finishes the tile (only then is C written) or stores to its own
+// slot and publishes the counter for the next part -- so every C(i,j) is still
 // one fp32 fmaf chain over ascending k and the result is bit-identical to the
 // plain kernel.  A workgroup publishes its head before doing anything else, so
 // with ranges of at least one tile the wait is over before it starts; with
@@ -485,7 +501,7 @@ __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)
 sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                           const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                           int accumulate, int nbm, int nbn, int *__restrict__ flags,
-                          int *__restrict__ err) {
+                          int *__restrict__ err, float *__restrict__ parts) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nk = (k + KB - 1) / KB;
   const int T = nbm * nbn, G = gridDim.x;
@@ -527,8 +543,13 @@ sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
     int tm, tn;
     tile_of(t, tm, tn);
     __syncthreads();   // LDS is reused from segment to segment; orders the loads after the acquire
+    // partial tiles live in the workspace, one dense BM x BN slot per range: never in C, so C needs
+    // no alignment and tiles that share cache lines at ragged edges never exchange data through them
+    const float *part_in = kb > 0 ? parts + (size_t)(q - 1) * BM * BN : nullptr;
+    float *part_out = ke < nk ? parts + (size_t)q * BM * BN : nullptr;
     mfma_tile_segment<BM, BN, EDGE, 4, 0, true, WTN, WTM, KB>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn,
-                                                              kb, ke, kb > 0 || accumulate != 0);
+                                                              kb, ke, kb == 0 && accumulate != 0, part_in,
+                                                              part_out);
     if (ke < nk) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();

@@ -152,12 +152,15 @@ def test_size_independent_properties_at_full_size(mm):
 
 
 @pytest.mark.parametrize("shape", [(2176, 2176, 2176), (3072, 3072, 1024), (2560, 3200, 512),
-                                   (2944, 2944, 2944), (3328, 2176, 96)])
+                                   (2944, 2944, 2944), (3328, 2176, 96),
+                                   # guarded stream-K: ragged edges, ragged K, odd leading dimensions
+                                   (2049, 2049, 200), (2177, 2305, 333), (4097, 4095, 70)])
 def test_stream_k_is_bit_identical(mm, oracle, shape):
     """Ragged tile counts run as ONE persistent chained stream-K launch: a tile
     split between two workgroups is still one fmaf chain over ascending k
-    (the second workgroup continues from the first one's partial result in C),
-    so the bits equal the one-workgroup-per-tile kernel's and the oracle's."""
+    (the second workgroup continues from the first one's partial accumulators, handed over in
+    a workspace slot), so the bits equal the one-workgroup-per-tile kernel's and the oracle's --
+    for whole shapes and, through the guarded kernel, for any m, n, k and leading dimensions."""
     import torch
     m, n, k = shape
     a, b = oracle.harness_inputs(m, n, k, seed=m + 7 * n + 13 * k)
@@ -166,6 +169,8 @@ def test_stream_k_is_bit_identical(mm, oracle, shape):
     mm.set_streamk(True)
     got = mm.matmul(da, db)
     assert mm.streamk_timeouts() == 0
+    import how_to_optimize_gemm_amd as H
+    assert "streamk" in H.last_launch(), H.last_launch()      # the persistent launch really ran
     mm.set_kernel("mfma_tiles")
     ref = mm.matmul(da, db)
     assert torch.equal(got, ref)

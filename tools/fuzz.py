@@ -69,7 +69,7 @@ print(f"fuzz: {cases} cases x {len(VARIANTS)} variants, {bad} failures")
 
 # stream-K stress
 sk_bad = 0
-for n in (2176, 2432, 2944, 3072, 3456, 3712, 4352, 4608):
+for n in (2176, 2432, 2944, 3072, 3456, 3712, 4352, 4608, 2049, 2305, 3001):   # the last three: guarded stream-K
     a = torch.rand((n, n), device="cuda") * 2 - 1
     b = torch.rand((n, n), device="cuda") * 2 - 1
     mm.set_kernel("mfma_tiles")
