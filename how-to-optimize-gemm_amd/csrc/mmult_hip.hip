@@ -283,15 +283,13 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
       const long tiles128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);
       const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
-      // At least one 256x256 tile per CU: the big tile (fewest staging ops per MFMA) -- when the
-      // shape fills its tiles (edge tiles cost a whole tile's time) and the rounds come out
-      // even: shapes made of whole tiles are balanced by stream-K, ragged ones only by luck.
+      // At least one 256x256 tile per CU: the big tile (fewest staging ops per MFMA) -- unless its
+      // edge tiles pad the shape noticeably more than 128x128 tiles would (an edge tile costs a whole
+      // tile's time; ragged tile COUNTS are balanced by stream-K for either size).
       if (tiles256 >= cus) {
-        const bool whole = (m % 256 == 0) && (n % 256 == 0);
-        const double fill = (double)m * (double)n / ((double)tiles256 * 65536.0);
-        const long rounds = (tiles256 + cus - 1) / cus;
-        const double balance = whole ? 1.0 : (double)tiles256 / (double)(rounds * cus);
-        if (fill * balance >= 0.97)
+        const double fill256 = (double)m * (double)n / ((double)tiles256 * 65536.0);
+        const double fill128 = (double)m * (double)n / ((double)tiles128 * 16384.0);
+        if (fill256 >= fill128 - 0.015)
           return sgemm_on(ctx, MMH_KERNEL_MFMA_256X256, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
       }
       if (tiles128x64 * 2 <= cus)

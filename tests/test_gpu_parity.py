@@ -194,6 +194,25 @@ def test_stream_k_is_bit_identical(mm, oracle, shape):
     mm.set_streamk(True)
 
 
+def test_auto_on_large_ragged_shapes_uses_the_big_tile_and_keeps_the_bits(mm, oracle):
+    """AUTO sends large shapes to the 256x256 tile when its edge padding is no worse than 128x128's:
+    guarded plain launch (4000 x 4000: 256 tiles) or guarded stream-K (5000 x 5000: 400 tiles on 256
+    workgroups).  Same bits as one workgroup per 128x128 tile and as the oracle."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    for (m, n, k) in [(4000, 4000, 40), (5000, 5000, 72)]:
+        a, b = oracle.harness_inputs(m, n, k, seed=m + k)
+        da, db = dev(a), dev(b)
+        mm.set_kernel("auto")
+        got = mm.matmul(da, db)
+        assert "<256,256>" in H.last_launch(), H.last_launch()
+        assert mm.streamk_timeouts() == 0
+        mm.set_kernel("mfma_tiles")
+        assert torch.equal(got, mm.matmul(da, db))
+        assert np.array_equal(got.cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
+    mm.set_kernel("auto")
+
+
 @pytest.mark.parametrize("kernel", ["mfma", "mfma_256x256", "mfma_128x64", "mfma_64x64", "valu"])
 def test_subnormals_and_nonfinite_values_follow_the_chain(mm, oracle, kernel):
     """Edge values the reference loop would produce on the CPU must come out of the

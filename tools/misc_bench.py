@@ -148,7 +148,8 @@ if "quant" in what:
 if "edge" in what:
     print("| m x n x k | auto | rocblas | torch.mm |")
     print("|---|---|---|---|")
-    for (m, n, k) in [(4096, 4096, 4096), (4000, 4000, 4000), (4097, 4095, 4099), (4096, 4096, 4100), (3000, 5000, 2000),
+    for (m, n, k) in [(4096, 4096, 4096), (4000, 4000, 4000), (5000, 5000, 5000), (4097, 4095, 4099), (4096, 4096, 4100),
+                      (3000, 5000, 2000), (6000, 4100, 3000),
                       (1000, 1000, 1000), (2049, 2049, 2049), (16384, 2048, 16384), (2048, 16384, 16384), (8192, 8192, 512),
                       (512, 512, 16384)]:
         print(f"| {m} x {n} x {k} | " + " | ".join(f"{time_f32(m, n, k, kk, reps=10):.1f}" for kk in ("auto", "rocblas", "torch.mm")) + " |",
