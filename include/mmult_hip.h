@@ -93,6 +93,10 @@ int mmh_device_count(int *count);
 /* name must hold >= 256 bytes; cu_count / clock_mhz may be NULL. */
 int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
 
+/* A handle owns device workspaces (host-flavour staging, stream-K hand-off flags and partial-tile
+ * slots, int8 / quantisation scratch) that consecutive calls reuse: use one handle per host thread AND
+ * per stream that may run concurrently with another -- calls on ONE stream through one handle are
+ * ordered by the stream and always safe (as cublasHandle_t with cublasSetStream). */
 int mmh_create(mmh_handle_t *handle, int device);
 int mmh_destroy(mmh_handle_t handle);
 int mmh_set_kernel(mmh_handle_t handle, int kernel);
