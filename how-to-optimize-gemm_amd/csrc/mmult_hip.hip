@@ -601,6 +601,31 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
       HIP_TRY(hipMemset2DAsync(dC, (size_t)ldc * 4, 0, (size_t)n * 4, (size_t)m, s));
     return MMH_OK;
   }
+  // Default mode: operands the in-place kernel cannot take as they are (an odd leading dimension, a
+  // base that is not dword-aligned) are first copied into dense dword-aligned workspace images -- one
+  // pass over m*k / k*n bytes, against m*n*k MACs -- instead of falling back to the slow kernels.
+  if (h->igemm_mode == 0 && !mmh::igemm_s8_inplace_ok(dA, lda, dB, ldb, k)) {
+    const bool a_ok = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(dA) & 3) == 0);
+    const bool b_ok = (ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(dB) & 3) == 0);
+    const int ka = a_ok ? lda : (k + 15) & ~15, nb = b_ok ? ldb : (n + 15) & ~15;
+    const int8_t *sa = dA, *sb = dB;
+    if (!a_ok) {
+      if ((rc = h->qa.reserve((size_t)m * ka)) != MMH_OK) return rc;
+      HIP_TRY(hipMemcpy2DAsync(h->qa.p, (size_t)ka, dA, (size_t)lda, (size_t)k, (size_t)m, hipMemcpyDeviceToDevice, s));
+      sa = static_cast<const int8_t *>(h->qa.p);
+    }
+    if (!b_ok) {
+      if ((rc = h->qb.reserve((size_t)k * nb)) != MMH_OK) return rc;
+      HIP_TRY(hipMemcpy2DAsync(h->qb.p, (size_t)nb, dB, (size_t)ldb, (size_t)n, (size_t)k, hipMemcpyDeviceToDevice, s));
+      sb = static_cast<const int8_t *>(h->qb.p);
+    }
+    if (mmh::igemm_s8_inplace_ok(sa, ka, sb, nb, k)) {
+      HIP_TRY(mmh::launch_igemm_s8(m, n, k, sa, ka, sb, nb, dC, ldc, accumulate ? 1 : 0, s, nullptr, 0,
+                                   h->cu_count > 0 ? h->cu_count : 256));
+      return MMH_OK;
+    }
+    // (operands beyond the descriptors' 2 GiB window: the general path below)
+  }
   int8_t *bt = nullptr;
   if (mmh::igemm_s8_needs_pack(h->igemm_mode, dA, lda, dB, ldb, k) &&
       h->bt.reserve(mmh::igemm_s8_pack_bytes(n, k)) == MMH_OK)
