@@ -21,24 +21,32 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libmmult_hip.so")
+AB_LIB_PATH = os.path.join(PKG_DIR, "libmmult_hip_ab.so")   # tools-only build (see use_ab_library)
 
 # status codes / kernel ids (include/mmult_hip.h)
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALLOC, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_256, KERNEL_NAIVE, KERNEL_MFMA_SIMPLE, KERNEL_MFMA_PIPE = 0, 1, 2, 3, 4, 5, 6
 OPT_STREAMK, OPT_STREAMK_TIMEOUTS, OPT_IGEMM_MODE = 1, 2, 3
+OPT_SPLITK, OPT_HOST_PANELS, OPT_STREAMK_SPIN_LIMIT, OPT_FAULT_INJECT = 4, 5, 6, 7
 KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
-           "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11, "mfma_256x256": 12}
+           "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11, "mfma_256x256": 12,
+           "valu_128x128": 13, "valu_64x64": 14, "mfma_splitk": 15, "mfma_splitk_128x64": 20}
+# kernels that keep the one-chain-per-element contract (bit-identical results); the split-K ids do not
+CHAIN_KERNELS = [k for k in KERNELS if "splitk" not in k]
 
 # every symbol include/mmult_hip.h declares (tests assert the .so exports them all)
 EXPORTS = [
-    "mmh_strerror", "mmh_last_error", "mmh_last_launch", "mmh_version", "mmh_device_count", "mmh_device_info",
+    "mmh_strerror", "mmh_last_error", "mmh_last_launch", "mmh_version", "mmh_is_ab_build", "mmh_device_count",
+    "mmh_device_info",
     "mmh_create", "mmh_destroy", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name",
     "mmh_set_option", "mmh_get_option",
     "mmh_sgemm", "mmh_sgemm_host", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
     "mmh_sgemm_rocblas", "mmh_shard_rows",
-    "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
-    "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy",
+    "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm",
+    "mmh_rccl_version",
+    "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
+    "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy", "mmh_probe_hbm_read",
 ]
 
 
@@ -49,6 +57,20 @@ class MMultError(RuntimeError):
 
 
 _lib: Optional[C.CDLL] = None
+_lib_path = LIB_PATH
+
+
+def use_ab_library() -> str:
+    """tools/ only: load libmmult_hip_ab.so (the product kernels plus the scheduling A/B variants and
+    the timing-only ablation builds, whose results are WRONG) instead of the product library.  Must be
+    called before the first lib(); builds the library on demand."""
+    global _lib_path
+    if _lib is not None and _lib_path != AB_LIB_PATH:
+        raise MMultError(ERR_INVALID_ARG, "use_ab_library", "the product library is already loaded")
+    from . import build as _build
+    _build.build_ab_library()
+    _lib_path = AB_LIB_PATH
+    return AB_LIB_PATH
 
 
 def _share_hip_runtime_with_torch() -> None:
@@ -82,17 +104,18 @@ def lib() -> C.CDLL:
     if _lib is not None:
         return _lib
     _share_hip_runtime_with_torch()
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(_lib_path):
         raise MMultError(ERR_UNSUPPORTED, "load",
-                         f"{LIB_PATH} is missing -- run __graft_entry__.build(); "
+                         f"{_lib_path} is missing -- run __graft_entry__.build(); "
                          "there is no CPU fallback")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(_lib_path)
     vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
     L.mmh_strerror.argtypes = [C.c_int]
     L.mmh_strerror.restype = C.c_char_p
     L.mmh_last_error.restype = C.c_char_p
     L.mmh_last_launch.restype = C.c_char_p
     L.mmh_version.restype = C.c_int
+    L.mmh_is_ab_build.restype = C.c_int
     L.mmh_device_count.argtypes = [ip]
     L.mmh_device_info.argtypes = [C.c_int, C.c_char_p, ip, ip]
     L.mmh_create.argtypes = [C.POINTER(vp), C.c_int]
@@ -113,7 +136,15 @@ def lib() -> C.CDLL:
     L.mmh_shard_rows.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
     L.mmh_sgemm_sharded.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int,
                                     vp, C.c_int, C.c_int, fp]
+    L.mmh_shard_create.argtypes = [C.POINTER(vp), C.c_int, ip]
+    L.mmh_shard_destroy.argtypes = [vp]
+    L.mmh_shard_set_kernel.argtypes = [vp, C.c_int]
+    L.mmh_shard_info.argtypes = [vp, ip, ip]
+    L.mmh_shard_sgemm.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, fp]
+    L.mmh_rccl_version.argtypes = [ip]
     L.mmh_time_sgemm.argtypes = gemm + [C.c_int, C.c_int, vp, fp]
+    L.mmh_trace_sgemm.argtypes = gemm + [C.c_int, vp, fp]
+    L.mmh_probe_hbm_read.argtypes = [vp, C.c_size_t, fp]
     L.mmh_probe_mfma_f32.argtypes = [vp, fp]
     L.mmh_probe_mfma_i8.argtypes = [vp, fp]
     L.mmh_probe_mfma_i8_sustained.argtypes = [vp, C.c_int, C.c_float, fp]
@@ -134,6 +165,14 @@ def device_count() -> int:
     n = C.c_int(0)
     _check(lib().mmh_device_count(C.byref(n)), "mmh_device_count")
     return n.value
+
+
+def rccl_version() -> int:
+    """ncclGetVersion's code as libmmult_hip.so sees RCCL (dlopen); raises MMultError(ERR_UNSUPPORTED)
+    when librccl or an entry point the shard needs is missing.  Needs no GPU."""
+    v = C.c_int(0)
+    _check(lib().mmh_rccl_version(C.byref(v)), "mmh_rccl_version")
+    return v.value
 
 
 def shard_rows(m: int, nranks: int, rank: int) -> tuple[int, int]:
@@ -205,14 +244,37 @@ class MMult:
     def set_igemm_mode(self, mode: int) -> None:
         """0 B read in place (default; packed B for unaligned operands), tile picked by size; 1 in-kernel
         transpose; 2 correctness-first kernel; 3 / 4 packed-B + LDS-DMA with 128x128 / 256x256 tiles;
-        5 / 6 in-place B likewise; 10..13 timing-only ablations (wrong results)."""
+        5 / 6 in-place B likewise.  (10..13, timing-only ablations with wrong results, exist only in
+        the tools build libmmult_hip_ab.so; the product library rejects them.)"""
         _check(lib().mmh_set_option(self._h, OPT_IGEMM_MODE, int(mode)), "mmh_set_option")
 
     def streamk_timeouts(self) -> int:
-        """Synchronises; number of stream-K hand-off waits that timed out (must be 0)."""
+        """Synchronises; the handle's sticky error count: stream-K / split-K hand-off waits that timed
+        out since it was last cleared (must be 0; while it is not, every call on the handle raises)."""
         v = C.c_int(0)
         _check(lib().mmh_get_option(self._h, OPT_STREAMK_TIMEOUTS, C.byref(v)), "mmh_get_option")
         return v.value
+
+    def clear_error(self) -> None:
+        """Synchronises and clears the sticky error."""
+        _check(lib().mmh_set_option(self._h, OPT_STREAMK_TIMEOUTS, 0), "mmh_set_option")
+
+    def set_option(self, option: int, value: int) -> None:
+        _check(lib().mmh_set_option(self._h, int(option), int(value)), "mmh_set_option")
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int(0)
+        _check(lib().mmh_get_option(self._h, int(option), C.byref(v)), "mmh_get_option")
+        return v.value
+
+    def set_splitk(self, parts: int) -> None:
+        """OPT-IN split-K for MMH_KERNEL_AUTO: 0 off (default), 1 as many parts as fill the chip,
+        2..16 that many.  Deterministic, inside the harness tolerance, NOT the chain's bits."""
+        self.set_option(OPT_SPLITK, parts)
+
+    def set_host_panels(self, panels: int) -> None:
+        """Row panels of the host flavour's copy/compute pipeline: -1 automatic, 0/1 plain, 2..16."""
+        self.set_option(OPT_HOST_PANELS, panels)
 
     def device_info(self) -> dict:
         name = C.create_string_buffer(256)
@@ -255,20 +317,35 @@ class MMult:
         a = np.ascontiguousarray(a, dtype=np.float32)
         b = np.ascontiguousarray(b, dtype=np.float32)
         if c is None:
+            if accumulate:
+                raise MMultError(ERR_INVALID_ARG, "sgemm_host", "accumulate needs c=")
             c = np.zeros((m, n), dtype=np.float32)
+        elif (not isinstance(c, np.ndarray) or c.dtype != np.float32 or not c.flags["C_CONTIGUOUS"]
+              or not c.flags["WRITEABLE"] or c.shape != (m, n)):
+            raise MMultError(ERR_INVALID_ARG, "sgemm_host", f"c must be a writable C-contiguous float32 ({m},{n}) array")
         _check(lib().mmh_sgemm_host(self._h, m, n, k, _np_ptr(a), max(k, 1), _np_ptr(b), max(n, 1),
                                     _np_ptr(c), max(n, 1), int(accumulate)), "mmh_sgemm_host")
         return c
 
     # -- torch device-tensor glue (device memory + streams only) -------------
-    @staticmethod
-    def _tensor_args(t, rows, cols, what):
+    def _tensor_args(self, t, rows, cols, what, dtype):
+        """(data_ptr, leading dimension) of a (rows, cols) row-major window, after checking what the
+        kernels take on trust: dtype, device (the handle's), unit column stride, and a row stride
+        that does not fold rows onto each other (an expanded / overlapping view has stride(0) < cols)."""
         if not t.is_cuda:
             raise MMultError(ERR_INVALID_ARG, what, "tensor is not on a GPU (no CPU fallback)")
+        if t.dtype != dtype:
+            raise MMultError(ERR_INVALID_ARG, what, f"need dtype {dtype}, got {t.dtype}")
+        if t.device.index != self.device:
+            raise MMultError(ERR_INVALID_ARG, what,
+                             f"tensor lives on cuda:{t.device.index}, the handle on cuda:{self.device}")
         if t.dim() != 2 or t.shape[0] != rows or t.shape[1] != cols or (cols > 1 and t.stride(1) != 1):
             raise MMultError(ERR_INVALID_ARG, what, f"need a ({rows},{cols}) row-major 2-D tensor")
+        if rows > 1 and t.stride(0) < max(cols, 1):
+            raise MMultError(ERR_INVALID_ARG, what,
+                             f"row stride {t.stride(0)} < {cols} columns: rows overlap (expanded view?)")
         ld = t.stride(0) if rows > 1 else max(cols, 1)
-        return t.data_ptr(), max(ld, cols, 1)
+        return t.data_ptr(), max(ld, 1)
 
     def matmul(self, a, b, out=None, accumulate: bool = False):
         """C = A @ B (+ C) for fp32 CUDA tensors, on torch's current stream."""
@@ -283,9 +360,9 @@ class MMult:
             if accumulate:
                 raise MMultError(ERR_INVALID_ARG, "matmul", "accumulate needs out=")
             out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-        pa, lda = self._tensor_args(a, m, k, "matmul(A)")
-        pb, ldb = self._tensor_args(b, k, n, "matmul(B)")
-        pc, ldc = self._tensor_args(out, m, n, "matmul(C)")
+        pa, lda = self._tensor_args(a, m, k, "matmul(A)", torch.float32)
+        pb, ldb = self._tensor_args(b, k, n, "matmul(B)", torch.float32)
+        pc, ldc = self._tensor_args(out, m, n, "matmul(C)", torch.float32)
         stream = torch.cuda.current_stream(a.device).cuda_stream
         self.sgemm(m, n, k, pa, lda, pb, ldb, pc, ldc, accumulate, stream)
         return out
@@ -303,9 +380,9 @@ class MMult:
             if accumulate:
                 raise MMultError(ERR_INVALID_ARG, "igemm_s8", "accumulate needs out=")
             out = torch.empty((m, n), dtype=torch.int32, device=a.device)
-        pa, lda = self._tensor_args(a, m, k, "igemm_s8(A)")
-        pb, ldb = self._tensor_args(b, k, n, "igemm_s8(B)")
-        pc, ldc = self._tensor_args(out, m, n, "igemm_s8(C)")
+        pa, lda = self._tensor_args(a, m, k, "igemm_s8(A)", torch.int8)
+        pb, ldb = self._tensor_args(b, k, n, "igemm_s8(B)", torch.int8)
+        pc, ldc = self._tensor_args(out, m, n, "igemm_s8(C)", torch.int32)
         stream = torch.cuda.current_stream(a.device).cuda_stream
         _check(lib().mmh_igemm_s8(self._h, m, n, k, pa, lda, pb, ldb, pc, ldc, int(accumulate), stream),
                "mmh_igemm_s8")
@@ -314,10 +391,12 @@ class MMult:
     def quantize_sym_s8(self, x):
         """fp32 CUDA tensor -> (int8 tensor in [-127,127], scale as a 1-element CUDA tensor)."""
         import torch
+        if x.dim() != 2:
+            raise MMultError(ERR_INVALID_ARG, "quantize(X)", "need a 2-D tensor")
         rows, cols = x.shape
+        px, ldx = self._tensor_args(x, rows, cols, "quantize(X)", torch.float32)
         q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
         scale = torch.empty(1, dtype=torch.float32, device=x.device)
-        px, ldx = self._tensor_args(x, rows, cols, "quantize(X)")
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _check(lib().mmh_quantize_sym_s8(self._h, rows, cols, px, ldx, q.data_ptr(), max(cols, 1),
                                          scale.data_ptr(), stream), "mmh_quantize_sym_s8")
@@ -327,12 +406,14 @@ class MMult:
         """C_f32 = dequantise(quantise(A) @ quantise(B)): chgemm-style symmetric int8 GEMM."""
         import torch
         m, k = a.shape
-        _, n = b.shape
+        k2, n = b.shape
+        if k != k2:
+            raise MMultError(ERR_INVALID_ARG, "qgemm", "inner dimensions differ")
         if out is None:
             out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-        pa, lda = self._tensor_args(a, m, k, "qgemm(A)")
-        pb, ldb = self._tensor_args(b, k, n, "qgemm(B)")
-        pc, ldc = self._tensor_args(out, m, n, "qgemm(C)")
+        pa, lda = self._tensor_args(a, m, k, "qgemm(A)", torch.float32)
+        pb, ldb = self._tensor_args(b, k, n, "qgemm(B)", torch.float32)
+        pc, ldc = self._tensor_args(out, m, n, "qgemm(C)", torch.float32)
         stream = torch.cuda.current_stream(a.device).cuda_stream
         _check(lib().mmh_qgemm_f32(self._h, m, n, k, pa, lda, pb, ldb, pc, ldc, stream), "mmh_qgemm_f32")
         return out
@@ -341,12 +422,14 @@ class MMult:
         """Vendor comparator (cuda/MMult_cuBLAS_1.cpp:11-19)."""
         import torch
         m, k = a.shape
-        _, n = b.shape
+        k2, n = b.shape
+        if k != k2:
+            raise MMultError(ERR_INVALID_ARG, "matmul_rocblas", "inner dimensions differ")
         if out is None:
             out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-        pa, lda = self._tensor_args(a, m, k, "rocblas(A)")
-        pb, ldb = self._tensor_args(b, k, n, "rocblas(B)")
-        pc, ldc = self._tensor_args(out, m, n, "rocblas(C)")
+        pa, lda = self._tensor_args(a, m, k, "rocblas(A)", torch.float32)
+        pb, ldb = self._tensor_args(b, k, n, "rocblas(B)", torch.float32)
+        pc, ldc = self._tensor_args(out, m, n, "rocblas(C)", torch.float32)
         stream = torch.cuda.current_stream(a.device).cuda_stream
         _check(lib().mmh_sgemm_rocblas(self._h, m, n, k, pa, lda, pb, ldb, pc, ldc, stream),
                "mmh_sgemm_rocblas")
@@ -360,6 +443,13 @@ class MMult:
         _check(lib().mmh_time_sgemm(self._h, m, n, k, dA, lda, dB, ldb, dC, ldc, warmup, reps, stream,
                                     C.byref(ms)), "mmh_time_sgemm")
         return ms.value
+
+    def trace_sgemm(self, m, n, k, dA, lda, dB, ldb, dC, ldc, count=400, stream: int = 0):
+        """Per-launch ms of `count` back-to-back launches (one hipEvent pair each): the clock ramp."""
+        buf = (C.c_float * count)()
+        _check(lib().mmh_trace_sgemm(self._h, m, n, k, dA, lda, dB, ldb, dC, ldc, count, stream, buf),
+               "mmh_trace_sgemm")
+        return list(buf)
 
     def probe_mfma_f32(self) -> float:
         v = C.c_float(0)
@@ -385,6 +475,66 @@ class MMult:
         _check(lib().mmh_probe_hbm_copy(self._h, nbytes, C.byref(v)), "mmh_probe_hbm_copy")
         return v.value
 
+    def probe_hbm_read(self, nbytes: int = 1 << 30) -> float:
+        v = C.c_float(0)
+        _check(lib().mmh_probe_hbm_read(self._h, nbytes, C.byref(v)), "mmh_probe_hbm_read")
+        return v.value
+
+
+class ShardedMMult:
+    """Single-process row-panel shard over `ngpus` devices with everything persistent (one RCCL
+    communicator, per-device streams, product handles and buffers): mmh_shard_create/_sgemm/_destroy.
+    Raises MMultError(ERR_NO_DEVICE) when fewer devices are visible -- never fewer ranks silently."""
+
+    def __init__(self, ngpus: int, devices=None, kernel="auto"):
+        self._h = C.c_void_p(None)
+        dev = None
+        if devices is not None:
+            if len(devices) != ngpus:
+                raise MMultError(ERR_INVALID_ARG, "ShardedMMult", "len(devices) != ngpus")
+            dev = (C.c_int * ngpus)(*devices)
+        _check(lib().mmh_shard_create(C.byref(self._h), ngpus, dev), "mmh_shard_create")
+        _check(lib().mmh_shard_set_kernel(self._h, _kernel_id(kernel)), "mmh_shard_set_kernel")
+
+    def close(self) -> None:
+        if self._h:
+            lib().mmh_shard_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def info(self) -> dict:
+        n, r = C.c_int(0), C.c_int(0)
+        _check(lib().mmh_shard_info(self._h, C.byref(n), C.byref(r)), "mmh_shard_info")
+        return {"ngpus": n.value, "rccl_ranks": r.value}
+
+    def sgemm(self, a: np.ndarray, b: np.ndarray, c: Optional[np.ndarray] = None, gemm_reps: int = 1):
+        """C = A @ B on host arrays.  Returns (C, {"h2d","bcast","gemm","d2h"} ms; gemm is per rep)."""
+        m, k = a.shape
+        k2, n = b.shape
+        if k != k2:
+            raise MMultError(ERR_INVALID_ARG, "ShardedMMult.sgemm", "inner dimensions differ")
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        if c is None:
+            c = np.zeros((m, n), dtype=np.float32)
+        elif c.dtype != np.float32 or not c.flags["C_CONTIGUOUS"] or c.shape != (m, n):
+            raise MMultError(ERR_INVALID_ARG, "ShardedMMult.sgemm", "c must be C-contiguous float32 (m,n)")
+        t = (C.c_float * 4)()
+        _check(lib().mmh_shard_sgemm(self._h, m, n, k, _np_ptr(a), max(k, 1), _np_ptr(b), max(n, 1), _np_ptr(c),
+                                     max(n, 1), gemm_reps, t), "mmh_shard_sgemm")
+        return c, dict(zip(("h2d", "bcast", "gemm", "d2h"), list(t)))
+
 
 def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
     """Single-process multi-device row-panel shard (mmh_sgemm_sharded).
@@ -400,7 +550,8 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
     return c, dict(zip(("h2d", "bcast", "gemm", "d2h"), list(t)))
 
 
-__all__ = ["MMult", "MMultError", "lib", "device_count", "shard_rows", "kernel_name", "last_launch", "sgemm_sharded",
-           "KERNELS", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
+__all__ = ["MMult", "ShardedMMult", "MMultError", "lib", "use_ab_library", "device_count", "rccl_version", "shard_rows",
+           "kernel_name", "last_launch", "sgemm_sharded", "KERNELS", "CHAIN_KERNELS", "AB_LIB_PATH",
+           "OPT_SPLITK", "OPT_HOST_PANELS", "OPT_STREAMK_SPIN_LIMIT", "OPT_FAULT_INJECT", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
            "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OPT_IGEMM_MODE", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

@@ -14,6 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libmmult_hip.so")
+AB_LIB = os.path.join(PKG_DIR, "libmmult_hip_ab.so")   # tools-only build: A/B variants + timing-only ablations
 HARNESS = os.path.join(PKG_DIR, "harness")
 ARCH = "gfx950"
 
@@ -50,6 +51,21 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     return LIB
+
+
+def build_ab_library(force: bool = False, verbose: bool = False) -> str:
+    """The same sources with -DMMH_AB_BUILD -> libmmult_hip_ab.so: the product kernels PLUS the
+    scheduling A/B variants and the timing-only ablation builds (wrong results).  Loaded by
+    tools/ab_bench.py and tools/misc_bench.py only; never by the package, the harness or the tests
+    of the product path."""
+    srcs = library_sources()
+    if force or _stale(AB_LIB, srcs):
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMMH_AB_BUILD",
+               "-Wno-unused-result", os.path.join(CSRC, "mmult_hip.hip"), "-o", AB_LIB, "-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return AB_LIB
 
 
 def build_harness(force: bool = False) -> str:

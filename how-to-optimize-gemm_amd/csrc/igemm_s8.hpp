@@ -813,8 +813,9 @@ inline hipError_t launch_igemm_s8_dequant(int m, int n, int k, const int8_t *A, 
 //           `bt_ws` >= igemm_s8_pack_bytes), else K3 / simple;
 //       1 = K3 (in-kernel transpose), 2 = the simple kernel,
 //       3 / 4 = K3d with 128x128 / 256x256 tiles forced, 5 / 6 = K3t likewise (A/B switches),
-//       10..13 = timing-only ablations of the packed 256x256 kernel (WRONG results; needs m, n
-//       multiples of 256): no DMA / no fragment reads / neither / no C store.
+//       10..13 = (libmmult_hip_ab.so only, -DMMH_AB_BUILD) timing-only ablations of the packed 256x256
+//       kernel (WRONG results; needs m, n multiples of 256): no DMA / no fragment reads / neither /
+//       no C store.  The product library rejects these modes.
 inline hipError_t launch_igemm_s8(int m, int n, int k, const int8_t *A, int lda, const int8_t *B,
                                   int ldb, int32_t *C, int ldc, int acc, hipStream_t s,
                                   int8_t *bt_ws = nullptr, int mode = 0, int num_cus = 256) {
@@ -846,10 +847,12 @@ inline hipError_t launch_igemm_s8(int m, int n, int k, const int8_t *A, int lda,
     switch (mode) {
       case 3: return launch_igemm_s8_dma<128, 128, 4>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
       case 4: return launch_igemm_s8_dma<256, 256, 8>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+#ifdef MMH_AB_BUILD   // timing-only ablations: libmmult_hip_ab.so (tools/) only
       case 10: return launch_igemm_s8_dma_edge<256, 256, 8, false, 1>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
       case 11: return launch_igemm_s8_dma_edge<256, 256, 8, false, 2>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
       case 12: return launch_igemm_s8_dma_edge<256, 256, 8, false, 3>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
       case 13: return launch_igemm_s8_dma_edge<256, 256, 8, false, 4>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+#endif
       default: break;
     }
     if (tiles256 >= num_cus)

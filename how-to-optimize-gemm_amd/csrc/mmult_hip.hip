@@ -7,6 +7,11 @@
 // host-pointer flavour's staging.  No torch, no CPU fallback: if no gfx950
 // device is visible every compute entry point returns MMH_ERR_NO_DEVICE /
 // MMH_ERR_HIP.
+//
+// Two builds of this one source:
+//   libmmult_hip.so     the product: every kernel id it accepts returns correct results;
+//   libmmult_hip_ab.so  (-DMMH_AB_BUILD, tools/ only) additionally carries the scheduling A/B
+//                       variants and the TIMING-ONLY ablation builds whose results are wrong.
 #include "../../include/mmult_hip.h"
 
 #include <dlfcn.h>
@@ -14,8 +19,13 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -63,6 +73,26 @@ struct DevBuf {
   }
 };
 
+// Entry points run on the HANDLE's device and leave the caller's current device as they found it
+// (a torch process whose current device differs from the handle's must not find it changed).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t enter(int device) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return e;
+    if (prev == device) return hipSuccess;
+    e = hipSetDevice(device);
+    switched = e == hipSuccess;
+    return e;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+constexpr int kMaxHostPanels = 16;
+
 }  // namespace
 
 struct mmh_context {
@@ -71,16 +101,47 @@ struct mmh_context {
   int cu_count = 0;
   DevBuf a, b, c;          // staging for the host-pointer flavour
   DevBuf bt;               // int8 GEMM: packed (transposed, padded) B
-  int igemm_mode = 0;      // 0 auto (packed-B + LDS-DMA), 1 in-kernel transpose, 2 simple
+  int igemm_mode = 0;      // 0 auto (B in place / packed-B + LDS-DMA), 1 in-kernel transpose, 2 simple
   DevBuf qa, qb, qc, qs;   // quantised GEMM workspace: int8 A, int8 B, int32 C, {amax bits, scales}
-  DevBuf flags;            // stream-K per-tile hand-off flags (+1 error word)
-  DevBuf parts;            // stream-K partial tiles: one dense BM x BN slot per persistent workgroup
-  long flags_tiles = -1;   // where the error word of the last stream-K launch sits
+  DevBuf flags;            // stream-K / split-K per-tile hand-off words
+  DevBuf parts;            // stream-K / split-K partial tiles
   int streamk = 1;         // allow the persistent stream-K launch for ragged tile counts
+  int splitk = 0;          // opt-in split-K: 0 off (default), 1 auto, >= 2 that many parts
+  int host_panels = -1;    // host flavour: -1 auto, 0/1 the plain staged form, n pipelined row panels
   void *rocblas = nullptr; // rocblas_handle, created on first use
+  // the sticky error word: host memory the device can write (a hand-off wait that times out adds to it);
+  // every entry point looks at it before doing anything else
+  int *sticky = nullptr;       // host view
+  int *sticky_dev = nullptr;   // device view of the same word
+  long long spin_limit = 1ll << 26;
+  int fault = 0;               // MMH_OPT_FAULT_INJECT
+  // the hand-off workspaces above are per handle: a launch on another stream first waits for the
+  // stream that used them last
+  hipStream_t ws_stream = nullptr;
+  bool ws_used = false;
+  // resident workgroups per CU of each persistent kernel, per handle (= per device)
+  std::vector<std::pair<const void *, int>> per_cu;
+  // host flavour pipeline: copy-in / compute / copy-out streams, per-panel events
+  hipStream_t hs_in = nullptr, hs_run = nullptr, hs_out = nullptr;
+  hipEvent_t ev_in[kMaxHostPanels] = {}, ev_run[kMaxHostPanels] = {}, ev_b = nullptr;
+  bool pipeline_ready = false;
 };
 
 namespace {
+
+// every compute entry point: refuse a handle whose sticky error word is set
+int check_sticky(mmh_context *h) {
+  if (h && h->sticky && *reinterpret_cast<volatile int *>(h->sticky) != 0) {
+    g_last_error = "an earlier stream-K / split-K launch on this handle timed out waiting for a hand-off: "
+                   "its result is invalid (clear with mmh_set_option(h, MMH_OPT_STREAMK_TIMEOUTS, 0))";
+    return MMH_ERR_HIP;
+  }
+  return MMH_OK;
+}
+#define ENTER(h)                                       \
+  DeviceGuard guard_;                                  \
+  HIP_TRY(guard_.enter((h)->device));                  \
+  if (int st_ = check_sticky(h); st_ != MMH_OK) return st_
 
 constexpr size_t lds_bytes(int BM, int BN, int KB = mmh::BK) {
   return 2ull * (size_t)KB * (BM + BN) * sizeof(float);
@@ -94,6 +155,19 @@ int allow_big_lds(K kernel, size_t bytes) {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// whole tiles, 16-byte aligned operands: the unguarded instantiations
+bool fast_shape(int BM, int BN, int KB, int m, int n, int k, const void *A, int lda, const void *B, int ldb,
+                const void *C, int ldc) {
+  return (m % BM == 0) && (n % BN == 0) && (k % KB == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) &&
+         aligned16(A) && aligned16(B) && aligned16(C);
+}
+
+// the buffer-descriptor path needs every byte offset inside a 2 GiB window
+bool window_ok(int BM, int BN, int k, int lda, int ldb) {
+  const size_t lim = (1ull << 31) - 4096;
+  return ((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim;
+}
+
 // SIMPLE: the un-pipelined rung.  SCHED / BUFLD / ABL: see sgemm_mfma.hpp.  The
 // buffer-descriptor path needs every byte offset inside a 2 GiB window; larger
 // operands fall back to 64-bit global addressing (same kernel, BUFLD = false).
@@ -102,14 +176,11 @@ template <int BM, int BN, bool SIMPLE = false, int SCHED = 4, int ABL = 0, bool 
 int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, int ldb,
                 float *C, int ldc, int acc, hipStream_t s) {
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
-  const bool fast = (m % BM == 0) && (n % BN == 0) && (k % KB == 0) && (lda % 4 == 0) &&
-                    (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(A) && aligned16(B) &&
-                    aligned16(C);
+  const bool fast = fast_shape(BM, BN, KB, m, n, k, A, lda, B, ldb, C, ldc);
   constexpr int threads = (BM / (16 * WTM)) * (BN / (16 * WTN)) * 64;
   constexpr size_t lds = lds_bytes(BM, BN, KB);
   dim3 grid((unsigned)(nbm * nbn)), block(threads);
-  const size_t lim = (1ull << 31) - 4096;
-  const bool window_ok = ((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim;
+  const bool win = window_ok(BM, BN, k, lda, ldb);
 #define MMH_LAUNCH(KERN)                                                                   \
   do {                                                                                     \
     auto kern = KERN;                                                                      \
@@ -123,9 +194,9 @@ int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, in
   } else if (!fast) {
     // guarded launch: buffer descriptors bound the reads (any alignment >= 4 B);
     // operands larger than the descriptor window use the per-element path
-    if (BUFLD && window_ok) MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, true, WTN, WTM, KB>));
-    else                    MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, false, WTN, WTM, KB>));
-  } else if (BUFLD && window_ok) {
+    if (BUFLD && win) MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, true, WTN, WTM, KB>));
+    else              MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, true, SCHED, 0, false, WTN, WTM, KB>));
+  } else if (BUFLD && win) {
     MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, BUFLD, WTN, WTM, KB>));
   } else {
     MMH_LAUNCH((mmh::sgemm_mfma_kernel<BM, BN, false, SCHED, ABL, false, WTN, WTM, KB>));
@@ -142,19 +213,53 @@ int launch_mfma(int m, int n, int k, const float *A, int lda, const float *B, in
   return MMH_OK;
 }
 
+// resident workgroups per CU of a persistent kernel: what the runtime reports, never more than the
+// LDS allows; computed once per handle (= per device) and kernel
+template <typename K>
+int resident_per_cu(mmh_context *ctx, K kernel, int threads, size_t lds) {
+  const void *key = reinterpret_cast<const void *>(kernel);
+  for (const auto &e : ctx->per_cu)
+    if (e.first == key) return e.second;
+  int v = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, threads, lds) != hipSuccess || v < 1) v = 1;
+  const int by_lds = (int)((160 * 1024) / lds);
+  v = v < by_lds ? v : by_lds;
+  if (v < 1) v = 1;
+  ctx->per_cu.emplace_back(key, v);
+  return v;
+}
+
+// The hand-off workspaces (flags, partial tiles) belong to the handle.  Launches on ONE stream are
+// ordered by the stream; a launch on ANOTHER stream than the last one first waits for that stream, so
+// two streams can never have the workspaces in use at once.
+int claim_workspaces(mmh_context *ctx, hipStream_t s) {
+  if (ctx->ws_used && ctx->ws_stream != s) {
+    hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &a);
+    (void)hipStreamIsCapturing(ctx->ws_stream, &b);
+    if (a != hipStreamCaptureStatusNone || b != hipStreamCaptureStatusNone) {
+      g_last_error = "the handle's stream-K workspaces were last used on another stream and one of the two is "
+                     "being captured: use one handle per stream";
+      return MMH_ERR_INVALID_ARG;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->ws_stream));
+  }
+  ctx->ws_stream = s;
+  ctx->ws_used = true;
+  return MMH_OK;
+}
+
 // Persistent chained stream-K launch (sgemm_mfma.hpp, K2p) of tile config
 // <BM, BN, WTN>.  Returns MMH_OK if it launched, 1 if the shape does not qualify
 // (caller then uses the plain one-tile-per-workgroup launch).
 template <int BM, int BN, int WTN, int WTM = 4, int KB = mmh::BK>
 int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, int lda,
                        const float *B, int ldb, float *C, int ldc, int acc, hipStream_t s) {
-  if (!ctx || !ctx->streamk) return 1;
-  const size_t lim = (1ull << 31) - 4096;
-  if (!(((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim)) return 1;   // descriptor window
+  if (!ctx || !ctx->streamk || !ctx->sticky_dev) return 1;
+  if (!window_ok(BM, BN, k, lda, ldb)) return 1;   // descriptor window
   // whole, 16-byte-aligned shapes run the unguarded kernel; everything else the guarded one (partial
   // tiles travel through a workspace, not through C, so C's alignment and ragged edges do not matter)
-  const bool fast = (m % BM == 0) && (n % BN == 0) && (k % KB == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
-                    (ldc % 4 == 0) && aligned16(A) && aligned16(B) && aligned16(C);
+  const bool fast = fast_shape(BM, BN, KB, m, n, k, A, lda, B, ldb, C, ldc);
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
   const long tiles = (long)nbm * nbn;
   const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
@@ -166,13 +271,7 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
     const int ok = allow_big_lds(fast ? kern_fast : kern_edge, lds);
     if (ok != MMH_OK) return ok;
   }
-  // resident workgroups per CU: what the runtime reports, never more than LDS allows
-  static int per_cu = [&] {
-    int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern_edge, threads, lds) != hipSuccess || v < 1) v = 1;
-    const int by_lds = (int)((160 * 1024) / lds);
-    return v < by_lds ? v : by_lds;
-  }();
+  const int per_cu = resident_per_cu(ctx, kern_edge, threads, lds);
   // the largest grid (whole CUs' worth of workgroups) that still gives every
   // workgroup at least one full tile, so that chains never stall.  (Shorter ranges
   // are legal for the kernel -- tiles then have three or more parts -- but measured
@@ -183,20 +282,21 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
     if (tiles >= (long)w * cus) { grid = w * cus; break; }
   if (grid == 0 || tiles % grid == 0) return 1;   // too few tiles, or already balanced
   if (tiles > (1L << 24)) return 1;
-  int rc = ctx->flags.reserve((size_t)(tiles + 1) * sizeof(int));
+  int rc = claim_workspaces(ctx, s);
+  if (rc != MMH_OK) return rc;
+  rc = ctx->flags.reserve((size_t)tiles * sizeof(int));
   if (rc != MMH_OK) return rc;
   rc = ctx->parts.reserve((size_t)grid * BM * BN * sizeof(float));   // one partial-tile slot per range
   if (rc != MMH_OK) return rc;
   int *flags = static_cast<int *>(ctx->flags.p);
   float *parts = static_cast<float *>(ctx->parts.p);
-  ctx->flags_tiles = tiles;
-  HIP_TRY(hipMemsetAsync(flags, 0, (size_t)(tiles + 1) * sizeof(int), s));
+  HIP_TRY(hipMemsetAsync(flags, 0, (size_t)tiles * sizeof(int), s));
   if (fast)
     hipLaunchKernelGGL(kern_fast, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
-                       acc, nbm, nbn, flags, flags + tiles, parts);
+                       acc, nbm, nbn, flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault);
   else
     hipLaunchKernelGGL(kern_edge, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
-                       acc, nbm, nbn, flags, flags + tiles, parts);
+                       acc, nbm, nbn, flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault);
   HIP_TRY(hipGetLastError());
   {
     char buf[176];
@@ -208,23 +308,68 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
   return MMH_OK;
 }
 
-int launch_valu(int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
-                int ldc, int acc, hipStream_t s) {
-  constexpr int BM = 128, BN = 128;
+// Opt-in split-K launch (sgemm_mfma.hpp, K2s) of tile config <BM, BN, WTN> with S concurrent K parts.
+// Returns MMH_OK if it launched, 1 if the shape does not qualify.
+template <int BM, int BN, int WTN, int WTM = 4, int KB = mmh::BK>
+int try_launch_splitk(mmh_context *ctx, int S, int m, int n, int k, const float *A, int lda, const float *B,
+                      int ldb, float *C, int ldc, int acc, hipStream_t s) {
+  if (!ctx || !ctx->sticky_dev || S < 2) return 1;
+  if (!window_ok(BM, BN, k, lda, ldb) || !fast_shape(BM, BN, KB, m, n, k, A, lda, B, ldb, C, ldc)) return 1;
+  const int nbm = m / BM, nbn = n / BN, nk = k / KB;
+  const long tiles = (long)nbm * nbn;
+  if (S > nk) S = nk;
+  if (S < 2) return 1;
+  const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+  constexpr size_t lds = lds_bytes(BM, BN, KB);
+  constexpr int threads = (BM / (16 * WTM)) * (BN / (16 * WTN)) * 64;
+  auto kern = mmh::sgemm_mfma_splitk_kernel<BM, BN, WTN, WTM, KB>;
+  {
+    const int ok = allow_big_lds(kern, lds);
+    if (ok != MMH_OK) return ok;
+  }
+  const int per_cu = resident_per_cu(ctx, kern, threads, lds);
+  while (S >= 2 && tiles * S > (long)per_cu * cus) --S;   // every part resident at once
+  if (S < 2) return 1;
+  int rc = claim_workspaces(ctx, s);
+  if (rc != MMH_OK) return rc;
+  rc = ctx->flags.reserve((size_t)tiles * sizeof(int));
+  if (rc != MMH_OK) return rc;
+  rc = ctx->parts.reserve((size_t)tiles * (S - 1) * BM * BN * sizeof(float));
+  if (rc != MMH_OK) return rc;
+  int *flags = static_cast<int *>(ctx->flags.p);
+  float *parts = static_cast<float *>(ctx->parts.p);
+  HIP_TRY(hipMemsetAsync(flags, 0, (size_t)tiles * sizeof(int), s));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc,
+                     nbm, nbn, S, flags, ctx->sticky_dev, parts, ctx->spin_limit);
+  HIP_TRY(hipGetLastError());
+  {
+    char buf[176];
+    snprintf(buf, sizeof buf,
+             "sgemm_mfma_splitk_kernel<%d,%d> wave tile %dx%d, K-slice %d, %ld tiles x %d concurrent K parts",
+             BM, BN, 16 * WTM, 16 * WTN, KB, tiles, S);
+    g_last_launch = buf;
+  }
+  return MMH_OK;
+}
+
+template <int BM, int BN, int KB>
+int launch_valu_tile(int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
+                     int ldc, int acc, hipStream_t s) {
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
-  const bool fast = (m % BM == 0) && (n % BN == 0) && (k % mmh::BK == 0) && (lda % 4 == 0) &&
-                    (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(A) && aligned16(B) &&
-                    aligned16(C);
-  constexpr size_t lds = lds_bytes(BM, BN);
+  const bool fast = fast_shape(BM, BN, KB, m, n, k, A, lda, B, ldb, C, ldc);
+  constexpr size_t lds = lds_bytes(BM, BN, KB);
   dim3 grid((unsigned)(nbm * nbn)), block(256);
   if (fast)
-    hipLaunchKernelGGL(mmh::sgemm_valu_kernel<false>, grid, block, lds, s, m, n, k, A, lda, B, ldb,
+    hipLaunchKernelGGL((mmh::sgemm_valu_kernel<BM, BN, KB, false>), grid, block, lds, s, m, n, k, A, lda, B, ldb,
                        C, ldc, acc, nbm, nbn);
   else
-    hipLaunchKernelGGL(mmh::sgemm_valu_kernel<true>, grid, block, lds, s, m, n, k, A, lda, B, ldb,
+    hipLaunchKernelGGL((mmh::sgemm_valu_kernel<BM, BN, KB, true>), grid, block, lds, s, m, n, k, A, lda, B, ldb,
                        C, ldc, acc, nbm, nbn);
   HIP_TRY(hipGetLastError());
-  g_last_launch = "sgemm_valu_kernel<128,128>";
+  char buf[96];
+  snprintf(buf, sizeof buf, "sgemm_valu_kernel<%d,%d> K-slice %d, %s%d workgroups", BM, BN, KB, fast ? "" : "guarded, ",
+           nbm * nbn);
+  g_last_launch = buf;
   return MMH_OK;
 }
 
@@ -234,6 +379,7 @@ int launch_naive(int m, int n, int k, const float *A, int lda, const float *B, i
   hipLaunchKernelGGL(mmh::sgemm_naive_kernel, grid, block, 0, s, m, n, k, A, lda, B, ldb, C, ldc,
                      acc);
   HIP_TRY(hipGetLastError());
+  g_last_launch = "sgemm_naive_kernel";
   return MMH_OK;
 }
 
@@ -245,6 +391,9 @@ int check_gemm_args(int m, int n, int k, const void *A, int lda, const void *B, 
   if (k > 0 && (!A || !B || lda < k || ldb < n)) return MMH_ERR_INVALID_ARG;
   return MMH_OK;
 }
+
+// is `kernel` an id this build accepts?
+bool known_kernel(int kernel) { return mmh_kernel_name(kernel) != nullptr; }
 
 int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
              float *dC, int ldc, int accumulate, hipStream_t s) {
@@ -262,9 +411,17 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
     return MMH_OK;
   }
   const int acc = accumulate ? 1 : 0;
+  const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
+  const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
   switch (kernel) {
     case MMH_KERNEL_VALU:
-      return launch_valu(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      // K1: the 128x128 rung while there is at least one such tile per CU, the 64x64 tile below
+      if (tiles128 < cus) return launch_valu_tile<64, 64, 64>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      return launch_valu_tile<128, 128, 32>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_VALU_128X128:
+      return launch_valu_tile<128, 128, 32>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_VALU_64X64:
+      return launch_valu_tile<64, 64, 64>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case MMH_KERNEL_NAIVE:
       return launch_naive(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case MMH_KERNEL_MFMA_SIMPLE:
@@ -279,8 +436,6 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       // workgroups, 94 % of the per-tile efficiency) wins; when even those number no more
       // than half the CUs, the 64x64 configuration; everything else is K2.  Each choice
       // runs as a stream-K launch when its tile count is ragged.
-      const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
-      const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
       const long tiles128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);
       const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
       // At least one 256x256 tile per CU: the big tile (fewest staging ops per MFMA) -- unless its
@@ -291,6 +446,21 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
         const double fill128 = (double)m * (double)n / ((double)tiles128 * 16384.0);
         if (fill256 >= fill128 - 0.015)
           return sgemm_on(ctx, MMH_KERNEL_MFMA_256X256, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+      }
+      // OPT-IN split-K (default off: it gives up the one-chain-per-element bits, see sgemm_mfma.hpp K2s):
+      // shapes with fewer 128x128 tiles than workgroup slots run their K ranges concurrently
+      if (ctx && ctx->splitk > 0 && tiles128 < cus) {
+        int S = ctx->splitk;
+        if (S == 1) {   // auto: fill two workgroups per CU, keep >= 8 K-slices per part
+          S = (int)((2 * cus) / (tiles128 > 0 ? tiles128 : 1));
+          const int by_k = k / (8 * mmh::BK);
+          if (S > by_k) S = by_k;
+          if (S > 8) S = 8;
+        }
+        if (S >= 2) {
+          const int sk = try_launch_splitk<128, 128, 4>(ctx, S, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+          if (sk <= 0) return sk;
+        }
       }
       if (tiles128x64 * 2 <= cus)
         return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
@@ -321,11 +491,34 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       if (sk <= 0) return sk;
       return launch_mfma<128, 64, false, 4, 0, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     }
+    case MMH_KERNEL_MFMA_SPLITK: {   // K2s forced: 128x128 tiles, ctx->splitk parts (auto when <= 1)
+      int S = ctx ? ctx->splitk : 0;
+      if (S <= 1) {
+        S = (int)((2 * cus) / (tiles128 > 0 ? tiles128 : 1));
+        const int by_k = k / (8 * mmh::BK);
+        S = std::min(std::min(S, by_k), 8);
+      }
+      const int sk = try_launch_splitk<128, 128, 4>(ctx, S, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      return sgemm_on(ctx, MMH_KERNEL_MFMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+    }
+    case MMH_KERNEL_MFMA_SPLITK_128X64: {   // K2s on 128x64 tiles
+      int S = ctx ? ctx->splitk : 0;
+      const long tiles = (long)((m + 127) / 128) * ((n + 63) / 64);
+      if (S <= 1) {
+        S = (int)((2 * cus) / (tiles > 0 ? tiles : 1));
+        const int by_k = k / (8 * mmh::BK);
+        S = std::min(std::min(S, by_k), 8);
+      }
+      const int sk = try_launch_splitk<128, 64, 2>(ctx, S, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      return sgemm_on(ctx, MMH_KERNEL_MFMA_128X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+    }
+#ifdef MMH_AB_BUILD
+    // ---- tools-only variants (libmmult_hip_ab.so); never part of the product library ----
     case 19: {  // A/B: B through LDS-DMA (buffer_load ... lds)
       const int nbm = m / 128, nbn = n / 128;
-      if ((m % 128) || (n % 128) || (k % 32) || (lda % 4) || (ldb % 4) || (ldc % 4) || !aligned16(dA) ||
-          !aligned16(dB) || !aligned16(dC))
-        return MMH_ERR_INVALID_ARG;
+      if (!fast_shape(128, 128, 32, m, n, k, dA, lda, dB, ldb, dC, ldc)) return MMH_ERR_INVALID_ARG;
       auto kern = mmh::sgemm_mfma_kernel<128, 128, false, 4, 0, true, 4, 4, 32, true>;
       hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(256), lds_bytes(128, 128), s, m, n, k, dA,
                          lda, dB, ldb, dC, ldc, acc, nbm, nbn);
@@ -369,6 +562,16 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return launch_mfma<128, 64, false, 4, 7, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case 40:
       return launch_mfma<128, 64, false, 4, 15, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    // and for the 64x64 configuration (one wave per SIMD, 128-deep slices)
+    case 41:
+      return launch_mfma<64, 64, false, 4, 1, true, 2, 2, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 42:
+      return launch_mfma<64, 64, false, 4, 3, true, 2, 2, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 43:
+      return launch_mfma<64, 64, false, 4, 7, true, 2, 2, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case 44:
+      return launch_mfma<64, 64, false, 4, 15, true, 2, 2, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+#endif
     default:
       g_last_error = "unknown kernel variant";
       return MMH_ERR_INVALID_ARG;
@@ -381,9 +584,189 @@ bool is_gfx950(int device) {
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
 }
 
+int create_context(mmh_context **out, int device) {
+  *out = nullptr;
+  int count = 0;
+  mmh_device_count(&count);
+  if (count <= 0 || device < 0 || device >= count) {
+    g_last_error = "no such HIP device";
+    return MMH_ERR_NO_DEVICE;
+  }
+  if (!is_gfx950(device)) {
+    g_last_error = "device is not gfx950 (this library carries gfx950 code objects only)";
+    return MMH_ERR_NO_DEVICE;
+  }
+  DeviceGuard guard;
+  HIP_TRY(guard.enter(device));
+  mmh_context *ctx = new (std::nothrow) mmh_context;
+  if (!ctx) return MMH_ERR_ALLOC;
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+  // the sticky error word: pinned, mapped host memory (the device adds to it with a system-scope atomic)
+  void *host = nullptr, *dev = nullptr;
+  if (hipHostMalloc(&host, 64, hipHostMallocMapped) == hipSuccess) {
+    memset(host, 0, 64);
+    if (hipHostGetDevicePointer(&dev, host, 0) == hipSuccess) {
+      ctx->sticky = static_cast<int *>(host);
+      ctx->sticky_dev = static_cast<int *>(dev);
+    } else {
+      (void)hipHostFree(host);
+    }
+  }
+  (void)hipGetLastError();   // without the word the persistent launches are simply not used
+  *out = ctx;
+  return MMH_OK;
+}
+
+void destroy_context(mmh_context *h) {
+  if (!h) return;
+  DeviceGuard guard;
+  (void)guard.enter(h->device);
+  h->a.release();
+  h->b.release();
+  h->c.release();
+  h->flags.release();
+  h->parts.release();
+  h->bt.release();
+  h->qa.release();
+  h->qb.release();
+  h->qc.release();
+  h->qs.release();
+  if (h->pipeline_ready) {
+    for (int i = 0; i < kMaxHostPanels; ++i) {
+      if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]);
+      if (h->ev_run[i]) (void)hipEventDestroy(h->ev_run[i]);
+    }
+    if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+    if (h->hs_in) (void)hipStreamDestroy(h->hs_in);
+    if (h->hs_run) (void)hipStreamDestroy(h->hs_run);
+    if (h->hs_out) (void)hipStreamDestroy(h->hs_out);
+  }
+  if (h->sticky) (void)hipHostFree(h->sticky);
+  mmh::rocblas_release(h->rocblas);
+  delete h;
+}
+
+// ---- host flavour: row-panel pipeline --------------------------------------------------------
+// The plain form moves A, B (and C when accumulating) in, runs the GEMM, moves C out, one after the
+// other: at N = 4096 that is 5.8 ms of PCIe around a 0.93 ms kernel.  The pipelined form cuts A and C
+// into row panels (mmh_shard_rows' 128-row granularity): after B, panel i's A (and C) go in on the
+// copy-in stream, its GEMM runs on the compute stream as soon as they have landed, and its C rows go
+// out on the copy-out stream -- from a helper thread, because a copy from/to pageable host memory
+// blocks the calling thread -- while panel i+1 is still going in.  Row panels of C depend on nothing
+// but their own rows of A (the same fact the multi-GPU shard rests on), so the bits are those of the
+// single launch.  What is left is the H2D time of A, B (and C): PCIe is the floor of this flavour.
+int ensure_pipeline(mmh_context *h) {
+  if (h->pipeline_ready) return MMH_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&h->hs_in, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&h->hs_run, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&h->hs_out, hipStreamNonBlocking));
+  for (int i = 0; i < kMaxHostPanels; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_run[i], hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
+  h->pipeline_ready = true;
+  return MMH_OK;
+}
+
+int sgemm_host_pipelined(mmh_context *h, int panels, int m, int n, int k, const float *A, int lda, const float *B,
+                         int ldb, float *C, int ldc, int accumulate, float *dA, float *dB, float *dC) {
+  int rc = ensure_pipeline(h);
+  if (rc != MMH_OK) return rc;
+  struct Panel { int row0, rows; };
+  std::vector<Panel> plan;
+  for (int p = 0; p < panels; ++p) {
+    Panel q{0, 0};
+    mmh_shard_rows(m, panels, p, &q.row0, &q.rows);
+    if (q.rows > 0) plan.push_back(q);
+  }
+  const int np = (int)plan.size();
+  // copy-out helper: waits for panel i's GEMM, then moves its C rows to the host.  The events are
+  // reused from call to call, so the helper first waits (mutex + condition variable) until THIS
+  // call has recorded ev_run[i] -- an event still carrying last call's record would read "done".
+  int out_rc = MMH_OK;           // written by the helper only, read after join()
+  std::string out_err;
+  std::atomic<bool> abandon{false};   // set by this thread when a later panel's GEMM will never run
+  std::mutex mu;
+  std::condition_variable cv;
+  int recorded = 0;
+  auto publish = [&](int upto) {
+    { std::lock_guard<std::mutex> lock(mu); recorded = upto; }
+    cv.notify_all();
+  };
+  std::thread out([&] {
+    const bool dev_ok = hipSetDevice(h->device) == hipSuccess;
+    if (!dev_ok) { out_rc = MMH_ERR_HIP; out_err = "hipSetDevice (copy-out thread)"; }
+    for (int i = 0; i < np; ++i) {
+      { std::unique_lock<std::mutex> lock(mu); cv.wait(lock, [&] { return recorded > i; }); }
+      if (out_rc != MMH_OK || abandon.load()) continue;   // keep draining the hand-shake, copy nothing more
+      hipError_t e = hipEventSynchronize(h->ev_run[i]);
+      if (e == hipSuccess)
+        e = hipMemcpy2DAsync(C + (size_t)plan[i].row0 * ldc, (size_t)ldc * 4, dC + (size_t)plan[i].row0 * n,
+                             (size_t)n * 4, (size_t)n * 4, plan[i].rows, hipMemcpyDeviceToHost, h->hs_out);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->hs_out);
+      if (e != hipSuccess) { out_rc = MMH_ERR_HIP; out_err = std::string("copy-out: ") + hipGetErrorString(e); }
+    }
+  });
+  // Every ev_run[i] the helper waits for MUST be recorded, whatever fails in between: on an error the
+  // remaining events are recorded on the (then idle) compute stream so that the helper drains.
+  int issued = 0;
+  auto finish = [&](int code) {
+    if (code != MMH_OK) abandon.store(true);   // the helper must not copy panels whose GEMM never ran
+    for (int i = issued; i < np; ++i) (void)hipEventRecord(h->ev_run[i], h->hs_run);
+    publish(np);
+    out.join();
+    (void)hipStreamSynchronize(h->hs_in);
+    (void)hipStreamSynchronize(h->hs_run);
+    if (code == MMH_OK && out_rc != MMH_OK) {
+      g_last_error = out_err;
+      return out_rc;
+    }
+    return code;
+  };
+#define PIPE_TRY(expr)                                  \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return finish(hip_fail(e_, #expr)); \
+  } while (0)
+  PIPE_TRY(hipMemcpy2DAsync(dB, (size_t)n * 4, B, (size_t)ldb * 4, (size_t)n * 4, k, hipMemcpyHostToDevice, h->hs_in));
+  PIPE_TRY(hipEventRecord(h->ev_b, h->hs_in));
+  PIPE_TRY(hipStreamWaitEvent(h->hs_run, h->ev_b, 0));
+  for (int i = 0; i < np; ++i) {
+    const int r0 = plan[i].row0, rows = plan[i].rows;
+    PIPE_TRY(hipMemcpy2DAsync(dA + (size_t)r0 * k, (size_t)k * 4, A + (size_t)r0 * lda, (size_t)lda * 4, (size_t)k * 4,
+                              rows, hipMemcpyHostToDevice, h->hs_in));
+    if (accumulate)
+      PIPE_TRY(hipMemcpy2DAsync(dC + (size_t)r0 * n, (size_t)n * 4, C + (size_t)r0 * ldc, (size_t)ldc * 4,
+                                (size_t)n * 4, rows, hipMemcpyHostToDevice, h->hs_in));
+    PIPE_TRY(hipEventRecord(h->ev_in[i], h->hs_in));
+    PIPE_TRY(hipStreamWaitEvent(h->hs_run, h->ev_in[i], 0));
+    rc = sgemm_on(h, h->kernel, rows, n, k, dA + (size_t)r0 * k, k, dB, n, dC + (size_t)r0 * n, n, accumulate, h->hs_run);
+    if (rc != MMH_OK) return finish(rc);
+    PIPE_TRY(hipEventRecord(h->ev_run[i], h->hs_run));
+    issued = i + 1;
+    publish(issued);
+  }
+#undef PIPE_TRY
+  return finish(MMH_OK);
+}
+
 }  // namespace
 
 // ===========================================================================
+struct mmh_shard {
+  int ngpus = 0;
+  int kernel = MMH_KERNEL_AUTO;
+  int rccl_ranks = 0;                 // ranks of the communicator (0 when ngpus == 1: no RCCL)
+  std::vector<int> devices;
+  std::vector<mmh_context *> ctx;     // one product handle per device (stream-K workspaces etc.)
+  std::vector<hipStream_t> streams;
+  std::vector<DevBuf> a, b, c;        // per device: A panel, B, C panel
+  std::vector<void *> comms;
+};
+
 extern "C" {
 
 const char *mmh_strerror(int status) {
@@ -403,7 +786,15 @@ const char *mmh_last_error(void) { return g_last_error.c_str(); }
 
 const char *mmh_last_launch(void) { return g_last_launch.c_str(); }
 
-int mmh_version(void) { return 100; }
+int mmh_version(void) { return 200; }
+
+int mmh_is_ab_build(void) {
+#ifdef MMH_AB_BUILD
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 int mmh_device_count(int *count) {
   if (!count) return MMH_ERR_INVALID_ARG;
@@ -429,84 +820,87 @@ int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz) {
 
 int mmh_create(mmh_handle_t *handle, int device) {
   if (!handle) return MMH_ERR_INVALID_ARG;
-  *handle = nullptr;
-  int count = 0;
-  mmh_device_count(&count);
-  if (count <= 0 || device < 0 || device >= count) {
-    g_last_error = "no such HIP device";
-    return MMH_ERR_NO_DEVICE;
-  }
-  if (!is_gfx950(device)) {
-    g_last_error = "device is not gfx950 (this library carries gfx950 code objects only)";
-    return MMH_ERR_NO_DEVICE;
-  }
-  HIP_TRY(hipSetDevice(device));
-  mmh_context *ctx = new (std::nothrow) mmh_context;
-  if (!ctx) return MMH_ERR_ALLOC;
-  ctx->device = device;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
-  *handle = ctx;
-  return MMH_OK;
+  return create_context(handle, device);
 }
 
 int mmh_destroy(mmh_handle_t h) {
-  if (!h) return MMH_OK;
-  (void)hipSetDevice(h->device);
-  h->a.release();
-  h->b.release();
-  h->c.release();
-  h->flags.release();
-  h->parts.release();
-  h->bt.release();
-  h->qa.release();
-  h->qb.release();
-  h->qc.release();
-  h->qs.release();
-  mmh::rocblas_release(h->rocblas);
-  delete h;
+  destroy_context(h);
   return MMH_OK;
 }
 
 int mmh_set_kernel(mmh_handle_t h, int kernel) {
-  if (!h || !mmh_kernel_name(kernel)) return MMH_ERR_INVALID_ARG;
+  if (!h || !known_kernel(kernel)) return MMH_ERR_INVALID_ARG;
   h->kernel = kernel;
   return MMH_OK;
 }
 
 int mmh_set_option(mmh_handle_t h, int option, int value) {
   if (!h) return MMH_ERR_INVALID_ARG;
-  if (option == MMH_OPT_STREAMK) {
-    h->streamk = value ? 1 : 0;
-    return MMH_OK;
+  switch (option) {
+    case MMH_OPT_STREAMK:
+      h->streamk = value ? 1 : 0;
+      return MMH_OK;
+    case MMH_OPT_STREAMK_TIMEOUTS:   // writing 0 clears the sticky error
+      if (value != 0) return MMH_ERR_INVALID_ARG;
+      {
+        DeviceGuard guard;
+        HIP_TRY(guard.enter(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+      }
+      if (h->sticky) *reinterpret_cast<volatile int *>(h->sticky) = 0;
+      return MMH_OK;
+    case MMH_OPT_IGEMM_MODE:
+      if ((value >= 0 && value <= 6)
+#ifdef MMH_AB_BUILD
+          || (value >= 10 && value <= 13)
+#endif
+      ) {
+        h->igemm_mode = value;
+        return MMH_OK;
+      }
+      return MMH_ERR_INVALID_ARG;
+    case MMH_OPT_SPLITK:
+      if (value < 0 || value > 16) return MMH_ERR_INVALID_ARG;
+      h->splitk = value;
+      return MMH_OK;
+    case MMH_OPT_HOST_PANELS:
+      if (value < -1 || value > kMaxHostPanels) return MMH_ERR_INVALID_ARG;
+      h->host_panels = value;
+      return MMH_OK;
+    case MMH_OPT_STREAMK_SPIN_LIMIT:   // in units of 1024 polls
+      if (value < 1) return MMH_ERR_INVALID_ARG;
+      h->spin_limit = (long long)value << 10;
+      return MMH_OK;
+    case MMH_OPT_FAULT_INJECT:
+      h->fault = value ? 1 : 0;
+      return MMH_OK;
+    default:
+      return MMH_ERR_INVALID_ARG;
   }
-  if (option == MMH_OPT_IGEMM_MODE && ((value >= 0 && value <= 6) || (value >= 10 && value <= 13))) {
-    h->igemm_mode = value;
-    return MMH_OK;
-  }
-  return MMH_ERR_INVALID_ARG;
 }
 
 int mmh_get_option(mmh_handle_t h, int option, int *value) {
   if (!h || !value) return MMH_ERR_INVALID_ARG;
-  if (option == MMH_OPT_STREAMK) {
-    *value = h->streamk;
-    return MMH_OK;
+  switch (option) {
+    case MMH_OPT_STREAMK: *value = h->streamk; return MMH_OK;
+    case MMH_OPT_IGEMM_MODE: *value = h->igemm_mode; return MMH_OK;
+    case MMH_OPT_SPLITK: *value = h->splitk; return MMH_OK;
+    case MMH_OPT_HOST_PANELS: *value = h->host_panels; return MMH_OK;
+    case MMH_OPT_STREAMK_SPIN_LIMIT: *value = (int)(h->spin_limit >> 10); return MMH_OK;
+    case MMH_OPT_FAULT_INJECT: *value = h->fault; return MMH_OK;
+    case MMH_OPT_STREAMK_TIMEOUTS: {
+      // synchronises, then reads the sticky word: how many hand-off waits have timed out on this
+      // handle since it was last cleared
+      *value = 0;
+      DeviceGuard guard;
+      HIP_TRY(guard.enter(h->device));
+      HIP_TRY(hipDeviceSynchronize());
+      if (h->sticky) *value = *reinterpret_cast<volatile int *>(h->sticky);
+      return MMH_OK;
+    }
+    default:
+      return MMH_ERR_INVALID_ARG;
   }
-  if (option == MMH_OPT_IGEMM_MODE) {
-    *value = h->igemm_mode;
-    return MMH_OK;
-  }
-  if (option == MMH_OPT_STREAMK_TIMEOUTS) {
-    *value = 0;
-    if (h->flags_tiles < 0 || !h->flags.p) return MMH_OK;
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(value, static_cast<int *>(h->flags.p) + h->flags_tiles, sizeof(int),
-                      hipMemcpyDeviceToHost));
-    return MMH_OK;
-  }
-  return MMH_ERR_INVALID_ARG;
 }
 
 int mmh_get_kernel(mmh_handle_t h, int *kernel) {
@@ -519,6 +913,8 @@ const char *mmh_kernel_name(int kernel) {
   switch (kernel) {
     case MMH_KERNEL_AUTO: return "MMult_hip_auto";
     case MMH_KERNEL_VALU: return "MMult_hip_valu";
+    case MMH_KERNEL_VALU_128X128: return "MMult_hip_valu_128x128";
+    case MMH_KERNEL_VALU_64X64: return "MMult_hip_valu_64x64";
     case MMH_KERNEL_MFMA: return "MMult_hip_mfma";
     case MMH_KERNEL_MFMA_256: return "MMult_hip_mfma256";
     case MMH_KERNEL_NAIVE: return "MMult_hip_naive";
@@ -528,6 +924,9 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_128X64: return "MMult_hip_mfma_128x64";
     case MMH_KERNEL_MFMA_64X64: return "MMult_hip_mfma_64x64";
     case MMH_KERNEL_MFMA_256X256: return "MMult_hip_mfma_256x256";
+    case MMH_KERNEL_MFMA_SPLITK: return "MMult_hip_mfma_splitk";
+    case MMH_KERNEL_MFMA_SPLITK_128X64: return "MMult_hip_mfma_splitk_128x64";
+#ifdef MMH_AB_BUILD
     case 19: return "exp_dma_b";
     case 16: return "cadence_3";
     case 17: return "cadence_4";
@@ -545,6 +944,11 @@ const char *mmh_kernel_name(int kernel) {
     case 38: return "ablate128x64_no_gload_no_ldswrite";
     case 39: return "ablate128x64_no_gload_no_ldswrite_no_barrier";
     case 40: return "ablate128x64_mfma_only";
+    case 41: return "ablate64x64_no_gload";
+    case 42: return "ablate64x64_no_gload_no_ldswrite";
+    case 43: return "ablate64x64_no_gload_no_ldswrite_no_barrier";
+    case 44: return "ablate64x64_mfma_only";
+#endif
     default: return nullptr;
   }
 }
@@ -552,7 +956,7 @@ const char *mmh_kernel_name(int kernel) {
 int mmh_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, const float *dB,
               int ldb, float *dC, int ldc, int accumulate, void *stream) {
   if (!h) return MMH_ERR_INVALID_ARG;
-  HIP_TRY(hipSetDevice(h->device));
+  ENTER(h);
   return sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate,
                   static_cast<hipStream_t>(stream));
 }
@@ -563,7 +967,7 @@ int mmh_sgemm_host(mmh_handle_t h, int m, int n, int k, const float *A, int lda,
   int rc = check_gemm_args(m, n, k, A, lda, B, ldb, C, ldc);
   if (rc != MMH_OK) return rc;
   if (m == 0 || n == 0) return MMH_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  ENTER(h);
   // Device images are dense (lda=k, ldb=n, ldc=n) whatever the host strides.
   const size_t ab = (size_t)m * k * sizeof(float), bb = (size_t)k * n * sizeof(float),
                cb = (size_t)m * n * sizeof(float);
@@ -572,6 +976,16 @@ int mmh_sgemm_host(mmh_handle_t h, int m, int n, int k, const float *A, int lda,
   if ((rc = h->c.reserve(cb)) != MMH_OK) return rc;
   float *dA = static_cast<float *>(h->a.p), *dB = static_cast<float *>(h->b.p),
         *dC = static_cast<float *>(h->c.p);
+  // row-panel pipeline when the problem is large enough for the copies to matter (>= 2 panels of
+  // >= 512 rows and >= 16 MiB moved), unless MMH_OPT_HOST_PANELS says otherwise
+  int panels = h->host_panels;
+  if (panels < 0) {
+    panels = 0;
+    if (k > 0 && m >= 1024 && (ab + bb + cb) >= (16u << 20)) panels = std::min(8, m / 512);
+  }
+  if (panels >= 2 && k > 0 && m >= 2 * 128)
+    return sgemm_host_pipelined(h, std::min(panels, kMaxHostPanels), m, n, k, A, lda, B, ldb, C, ldc, accumulate, dA,
+                                dB, dC);
   if (k > 0) {
     HIP_TRY(hipMemcpy2D(dA, (size_t)k * 4, A, (size_t)lda * 4, (size_t)k * 4, m,
                         hipMemcpyHostToDevice));
@@ -594,7 +1008,7 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
   int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
   if (rc != MMH_OK) return rc;
   if (m == 0 || n == 0) return MMH_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  ENTER(h);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (k == 0) {
     if (!accumulate)
@@ -640,14 +1054,17 @@ int mmh_quantize_sym_s8(mmh_handle_t h, int rows, int cols, const float *dX, int
   if (!h || rows < 0 || cols < 0) return MMH_ERR_INVALID_ARG;
   if (rows == 0 || cols == 0) return MMH_OK;
   if (!dX || !dQ || !d_scale || ldx < cols || ldq < cols) return MMH_ERR_INVALID_ARG;
-  HIP_TRY(hipSetDevice(h->device));
+  ENTER(h);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int rc = h->qs.reserve(64);
+  // qs: [0, 2 AMAX_WORDS) abs-max words of a quantised GEMM's A and B, then its two scales, then the
+  // abs-max words of stand-alone calls
+  constexpr size_t qs_words = 4 * mmh::AMAX_WORDS + 16;
+  int rc = h->qs.reserve(qs_words * sizeof(unsigned));
   if (rc != MMH_OK) return rc;
-  unsigned *amax = static_cast<unsigned *>(h->qs.p) + 8;   // scratch words for stand-alone calls
-  HIP_TRY(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), s));
+  unsigned *amax = static_cast<unsigned *>(h->qs.p) + 2 * mmh::AMAX_WORDS + 16;
+  HIP_TRY(hipMemsetAsync(amax, 0, 2 * mmh::AMAX_WORDS * sizeof(unsigned), s));
   const mmh::QuantTensor t{dX, rows, cols, ldx, dQ, ldq}, none{nullptr, 0, 0, 0, nullptr, 0};
-  const dim3 g(mmh::quant_rows_grid(rows, 0), 1), gmax(mmh::quant_rows_grid(rows, 0, 512), 1);
+  const dim3 g(mmh::quant_rows_grid(rows, 0), 1), gmax(mmh::quant_rows_grid(rows, 0, 2048), 1);
   hipLaunchKernelGGL(mmh::absmax_kernel, gmax, dim3(256), 0, s, t, none, mmh::quant_vec_ok(t, false) ? 1 : 0, 0,
                      amax);
   hipLaunchKernelGGL(mmh::quantize_kernel, g, dim3(256), 0, s, t, none, mmh::quant_vec_ok(t, true) ? 1 : 0, 0, amax,
@@ -662,7 +1079,7 @@ int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
   int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
   if (rc != MMH_OK) return rc;
   if (m == 0 || n == 0) return MMH_OK;
-  HIP_TRY(hipSetDevice(h->device));
+  ENTER(h);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (k == 0) {
     HIP_TRY(hipMemset2DAsync(dC, (size_t)ldc * 4, 0, (size_t)n * 4, (size_t)m, s));
@@ -672,14 +1089,15 @@ int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
   const int ka = (k + 15) & ~15, nb = (n + 3) & ~3;
   if ((rc = h->qa.reserve((size_t)m * ka)) != MMH_OK) return rc;
   if ((rc = h->qb.reserve((size_t)k * nb)) != MMH_OK) return rc;
-  if ((rc = h->qs.reserve(64)) != MMH_OK) return rc;
+  constexpr size_t qs_words = 4 * mmh::AMAX_WORDS + 16;
+  if ((rc = h->qs.reserve(qs_words * sizeof(unsigned))) != MMH_OK) return rc;
   int8_t *qa = static_cast<int8_t *>(h->qa.p), *qb = static_cast<int8_t *>(h->qb.p);
-  unsigned *amax = static_cast<unsigned *>(h->qs.p);        // [0] A, [1] B
-  float *scales = reinterpret_cast<float *>(amax + 2);      // [0] A, [1] B
-  HIP_TRY(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), s));
+  unsigned *amax = static_cast<unsigned *>(h->qs.p);                           // A's words, then B's
+  float *scales = reinterpret_cast<float *>(amax + 2 * mmh::AMAX_WORDS);       // [0] A, [1] B
+  HIP_TRY(hipMemsetAsync(amax, 0, 2 * mmh::AMAX_WORDS * sizeof(unsigned), s));
   // A and B share one abs-max launch and one quantisation launch (blockIdx.y picks the tensor)
   const mmh::QuantTensor ta{dA, m, k, lda, qa, ka}, tb{dB, k, n, ldb, qb, nb};
-  const dim3 g(mmh::quant_rows_grid(m, k), 2), gmax(mmh::quant_rows_grid(m, k, 512), 2);
+  const dim3 g(mmh::quant_rows_grid(m, k), 2), gmax(mmh::quant_rows_grid(m, k, 2048), 2);
   hipLaunchKernelGGL(mmh::absmax_kernel, gmax, dim3(256), 0, s, ta, tb, mmh::quant_vec_ok(ta, false) ? 1 : 0,
                      mmh::quant_vec_ok(tb, false) ? 1 : 0, amax);
   hipLaunchKernelGGL(mmh::quantize_kernel, g, dim3(256), 0, s, ta, tb, mmh::quant_vec_ok(ta, true) ? 1 : 0,
@@ -709,8 +1127,8 @@ int mmh_sgemm_rocblas(mmh_handle_t h, int m, int n, int k, const float *dA, int 
   if (!h) return MMH_ERR_INVALID_ARG;
   int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
   if (rc != MMH_OK) return rc;
+  ENTER(h);
   if (m == 0 || n == 0 || k == 0) return sgemm_on(h, MMH_KERNEL_MFMA, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, static_cast<hipStream_t>(stream));
-  HIP_TRY(hipSetDevice(h->device));
   return mmh::rocblas_sgemm_rowmajor(&h->rocblas, m, n, k, dA, lda, dB, ldb, dC, ldc, stream,
                                      &g_last_error);
 }
@@ -734,30 +1152,240 @@ int mmh_shard_rows(int m, int nranks, int rank, int *row0, int *rows) {
   return MMH_OK;
 }
 
+// ---- single-process row-panel shard: a handle (BASELINE.json config 4) ----------------------------
+int mmh_rccl_version(int *version) {
+  if (!version) return MMH_ERR_INVALID_ARG;
+  *version = 0;
+  mmh::RcclApi &api = mmh::rccl_api();
+  if (!api.ok) {
+    g_last_error = "librccl.so could not be loaded (or lacks an entry point the shard needs)";
+    return MMH_ERR_UNSUPPORTED;
+  }
+  if (api.get_version(version) != 0) return MMH_ERR_COMM;
+  return MMH_OK;
+}
+
+int mmh_shard_destroy(mmh_shard_t sh) {
+  if (!sh) return MMH_OK;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  for (int d = 0; d < (int)sh->devices.size(); ++d) {
+    (void)hipSetDevice(sh->devices[d]);
+    if (d < (int)sh->comms.size() && sh->comms[d]) mmh::rccl_api().comm_destroy(sh->comms[d]);
+    if (d < (int)sh->a.size()) { sh->a[d].release(); sh->b[d].release(); sh->c[d].release(); }
+    if (d < (int)sh->streams.size() && sh->streams[d]) (void)hipStreamDestroy(sh->streams[d]);
+    if (d < (int)sh->ctx.size()) destroy_context(sh->ctx[d]);
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  delete sh;
+  return MMH_OK;
+}
+
+int mmh_shard_create(mmh_shard_t *out, int ngpus, const int *devices) {
+  if (!out) return MMH_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (ngpus <= 0 || ngpus > 64) return MMH_ERR_INVALID_ARG;
+  int count = 0;
+  mmh_device_count(&count);
+  if (count < ngpus) {
+    g_last_error = "fewer visible devices (" + std::to_string(count) + ") than ngpus (" + std::to_string(ngpus) + ")";
+    return MMH_ERR_NO_DEVICE;
+  }
+  if (ngpus > 1 && !mmh::rccl_api().ok) {
+    g_last_error = "librccl.so could not be loaded";
+    return MMH_ERR_UNSUPPORTED;
+  }
+  mmh_shard *sh = new (std::nothrow) mmh_shard;
+  if (!sh) return MMH_ERR_ALLOC;
+  sh->ngpus = ngpus;
+  for (int d = 0; d < ngpus; ++d) {
+    const int dev = devices ? devices[d] : d;
+    if (dev < 0 || dev >= count || std::find(sh->devices.begin(), sh->devices.end(), dev) != sh->devices.end()) {
+      delete sh;
+      g_last_error = "device list names a device twice or out of range";
+      return MMH_ERR_INVALID_ARG;
+    }
+    sh->devices.push_back(dev);
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  sh->ctx.assign(ngpus, nullptr);
+  sh->streams.assign(ngpus, nullptr);
+  sh->a.resize(ngpus);
+  sh->b.resize(ngpus);
+  sh->c.resize(ngpus);
+  sh->comms.assign(ngpus, nullptr);
+  int rc = MMH_OK;
+  for (int d = 0; d < ngpus && rc == MMH_OK; ++d) {
+    rc = create_context(&sh->ctx[d], sh->devices[d]);
+    if (rc != MMH_OK) break;
+    if (hipSetDevice(sh->devices[d]) != hipSuccess || hipStreamCreate(&sh->streams[d]) != hipSuccess) {
+      g_last_error = "hipStreamCreate failed";
+      rc = MMH_ERR_HIP;
+    }
+  }
+  if (rc == MMH_OK && ngpus > 1) {
+    // ONE communicator for the life of the handle (creating it costs far more than any GEMM here)
+    if (mmh::rccl_api().comm_init_all(sh->comms.data(), ngpus, sh->devices.data()) != 0) {
+      g_last_error = "ncclCommInitAll failed";
+      rc = MMH_ERR_COMM;
+    } else {
+      int ranks = 0;
+      if (mmh::rccl_api().comm_count(sh->comms[0], &ranks) == 0) sh->rccl_ranks = ranks;
+    }
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (rc != MMH_OK) {
+    mmh_shard_destroy(sh);
+    return rc;
+  }
+  *out = sh;
+  return MMH_OK;
+}
+
+int mmh_shard_set_kernel(mmh_shard_t sh, int kernel) {
+  if (!sh || !known_kernel(kernel)) return MMH_ERR_INVALID_ARG;
+  sh->kernel = kernel;
+  return MMH_OK;
+}
+
+int mmh_shard_info(mmh_shard_t sh, int *ngpus, int *rccl_ranks) {
+  if (!sh) return MMH_ERR_INVALID_ARG;
+  if (ngpus) *ngpus = sh->ngpus;
+  if (rccl_ranks) *rccl_ranks = sh->rccl_ranks;
+  return MMH_OK;
+}
+
+int mmh_shard_sgemm(mmh_shard_t sh, int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
+                    int ldc, int gemm_reps, float *timings_ms) {
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point t) { return std::chrono::duration<float, std::milli>(clk::now() - t).count(); };
+  if (!sh || gemm_reps < 1) return MMH_ERR_INVALID_ARG;
+  int rc = check_gemm_args(m, n, k, A, lda, B, ldb, C, ldc);
+  if (rc != MMH_OK) return rc;
+  if (timings_ms) timings_ms[0] = timings_ms[1] = timings_ms[2] = timings_ms[3] = 0.f;
+  if (m == 0 || n == 0) return MMH_OK;
+  const int G = sh->ngpus;
+  for (int d = 0; d < G; ++d)
+    if ((rc = check_sticky(sh->ctx[d])) != MMH_OK) return rc;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  struct Restore {
+    int prev;
+    ~Restore() { if (prev >= 0) (void)hipSetDevice(prev); }
+  } restore{prev};
+  std::vector<int> row0(G), rows(G);
+  const size_t kk = k > 0 ? k : 1;
+  for (int d = 0; d < G; ++d) {
+    mmh_shard_rows(m, G, d, &row0[d], &rows[d]);
+    HIP_TRY(hipSetDevice(sh->devices[d]));
+    const size_t r = rows[d] > 0 ? rows[d] : 1;
+    if ((rc = sh->a[d].reserve(r * kk * sizeof(float))) != MMH_OK) return rc;
+    if ((rc = sh->b[d].reserve(kk * n * sizeof(float))) != MMH_OK) return rc;
+    if ((rc = sh->c[d].reserve(r * n * sizeof(float))) != MMH_OK) return rc;
+  }
+  // One host thread per device for the host <-> device phases: a copy from/to pageable memory blocks
+  // its calling thread, and every device has a PCIe link of its own.
+  std::vector<hipError_t> err(G, hipSuccess);
+  auto per_device = [&](auto &&fn) {
+    std::vector<std::thread> pool;
+    for (int d = 0; d < G; ++d)
+      pool.emplace_back([&, d] {
+        hipError_t e = hipSetDevice(sh->devices[d]);
+        if (e == hipSuccess) e = fn(d);
+        if (e == hipSuccess) e = hipStreamSynchronize(sh->streams[d]);
+        err[d] = e;
+      });
+    for (auto &t : pool) t.join();
+    for (int d = 0; d < G; ++d)
+      if (err[d] != hipSuccess) return hip_fail(err[d], "row-panel shard: host <-> device phase");
+    return (int)MMH_OK;
+  };
+  // ---- host -> device: A panels to their owners, B to device 0 only (every device when there is no
+  // communicator, i.e. G == 1) ----
+  auto t = clk::now();
+  if (k > 0) {
+    rc = per_device([&](int d) -> hipError_t {
+      hipError_t e = hipSuccess;
+      if (rows[d] > 0)
+        e = hipMemcpy2DAsync(sh->a[d].p, (size_t)k * 4, A + (size_t)row0[d] * lda, (size_t)lda * 4, (size_t)k * 4,
+                             rows[d], hipMemcpyHostToDevice, sh->streams[d]);
+      if (e == hipSuccess && d == 0)
+        e = hipMemcpy2DAsync(sh->b[0].p, (size_t)n * 4, B, (size_t)ldb * 4, (size_t)n * 4, k, hipMemcpyHostToDevice,
+                             sh->streams[0]);
+      return e;
+    });
+    if (rc != MMH_OK) return rc;
+  }
+  if (timings_ms) timings_ms[0] = ms_since(t);
+  // ---- the one collective: broadcast B from device 0 over xGMI ----
+  t = clk::now();
+  if (G > 1 && k > 0) {
+    mmh::RcclApi &api = mmh::rccl_api();
+    bool bad = api.group_start() != 0;
+    for (int d = 0; d < G && !bad; ++d) {
+      constexpr int nccl_float = 7;
+      bad = api.broadcast(sh->b[0].p, sh->b[d].p, (size_t)k * n, nccl_float, 0, sh->comms[d], sh->streams[d]) != 0;
+    }
+    if (api.group_end() != 0) bad = true;
+    if (bad) {
+      g_last_error = "ncclBroadcast failed";
+      return MMH_ERR_COMM;
+    }
+    for (int d = 0; d < G; ++d) {
+      HIP_TRY(hipSetDevice(sh->devices[d]));
+      HIP_TRY(hipStreamSynchronize(sh->streams[d]));
+    }
+  }
+  if (timings_ms) timings_ms[1] = (G > 1 && k > 0) ? ms_since(t) : 0.f;
+  // ---- independent row-panel GEMMs (gemm_reps back-to-back launches per device: phase time / reps) ----
+  t = clk::now();
+  for (int rep = 0; rep < gemm_reps; ++rep)
+    for (int d = 0; d < G; ++d) {
+      if (rows[d] == 0) continue;
+      HIP_TRY(hipSetDevice(sh->devices[d]));
+      rc = sgemm_on(sh->ctx[d], sh->kernel, rows[d], n, k, static_cast<float *>(sh->a[d].p), k,
+                    static_cast<float *>(sh->b[d].p), n, static_cast<float *>(sh->c[d].p), n, 0, sh->streams[d]);
+      if (rc != MMH_OK) return rc;
+    }
+  for (int d = 0; d < G; ++d) {
+    HIP_TRY(hipSetDevice(sh->devices[d]));
+    HIP_TRY(hipStreamSynchronize(sh->streams[d]));
+  }
+  if (timings_ms) timings_ms[2] = ms_since(t) / gemm_reps;
+  for (int d = 0; d < G; ++d)
+    if ((rc = check_sticky(sh->ctx[d])) != MMH_OK) return rc;
+  // ---- device -> host: disjoint C panels ----
+  t = clk::now();
+  rc = per_device([&](int d) -> hipError_t {
+    if (rows[d] == 0) return hipSuccess;
+    return hipMemcpy2DAsync(C + (size_t)row0[d] * ldc, (size_t)ldc * 4, sh->c[d].p, (size_t)n * 4, (size_t)n * 4,
+                            rows[d], hipMemcpyDeviceToHost, sh->streams[d]);
+  });
+  if (rc != MMH_OK) return rc;
+  if (timings_ms) timings_ms[3] = ms_since(t);
+  return MMH_OK;
+}
+
+// one-shot convenience form: create, run once, destroy (what the round-1 entry point did on every call)
 int mmh_sgemm_sharded(int ngpus, int m, int n, int k, const float *A, int lda, const float *B,
                       int ldb, float *C, int ldc, int kernel, float *timings_ms) {
   int rc = check_gemm_args(m, n, k, A, lda, B, ldb, C, ldc);
   if (rc != MMH_OK) return rc;
-  if (ngpus <= 0 || !mmh_kernel_name(kernel)) return MMH_ERR_INVALID_ARG;
-  int count = 0;
-  mmh_device_count(&count);
-  if (count < ngpus) {
-    g_last_error = "fewer visible devices than ngpus";
-    return MMH_ERR_NO_DEVICE;
-  }
-  return mmh::sgemm_sharded_impl(ngpus, m, n, k, A, lda, B, ldb, C, ldc, kernel, timings_ms,
-                                 &g_last_error,
-                                 [](int kern, int mm, int nn, int kk, const float *a, int la,
-                                    const float *b, int lb, float *c, int lc, hipStream_t s) {
-                                   return sgemm_on(nullptr, kern, mm, nn, kk, a, la, b, lb, c, lc, 0, s);
-                                 });
+  if (ngpus <= 0 || !known_kernel(kernel)) return MMH_ERR_INVALID_ARG;
+  mmh_shard_t sh = nullptr;
+  if ((rc = mmh_shard_create(&sh, ngpus, nullptr)) != MMH_OK) return rc;
+  rc = mmh_shard_set_kernel(sh, kernel);
+  if (rc == MMH_OK) rc = mmh_shard_sgemm(sh, m, n, k, A, lda, B, ldb, C, ldc, 1, timings_ms);
+  mmh_shard_destroy(sh);
+  return rc;
 }
 
 int mmh_time_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, const float *dB,
                    int ldb, float *dC, int ldc, int warmup, int reps, void *stream,
                    float *ms_per_call) {
   if (!h || reps <= 0 || warmup < 0 || !ms_per_call) return MMH_ERR_INVALID_ARG;
-  HIP_TRY(hipSetDevice(h->device));
+  ENTER(h);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc;
   for (int i = 0; i < warmup; ++i)
@@ -775,31 +1403,58 @@ int mmh_time_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda
   (void)hipEventDestroy(t0);
   (void)hipEventDestroy(t1);
   *ms_per_call = ms / reps;
-  return MMH_OK;
+  return check_sticky(h);
+}
+
+// per-launch durations of `count` back-to-back calls (one event pair each): the clock-ramp trace
+int mmh_trace_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
+                    float *dC, int ldc, int count, void *stream, float *ms_each) {
+  if (!h || count <= 0 || count > 4096 || !ms_each) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::vector<hipEvent_t> ev(count + 1);
+  for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+  int rc = MMH_OK;
+  HIP_TRY(hipEventRecord(ev[0], s));
+  for (int i = 0; i < count && rc == MMH_OK; ++i) {
+    rc = sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s);
+    if (rc == MMH_OK && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = MMH_ERR_HIP;
+  }
+  if (rc == MMH_OK && hipEventSynchronize(ev[count]) != hipSuccess) rc = MMH_ERR_HIP;
+  for (int i = 0; i < count && rc == MMH_OK; ++i)
+    if (hipEventElapsedTime(&ms_each[i], ev[i], ev[i + 1]) != hipSuccess) rc = MMH_ERR_HIP;
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  return rc;
 }
 
 int mmh_probe_mfma_f32(mmh_handle_t h, float *tflops) {
   if (!h || !tflops) return MMH_ERR_INVALID_ARG;
-  HIP_TRY(hipSetDevice(h->device));
+  ENTER(h);
   return mmh::probe_mfma_f32(h->cu_count, tflops, &g_last_error);
 }
 
 int mmh_probe_mfma_i8(mmh_handle_t h, float *tops) {
   if (!h || !tops) return MMH_ERR_INVALID_ARG;
-  HIP_TRY(hipSetDevice(h->device));
+  ENTER(h);
   return mmh::probe_mfma_i8(h->cu_count, tops, &g_last_error);
 }
 
 int mmh_probe_mfma_i8_sustained(mmh_handle_t h, int random_operands, float min_ms, float *tops) {
   if (!h || !tops || min_ms < 0.f || min_ms > 2000.f) return MMH_ERR_INVALID_ARG;
-  HIP_TRY(hipSetDevice(h->device));
+  ENTER(h);
   return mmh::probe_mfma_i8(h->cu_count, tops, &g_last_error, random_operands ? 1 : 0, min_ms);
 }
 
 int mmh_probe_hbm_copy(mmh_handle_t h, size_t bytes, float *gbps) {
   if (!h || !gbps || bytes < (1u << 20)) return MMH_ERR_INVALID_ARG;
-  HIP_TRY(hipSetDevice(h->device));
-  return mmh::probe_hbm_copy(bytes, gbps, &g_last_error);
+  ENTER(h);
+  return mmh::probe_hbm_copy(bytes, gbps, &g_last_error, h->cu_count, 0);
+}
+
+int mmh_probe_hbm_read(mmh_handle_t h, size_t bytes, float *gbps) {
+  if (!h || !gbps || bytes < (1u << 20)) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return mmh::probe_hbm_copy(bytes, gbps, &g_last_error, h->cu_count, 1);
 }
 
 }  // extern "C"

@@ -1,5 +1,5 @@
 // probes.hpp -- peak probes and the two vendor-library bridges (rocBLAS
-// comparator, RCCL broadcast for the single-process row-panel shard).
+// comparator; the RCCL entry points the single-process row-panel shard uses).
 //
 // Probes: the reference measures its ceilings before quoting percentages
 // (aarch64/gflops_benchmark/main.c:19-25 -- an FMLA-only loop;
@@ -13,8 +13,6 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
-#include <chrono>
-#include <functional>
 #include <string>
 #include <vector>
 
@@ -167,18 +165,51 @@ inline int probe_mfma_i8(int cu_count, float *tops, std::string *err, int random
 }
 
 // -------------------------------------------------------------- HBM probe --
+// Stream copy with the memory-level parallelism a streaming kernel needs on this part: every thread
+// keeps FOUR 16-byte loads in flight per trip (issued before the first store), non-temporal on both
+// sides (the data is touched once), 8 workgroups per CU.  The guide's reference figure for a float4
+// copy is 6.29 TB/s (MI355X_MICROARCH.md, chip-level parameters); the round-1 form of this probe
+// (one load in flight per thread) read 4.96.
 __global__ void __launch_bounds__(256) probe_copy_kernel(const f32x4 *__restrict__ src,
                                                          f32x4 *__restrict__ dst, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) dst[i] = src[i];
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const f32x4 v0 = __builtin_nontemporal_load(src + i);
+    const f32x4 v1 = __builtin_nontemporal_load(src + i + stride);
+    const f32x4 v2 = __builtin_nontemporal_load(src + i + 2 * stride);
+    const f32x4 v3 = __builtin_nontemporal_load(src + i + 3 * stride);
+    __builtin_nontemporal_store(v0, dst + i);
+    __builtin_nontemporal_store(v1, dst + i + stride);
+    __builtin_nontemporal_store(v2, dst + i + 2 * stride);
+    __builtin_nontemporal_store(v3, dst + i + 3 * stride);
+  }
+  for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
-inline int probe_hbm_copy(size_t bytes, float *gbps, std::string *err) {
+// Read-only twin (what an abs-max style reduction can reach): eight loads in flight per thread.
+__global__ void __launch_bounds__(256) probe_read_kernel(const f32x4 *__restrict__ src, float *__restrict__ out,
+                                                         size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (; i + 7 * stride < n; i += 8 * stride) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[i + j * stride];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; i < n; i += stride) s += src[i];
+  if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];   // keep the loads live
+}
+
+// mode 0: copy (read + write bytes counted); mode 1: read only.
+inline int probe_hbm_copy(size_t bytes, float *gbps, std::string *err, int cu_count = 256, int mode = 0) {
   const size_t n = bytes / sizeof(f32x4);
   f32x4 *src = nullptr, *dst = nullptr;
   MMH_HIP_TRY(hipMalloc(&src, n * sizeof(f32x4)), err);
-  if (hipMalloc(&dst, n * sizeof(f32x4)) != hipSuccess) {
+  if (hipMalloc(&dst, mode == 0 ? n * sizeof(f32x4) : 64) != hipSuccess) {
     (void)hipFree(src);
     if (err) *err = "hipMalloc(dst) failed";
     return MMH_ERR_ALLOC;
@@ -187,16 +218,21 @@ inline int probe_hbm_copy(size_t bytes, float *gbps, std::string *err) {
   hipEvent_t t0, t1;
   MMH_HIP_TRY(hipEventCreate(&t0), err);
   MMH_HIP_TRY(hipEventCreate(&t1), err);
-  const int blocks = 256 * 8, reps = 10;
-  hipLaunchKernelGGL(probe_copy_kernel, dim3(blocks), dim3(256), 0, 0, src, dst, n);
+  if (cu_count <= 0) cu_count = 256;
+  const int blocks = cu_count * 8, reps = 10;
+  auto launch = [&] {
+    if (mode == 0) hipLaunchKernelGGL(probe_copy_kernel, dim3(blocks), dim3(256), 0, 0, src, dst, n);
+    else hipLaunchKernelGGL(probe_read_kernel, dim3(blocks), dim3(256), 0, 0, src, reinterpret_cast<float *>(dst), n);
+  };
+  launch();
+  launch();
   MMH_HIP_TRY(hipEventRecord(t0, 0), err);
-  for (int r = 0; r < reps; ++r)
-    hipLaunchKernelGGL(probe_copy_kernel, dim3(blocks), dim3(256), 0, 0, src, dst, n);
+  for (int r = 0; r < reps; ++r) launch();
   MMH_HIP_TRY(hipEventRecord(t1, 0), err);
   MMH_HIP_TRY(hipEventSynchronize(t1), err);
   float ms = 0.f;
   MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
-  *gbps = (float)(2.0 * n * sizeof(f32x4) * reps / (ms * 1e-3) / 1e9);
+  *gbps = (float)((mode == 0 ? 2.0 : 1.0) * n * sizeof(f32x4) * reps / (ms * 1e-3) / 1e9);
   (void)hipEventDestroy(t0);
   (void)hipEventDestroy(t1);
   (void)hipFree(src);
@@ -265,8 +301,10 @@ inline int rocblas_sgemm_rowmajor(void **handle, int m, int n, int k, const floa
 // ------------------------------------------------------------------- RCCL --
 struct RcclApi {
   void *lib = nullptr;
+  int (*get_version)(int *) = nullptr;
   int (*comm_init_all)(void **, int, const int *) = nullptr;
   int (*comm_destroy)(void *) = nullptr;
+  int (*comm_count)(void *, int *) = nullptr;
   int (*group_start)() = nullptr;
   int (*group_end)() = nullptr;
   int (*broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -277,159 +315,21 @@ inline RcclApi &rccl_api() {
   static RcclApi api = [] {
     RcclApi a;
     a.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!a.lib) a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!a.lib) a.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!a.lib) return a;
+    a.get_version = reinterpret_cast<decltype(a.get_version)>(dlsym(a.lib, "ncclGetVersion"));
     a.comm_init_all = reinterpret_cast<decltype(a.comm_init_all)>(dlsym(a.lib, "ncclCommInitAll"));
     a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(a.lib, "ncclCommDestroy"));
+    a.comm_count = reinterpret_cast<decltype(a.comm_count)>(dlsym(a.lib, "ncclCommCount"));
     a.group_start = reinterpret_cast<decltype(a.group_start)>(dlsym(a.lib, "ncclGroupStart"));
     a.group_end = reinterpret_cast<decltype(a.group_end)>(dlsym(a.lib, "ncclGroupEnd"));
     a.broadcast = reinterpret_cast<decltype(a.broadcast)>(dlsym(a.lib, "ncclBroadcast"));
-    a.ok = a.comm_init_all && a.comm_destroy && a.group_start && a.group_end && a.broadcast;
+    a.ok = a.get_version && a.comm_init_all && a.comm_destroy && a.comm_count && a.group_start && a.group_end &&
+           a.broadcast;
     return a;
   }();
   return api;
-}
-
-using GemmLauncher = std::function<int(int, int, int, int, const float *, int, const float *, int,
-                                       float *, int, hipStream_t)>;
-
-// Single-process, `ngpus`-device row-panel shard (BASELINE.json config 4; no
-// reference analogue -- cuda/test_MMult.cpp:24-25 pins device 0).  Device d
-// owns C rows mmh_shard_rows(m, ngpus, d); A panels go host -> owner, B goes
-// host -> device 0 and then to everyone with ONE ncclBroadcast over xGMI;
-// C row panels are disjoint, so there is no reduction.
-inline int sgemm_sharded_impl(int ngpus, int m, int n, int k, const float *A, int lda,
-                              const float *B, int ldb, float *C, int ldc, int kernel,
-                              float *timings_ms, std::string *err, const GemmLauncher &gemm) {
-  using clk = std::chrono::steady_clock;
-  auto ms_since = [](clk::time_point t) {
-    return std::chrono::duration<float, std::milli>(clk::now() - t).count();
-  };
-  if (timings_ms) timings_ms[0] = timings_ms[1] = timings_ms[2] = timings_ms[3] = 0.f;
-  if (m == 0 || n == 0) return MMH_OK;
-
-  struct Dev {
-    int row0 = 0, rows = 0;
-    float *a = nullptr, *b = nullptr, *c = nullptr;
-    hipStream_t s = nullptr;
-  };
-  std::vector<Dev> dev(ngpus);
-  std::vector<void *> comms(ngpus, nullptr);
-  int rc = MMH_OK;
-  auto cleanup = [&]() {
-    for (int d = 0; d < ngpus; ++d) {
-      (void)hipSetDevice(d);
-      if (dev[d].a) (void)hipFree(dev[d].a);
-      if (dev[d].b) (void)hipFree(dev[d].b);
-      if (dev[d].c) (void)hipFree(dev[d].c);
-      if (dev[d].s) (void)hipStreamDestroy(dev[d].s);
-      if (comms[d]) rccl_api().comm_destroy(comms[d]);
-    }
-  };
-#define SH_TRY(expr)                                                      \
-  do {                                                                    \
-    hipError_t e_ = (expr);                                               \
-    if (e_ != hipSuccess) {                                               \
-      if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_);  \
-      cleanup();                                                          \
-      return MMH_ERR_HIP;                                                 \
-    }                                                                     \
-  } while (0)
-
-  if (ngpus > 1) {
-    if (!rccl_api().ok) {
-      if (err) *err = "librccl.so could not be loaded";
-      return MMH_ERR_UNSUPPORTED;
-    }
-    std::vector<int> ids(ngpus);
-    for (int d = 0; d < ngpus; ++d) ids[d] = d;
-    if (rccl_api().comm_init_all(comms.data(), ngpus, ids.data()) != 0) {
-      if (err) *err = "ncclCommInitAll failed";
-      return MMH_ERR_COMM;
-    }
-  }
-  const size_t kk = k > 0 ? k : 1;
-  for (int d = 0; d < ngpus; ++d) {
-    mmh_shard_rows(m, ngpus, d, &dev[d].row0, &dev[d].rows);
-    SH_TRY(hipSetDevice(d));
-    SH_TRY(hipStreamCreate(&dev[d].s));
-    const size_t rows = dev[d].rows > 0 ? dev[d].rows : 1;
-    SH_TRY(hipMalloc(&dev[d].a, rows * kk * sizeof(float)));
-    SH_TRY(hipMalloc(&dev[d].b, kk * n * sizeof(float)));
-    SH_TRY(hipMalloc(&dev[d].c, rows * n * sizeof(float)));
-  }
-  // ---- host -> device: A panels to their owners, B to device 0 only ----
-  auto t = clk::now();
-  for (int d = 0; d < ngpus && k > 0; ++d) {
-    SH_TRY(hipSetDevice(d));
-    if (dev[d].rows > 0)
-      SH_TRY(hipMemcpy2DAsync(dev[d].a, (size_t)k * 4, A + (size_t)dev[d].row0 * lda,
-                              (size_t)lda * 4, (size_t)k * 4, dev[d].rows, hipMemcpyHostToDevice,
-                              dev[d].s));
-    if (d == 0)
-      SH_TRY(hipMemcpy2DAsync(dev[0].b, (size_t)n * 4, B, (size_t)ldb * 4, (size_t)n * 4, k,
-                              hipMemcpyHostToDevice, dev[0].s));
-  }
-  for (int d = 0; d < ngpus; ++d) {
-    SH_TRY(hipSetDevice(d));
-    SH_TRY(hipStreamSynchronize(dev[d].s));
-  }
-  if (timings_ms) timings_ms[0] = ms_since(t);
-  // ---- the one collective: broadcast B from device 0 over xGMI ----
-  t = clk::now();
-  if (ngpus > 1 && k > 0) {
-    rccl_api().group_start();
-    for (int d = 0; d < ngpus; ++d) {
-      constexpr int nccl_float = 7;
-      if (rccl_api().broadcast(dev[0].b, dev[d].b, (size_t)k * n, nccl_float, 0, comms[d],
-                               dev[d].s) != 0)
-        rc = MMH_ERR_COMM;
-    }
-    if (rccl_api().group_end() != 0) rc = MMH_ERR_COMM;
-    if (rc != MMH_OK) {
-      if (err) *err = "ncclBroadcast failed";
-      cleanup();
-      return rc;
-    }
-    for (int d = 0; d < ngpus; ++d) {
-      SH_TRY(hipSetDevice(d));
-      SH_TRY(hipStreamSynchronize(dev[d].s));
-    }
-  }
-  if (timings_ms) timings_ms[1] = ms_since(t);
-  // ---- independent row-panel GEMMs ----
-  t = clk::now();
-  for (int d = 0; d < ngpus; ++d) {
-    if (dev[d].rows == 0) continue;
-    SH_TRY(hipSetDevice(d));
-    rc = gemm(kernel, dev[d].rows, n, k, dev[d].a, k, dev[d].b, n, dev[d].c, n, dev[d].s);
-    if (rc != MMH_OK) {
-      cleanup();
-      return rc;
-    }
-  }
-  for (int d = 0; d < ngpus; ++d) {
-    SH_TRY(hipSetDevice(d));
-    SH_TRY(hipStreamSynchronize(dev[d].s));
-  }
-  if (timings_ms) timings_ms[2] = ms_since(t);
-  // ---- device -> host: disjoint C panels ----
-  t = clk::now();
-  for (int d = 0; d < ngpus; ++d) {
-    if (dev[d].rows == 0) continue;
-    SH_TRY(hipSetDevice(d));
-    SH_TRY(hipMemcpy2DAsync(C + (size_t)dev[d].row0 * ldc, (size_t)ldc * 4, dev[d].c,
-                            (size_t)n * 4, (size_t)n * 4, dev[d].rows, hipMemcpyDeviceToHost,
-                            dev[d].s));
-  }
-  for (int d = 0; d < ngpus; ++d) {
-    SH_TRY(hipSetDevice(d));
-    SH_TRY(hipStreamSynchronize(dev[d].s));
-  }
-  if (timings_ms) timings_ms[3] = ms_since(t);
-  cleanup();
-#undef SH_TRY
-  return MMH_OK;
 }
 
 }  // namespace mmh

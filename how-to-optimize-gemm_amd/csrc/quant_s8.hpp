@@ -3,11 +3,15 @@
 //
 // Contract (the reference only has prose for this, README.md:71-85 -- chgemm
 // "symmetric quantisation", inputs in [-127,127]; parity unpinned):
-//   scale = 127 / max|x|   (1 if the tensor is all zero)
-//   q     = clamp(rint(x * scale), -127, 127)          round-half-even, never -128
+//   scale = 127 / max|x|   over the FINITE elements (1 if that maximum is 0; clamped to FLT_MAX when
+//                           the maximum is so small -- below ~3.7e-37 -- that the quotient overflows)
+//   q     = clamp(rint(x * scale), -127, 127)          round-half-even, never -128;
+//                           NaN -> 0, +-inf -> +-127 (non-finite inputs never poison the scale)
 //   C_f32 = (float)acc_i32 * (1 / (scale_a * scale_b))
-// The kernels are HBM-bound streaming passes: rows to workgroups, 16-byte loads, one atomic per
-// workgroup for the abs-max; A and B of a quantised GEMM share one launch each.  The dequantisation
+// The kernels are HBM-bound streaming passes: rows to workgroups, 16-byte loads (eight in flight per
+// thread in the abs-max pass), one atomic per workgroup for the abs-max, spread over AMAX_WORDS words
+// per tensor so that thousands of workgroups do not serialise on one; A and B of a quantised GEMM
+// share one launch each.  The dequantisation
 // normally runs inside the int8 GEMM's epilogue (igemm_s8.hpp, `deq`); dequantize_kernel is the
 // stand-alone form.
 #pragma once
@@ -18,6 +22,17 @@ namespace mmh {
 
 typedef float qf32x4 __attribute__((ext_vector_type(4)));
 typedef int qi32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AMAX_WORDS = 64;   // abs-max accumulator words per tensor (reduced by the quantise pass)
+
+// |x| for the abs-max: non-finite elements do not take part (NaN never wins an fmaxf; inf is dropped)
+__device__ __forceinline__ float finite_abs(float x) {
+  const float a = fabsf(x);
+  return a <= 3.402823466e+38f ? a : 0.0f;
+}
+__device__ __forceinline__ float abs4(qf32x4 v) {
+  return fmaxf(fmaxf(finite_abs(v[0]), finite_abs(v[1])), fmaxf(finite_abs(v[2]), finite_abs(v[3])));
+}
 
 // One launch covers up to two tensors (blockIdx.y): A and B of a quantised GEMM.
 struct QuantTensor {
@@ -38,22 +53,22 @@ __global__ void __launch_bounds__(256) absmax_kernel(QuantTensor ta, QuantTensor
   for (int r = blockIdx.x; r < t.rows; r += gridDim.x) {
     const float *row = t.x + (size_t)r * t.ld;
     int c = threadIdx.x;
-    for (; c + 768 < c4; c += 1024) {   // four independent 16-byte loads in flight per thread
-      const qf32x4 v0 = *reinterpret_cast<const qf32x4 *>(row + 4 * c);
-      const qf32x4 v1 = *reinterpret_cast<const qf32x4 *>(row + 4 * (c + 256));
-      const qf32x4 v2 = *reinterpret_cast<const qf32x4 *>(row + 4 * (c + 512));
-      const qf32x4 v3 = *reinterpret_cast<const qf32x4 *>(row + 4 * (c + 768));
-      const qf32x4 a = {fmaxf(fabsf(v0[0]), fabsf(v1[0])), fmaxf(fabsf(v0[1]), fabsf(v1[1])),
-                        fmaxf(fabsf(v0[2]), fabsf(v1[2])), fmaxf(fabsf(v0[3]), fabsf(v1[3]))};
-      const qf32x4 b = {fmaxf(fabsf(v2[0]), fabsf(v3[0])), fmaxf(fabsf(v2[1]), fabsf(v3[1])),
-                        fmaxf(fabsf(v2[2]), fabsf(v3[2])), fmaxf(fabsf(v2[3]), fabsf(v3[3]))};
-      best = fmaxf(best, fmaxf(fmaxf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(fmaxf(a[2], b[2]), fmaxf(a[3], b[3]))));
+    for (; c + 1792 < c4; c += 2048) {   // eight independent 16-byte loads in flight per thread
+      qf32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const qf32x4 *>(row + 4 * (c + 256 * j));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) best = fmaxf(best, abs4(v[j]));
     }
-    for (; c < c4; c += 256) {
-      const qf32x4 v = *reinterpret_cast<const qf32x4 *>(row + 4 * c);
-      best = fmaxf(fmaxf(best, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    for (; c + 768 < c4; c += 1024) {    // four
+      qf32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const qf32x4 *>(row + 4 * (c + 256 * j));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) best = fmaxf(best, abs4(v[j]));
     }
-    for (c = 4 * c4 + threadIdx.x; c < t.cols; c += 256) best = fmaxf(best, fabsf(row[c]));
+    for (; c < c4; c += 256) best = fmaxf(best, abs4(*reinterpret_cast<const qf32x4 *>(row + 4 * c)));
+    for (c = 4 * c4 + threadIdx.x; c < t.cols; c += 256) best = fmaxf(best, finite_abs(row[c]));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_down(best, off, 64));
@@ -62,12 +77,24 @@ __global__ void __launch_bounds__(256) absmax_kernel(QuantTensor ta, QuantTensor
   __syncthreads();
   if (threadIdx.x == 0) {
     best = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-    atomicMax(out_bits + blockIdx.y, __float_as_uint(best));     // non-negative floats order like their bits
+    // non-negative floats order like their bits; AMAX_WORDS words per tensor share the arrivals
+    atomicMax(out_bits + blockIdx.y * AMAX_WORDS + (blockIdx.x % AMAX_WORDS), __float_as_uint(best));
   }
 }
 
+// scale from the AMAX_WORDS partial maxima of tensor `y` (every wave computes it for itself)
+__device__ __forceinline__ float quant_scale(const unsigned *__restrict__ amax_bits, int y) {
+  float amax = __uint_as_float(amax_bits[y * AMAX_WORDS + (threadIdx.x & (AMAX_WORDS - 1))]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  if (!(amax > 0.0f)) return 1.0f;
+  const float s = 127.0f / amax;
+  return s <= 3.402823466e+38f ? s : 3.402823466e+38f;
+}
+
 __device__ __forceinline__ int quantize_one(float x, float scale) {
-  return (int)fminf(fmaxf(rintf(x * scale), -127.0f), 127.0f);
+  const float y = x == x ? x * scale : 0.0f;   // NaN -> 0 (0 * inf cannot occur: scale is finite)
+  return (int)fminf(fmaxf(rintf(y), -127.0f), 127.0f);
 }
 
 // `vec`: additionally q 4-byte aligned and ldq % 4 == 0 -> one dword of four int8 per float4.
@@ -76,8 +103,7 @@ __global__ void __launch_bounds__(256) quantize_kernel(QuantTensor ta, QuantTens
                                                        float *__restrict__ scale_out) {
   const QuantTensor t = blockIdx.y ? tb : ta;
   const bool vec = blockIdx.y ? vec_b : vec_a;
-  const float amax = __uint_as_float(amax_bits[blockIdx.y]);
-  const float scale = amax > 0.0f ? 127.0f / amax : 1.0f;
+  const float scale = quant_scale(amax_bits, blockIdx.y);
   if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[blockIdx.y] = scale;
   const int c4 = vec ? t.cols / 4 : 0;
   for (int r = blockIdx.x; r < t.rows; r += gridDim.x) {
@@ -99,8 +125,8 @@ inline bool quant_vec_ok(const QuantTensor &t, bool with_q) {
          (!with_q || (((reinterpret_cast<uintptr_t>(t.q) & 3) == 0) && (t.ldq % 4 == 0)));
 }
 // workgroups per tensor: enough to fill the chip several times over, never more than rows.  The
-// abs-max pass ends in one atomicMax per workgroup on a single word, and 8192 of those serialise
-// into ~80 us at N = 4096: it runs with `cap` = 512.
+// abs-max pass ends in one atomicMax per workgroup (8192 of them on ONE word serialised into ~80 us
+// at N = 4096; they are spread over AMAX_WORDS words and the pass runs with `cap` = 2048).
 inline unsigned quant_rows_grid(int rows_a, int rows_b, int cap = 4096) {
   const int r = rows_a > rows_b ? rows_a : rows_b;
   return (unsigned)(r < 1 ? 1 : (r < cap ? r : cap));

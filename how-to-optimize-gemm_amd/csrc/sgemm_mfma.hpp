@@ -164,14 +164,26 @@ sgemm_mfma_simple_kernel(int m, int n, int k, const float *__restrict__ A, int l
 // bit-identical to the simple kernel and to the fmaf-chain oracle.
 // ---------------------------------------------------------------------------
 
+// What a split-K finisher adds to its accumulators before it stores the tile (sgemm_mfma_splitk_kernel):
+// `count` dense BM x BN partial tiles, `stride` floats apart, published by `count` arrivals on `*flag`.
+struct SplitFix {
+  const float *parts = nullptr;
+  size_t stride = 0;
+  int count = 0;
+  int *flag = nullptr;
+  int *err = nullptr;
+  long long spin_limit = 0;
+};
+
 template <int BM, int BN, bool EDGE, int SCHED, int ABL, bool BUFLD, int WTN = 4, int WTM = 4, int KB = BK,
-          bool DMAB = false>
+          bool DMAB = false, bool PART_WT = false>
 __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int k,
                                                   const float *__restrict__ A, int lda,
                                                   const float *__restrict__ B, int ldb,
                                                   float *__restrict__ C, int ldc, int tm, int tn,
                                                   int kb, int ke, bool init_from_c,
-                                                  const float *part_in = nullptr, float *part_out = nullptr) {
+                                                  const float *part_in = nullptr, float *part_out = nullptr,
+                                                  const SplitFix fix = SplitFix{}) {
   // One C tile (tm, tn), K-slices [kb, ke) of it.  init_from_c: the accumulators
   // start from C's current value (accumulate mode); the tile is stored at the end.
   // Stream-K (below) splits a tile's chain between two workgroups: the first stores its partial
@@ -436,6 +448,42 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
   if (kt + 1 < ke) { slice(kt, T{}, F{}, F{}); ++kt; }
   if (kt < ke) slice(kt, F{}, F{}, F{});
 
+  // Split-K finisher: the other K ranges of this tile were accumulated by `fix.count` producer
+  // workgroups, each into a dense partial tile of its own; add them in range order (a fixed order:
+  // the result does not depend on who arrives when).  Consumer side of cdna guide G16 / R1: ONE lane
+  // polls the arrival counter relaxed (bounded), ONE agent acquire, barrier, plain loads.
+  if (fix.count > 0) {
+    int bad = 0;
+    if (threadIdx.x == 0) {
+      long long spins = 0;
+      while (__hip_atomic_load(fix.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fix.count) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > fix.spin_limit) { bad = 1; break; }
+      }
+      if (bad) __hip_atomic_fetch_add(fix.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      reinterpret_cast<volatile int *>(lds)[0] = bad;   // every wave is past its last LDS read (the
+    }                                                   // slice loop ends in a barrier)
+    __syncthreads();
+    if (reinterpret_cast<volatile int *>(lds)[0]) return;   // timed out: loud (sticky error), no store
+    for (int p = 0; p < fix.count; ++p) {
+      const float *src = fix.parts + (size_t)p * fix.stride;
+#pragma unroll
+      for (int t = 0; t < WTM; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bfrag_t v = *reinterpret_cast<const bfrag_t *>(src + (size_t)(c_row(t, r) - row0) * BN + (ccol - col0));
+#pragma unroll
+          for (int u = 0; u < WTN; ++u) acc[t][u][r] += v[u];
+        }
+    }
+  }
+
+  // partial tiles published to another workgroup of the same launch go out WRITE-THROUGH (sc1 buffer
+  // stores, cdna guide G16 R1: no release fence, the publisher drains vmcnt and stores a flag)
+  __amdgpu_buffer_rsrc_t rsrc_p;
+  if (PART_WT && part_out)
+    rsrc_p = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, BM * BN * 4, 0x00020000);
 #pragma unroll
   for (int t = 0; t < WTM; ++t)
 #pragma unroll
@@ -445,7 +493,18 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
 #pragma unroll
       for (int u = 0; u < WTN; ++u) v[u] = acc[t][u][r];
       if (part_out) {
-        *reinterpret_cast<bfrag_t *>(part_out + (size_t)(row - row0) * BN + (ccol - col0)) = v;
+        if constexpr (PART_WT) {
+          const uint32_t off = (uint32_t)(((row - row0) * BN + (ccol - col0)) * 4);
+          if constexpr (WTN == 4) {
+            typedef int i32x4_t __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rsrc_p, off, 0, 16);
+          } else {
+            typedef int i32x2_t __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, v), rsrc_p, off, 0, 16);
+          }
+        } else {
+          *reinterpret_cast<bfrag_t *>(part_out + (size_t)(row - row0) * BN + (ccol - col0)) = v;
+        }
       } else if (whole_c) {
         *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + ccol) = v;
       } else if (row < m) {
@@ -501,7 +560,11 @@ __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)
 sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                           const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                           int accumulate, int nbm, int nbn, int *__restrict__ flags,
-                          int *__restrict__ err, float *__restrict__ parts) {
+                          int *__restrict__ err, float *__restrict__ parts, long long spin_limit, int fault) {
+  // err: the handle's STICKY error word (host-mapped): a hand-off wait that runs into `spin_limit`
+  // adds to it and the workgroup stops -- it never continues a chain from a slot that was not
+  // published -- and every later mmh_* call on the handle fails until the word is cleared.
+  // fault != 0 (MMH_OPT_FAULT_INJECT, tests): producers do not publish, so every consumer times out.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nk = (k + KB - 1) / KB;
   const int T = nbm * nbn, G = gridDim.x;
@@ -524,25 +587,34 @@ sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
     tn = in_group / gsize;
   };
   // slices [kb, ke) of tile t.  kb > 0: a later part -- wait for the parts before it.
-  // ke < nk: not the last part -- publish.
-  auto run = [&](int t, int kb, int ke) {
+  // ke < nk: not the last part -- publish.  Returns false when the wait timed out.
+  auto run = [&](int t, int kb, int ke) -> bool {
     int part = 0;                                  // how many ranges begin inside tile t before ours
     if (kb > 0)
       for (int r = q; r > 0 && range_start(r) > (long long)t * nk; --r) ++part;
+    int bad = 0;
     if (kb > 0 && threadIdx.x == 0) {
       long long spins = 0;
       while (__hip_atomic_load(&flags[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < part) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1ll << 26)) {               // ~ seconds: give up loudly rather than hang
-          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > spin_limit) {                // default ~ seconds: give up loudly rather than hang
+          bad = 1;
           break;
         }
       }
+      if (bad) __hip_atomic_fetch_add(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     int tm, tn;
     tile_of(t, tm, tn);
     __syncthreads();   // LDS is reused from segment to segment; orders the loads after the acquire
+    if (kb > 0) {      // (uniform) tell every wave whether the wait succeeded
+      if (threadIdx.x == 0) reinterpret_cast<volatile int *>(lds)[0] = bad;
+      __syncthreads();
+      const int b = reinterpret_cast<volatile int *>(lds)[0];
+      __syncthreads();
+      if (b) return false;
+    }
     // partial tiles live in the workspace, one dense BM x BN slot per range: never in C, so C needs
     // no alignment and tiles that share cache lines at ragged edges never exchange data through them
     const float *part_in = kb > 0 ? parts + (size_t)(q - 1) * BM * BN : nullptr;
@@ -553,22 +625,75 @@ sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
     if (ke < nk) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (threadIdx.x == 0) {
+      if (threadIdx.x == 0 && !fault) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&flags[t], part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    return true;
   };
   if (t_first == t_last) {                         // the whole range lies in one tile
     run(t_first, k_first, k_last_end);
     return;
   }
   const bool first_partial = k_first != 0, last_partial = k_last_end != nk;
-  if (last_partial) run(t_last, 0, k_last_end);                       // 1. head of the last tile
+  if (last_partial && !run(t_last, 0, k_last_end)) return;                // 1. head of the last tile
   for (int t = t_first + (first_partial ? 1 : 0); t <= t_last - (last_partial ? 1 : 0); ++t)
-    run(t, 0, nk);                                                    // 2. whole tiles
-  if (first_partial) run(t_first, k_first, nk);                       // 3. rest of the first tile
+    if (!run(t, 0, nk)) return;                                          // 2. whole tiles
+  if (first_partial) run(t_first, k_first, nk);                           // 3. rest of the first tile
+}
+
+// ---------------------------------------------------------------------------
+// K2s: OPT-IN split-K (MMH_OPT_SPLITK, default off).  Every other kernel in this library keeps the
+// reference's arithmetic -- ONE fp32 chain over ascending k per C element -- and under that contract
+// a tile's K range cannot run in parallel, which leaves shapes with fewer tiles than the chip has
+// workgroup slots (the N < 1920 end of the reference sweep) short of work.  This kernel gives that
+// up on request: the K range of every tile is cut into S parts that run CONCURRENTLY on S
+// workgroups; parts 1..S-1 write their partial tile (write-through) into a workspace and bump the
+// tile's arrival counter, part 0 (which starts from C when accumulating) waits for the counter and
+// adds the partials in part order, then stores C.  The sum is  ((P0 + P1) + P2) + ... : deterministic
+// run to run, NOT bit-equal to the chain -- the reference harness's own tolerance (|diff| <= 0.5,
+// cuda/test_MMult.cpp:123-127; observed diffs vs the unfused loop stay inside 2e-7 k) is what it
+// meets, and what the split-K parity tests assert.
+// Block order: producers first (lower block ids dispatch first), the finishers last, so a finisher
+// never occupies a slot its producers still need; the launcher additionally keeps the grid within
+// what is resident at once.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WTN = 4, int WTM = 4, int KB = BK>
+__global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)
+sgemm_mfma_splitk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
+                         const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                         int accumulate, int nbm, int nbn, int S, int *__restrict__ flags,
+                         int *__restrict__ err, float *__restrict__ parts, long long spin_limit) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nk = (k + KB - 1) / KB;
+  const int T = nbm * nbn;
+  const int lin = blockIdx.x % T;
+  const int s = S - 1 - (int)(blockIdx.x / T);     // part index: S-1 .. 1 producers, 0 the finisher
+  int tm, tn;
+  block_to_tile(lin, T, nbm, nbn, tm, tn);
+  const int t = tm * nbn + tn;
+  const int kb = (int)((long long)nk * s / S), ke = (int)((long long)nk * (s + 1) / S);
+  if (s > 0) {
+    float *part_out = parts + ((size_t)(s - 1) * T + t) * BM * BN;
+    mfma_tile_segment<BM, BN, false, 4, 0, true, WTN, WTM, KB, false, true>(lds, m, n, k, A, lda, B, ldb, C, ldc,
+                                                                            tm, tn, kb, ke, false, nullptr, part_out);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave drains (G16 R1)
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_fetch_add(&flags[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  SplitFix fix;
+  fix.parts = parts + (size_t)t * BM * BN;
+  fix.stride = (size_t)T * BM * BN;
+  fix.count = S - 1;
+  fix.flag = flags + t;
+  fix.err = err;
+  fix.spin_limit = spin_limit;
+  mfma_tile_segment<BM, BN, false, 4, 0, true, WTN, WTM, KB>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke,
+                                                             accumulate != 0, nullptr, nullptr, fix);
 }
 
 }  // namespace mmh

@@ -19,13 +19,20 @@
 
 namespace mmh {
 
-template <bool EDGE>
+// Two tile configurations of the one template: <128,128,32> (8x8 outputs per thread: the rung
+// BASELINE config 2 names) and <64,64,64> (4x4 per thread, 64-deep K-slices) for shapes with fewer
+// 128x128 tiles than CUs -- N = 1024 has 64 of them for 256 CUs; the small tile fills the chip at
+// the price of twice the LDS reads per FMA.  Same chain per element, same bits.
+template <int BM, int BN, int KB, bool EDGE>
 __global__ void __launch_bounds__(256)
 sgemm_valu_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                   const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                   int accumulate, int nbm, int nbn) {
-  constexpr int BM = 128, BN = 128, THREADS = 256;
-  constexpr int A_FLOATS = BK * BM, B_FLOATS = BK * BN;
+  constexpr int THREADS = 256;
+  constexpr int RI = BM / 64, RJ = BN / 64;        // 4x4 output blocks per thread, 64 apart
+  constexpr int TI = 4 * RI, TJ = 4 * RJ;
+  constexpr int A_FLOATS = KB * BM, B_FLOATS = KB * BN;
+  static_assert((BM == 64 || BM == 128) && (BN == 64 || BN == 128), "thread map: 16 x 16 threads of 4x4 blocks");
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   int tm, tn;
@@ -34,19 +41,19 @@ sgemm_valu_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
 
-  float acc[8][8];
+  float acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < TJ; ++j) {
       const int row = row0 + 4 * ty + (i & 3) + 64 * (i >> 2);
       const int col = col0 + 4 * tx + (j & 3) + 64 * (j >> 2);
       acc[i][j] = (accumulate && (!EDGE || (row < m && col < n)))
                       ? C[(size_t)row * ldc + col] : 0.0f;
     }
 
-  Stage<BM, BN, THREADS> st;
-  const int nk = (k + BK - 1) / BK;
+  Stage<BM, BN, THREADS, false, false, KB> st;
+  const int nk = (k + KB - 1) / KB;
   if (nk > 0) {
     if (EDGE) st.load_edge(A, lda, B, ldb, row0, col0, 0, m, n, k, tid);
     else      st.load(A, lda, B, ldb, row0, col0, 0, tid);
@@ -58,24 +65,29 @@ sgemm_valu_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
-      if (EDGE) st.load_edge(A, lda, B, ldb, row0, col0, (kt + 1) * BK, m, n, k, tid);
-      else      st.load(A, lda, B, ldb, row0, col0, (kt + 1) * BK, tid);
+      if (EDGE) st.load_edge(A, lda, B, ldb, row0, col0, (kt + 1) * KB, m, n, k, tid);
+      else      st.load(A, lda, B, ldb, row0, col0, (kt + 1) * KB, tid);
     }
     const float *As = lds + cur * (A_FLOATS + B_FLOATS);
     const float *Bs = As + A_FLOATS;
 #pragma unroll 4
-    for (int kk = 0; kk < BK; ++kk) {
+    for (int kk = 0; kk < KB; ++kk) {
       const int g = swz_slot(kk >> 2);
-      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(As + kk * BM + 4 * (ty ^ g));
-      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(As + kk * BM + 4 * ((ty + 16) ^ g));
-      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Bs + kk * BN + 4 * tx);
-      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(Bs + kk * BN + 64 + 4 * tx);
-      const float a[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      const float b[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      float a[TI], b[TJ];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int h = 0; h < RI; ++h) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(As + kk * BM + 4 * ((ty + 16 * h) ^ g));
+        a[4 * h] = v[0]; a[4 * h + 1] = v[1]; a[4 * h + 2] = v[2]; a[4 * h + 3] = v[3];
+      }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_fmaf(a[i], b[j], acc[i][j]);
+      for (int h = 0; h < RJ; ++h) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(Bs + kk * BN + 64 * h + 4 * tx);
+        b[4 * h] = v[0]; b[4 * h + 1] = v[1]; b[4 * h + 2] = v[2]; b[4 * h + 3] = v[3];
+      }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_fmaf(a[i], b[j], acc[i][j]);
     }
     if (more) {
       float *nxt = lds + (cur ^ 1) * (A_FLOATS + B_FLOATS);
@@ -86,10 +98,10 @@ sgemm_valu_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   }
 
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < TI; ++i) {
     const int row = row0 + 4 * ty + (i & 3) + 64 * (i >> 2);
 #pragma unroll
-    for (int jh = 0; jh < 2; ++jh) {
+    for (int jh = 0; jh < RJ; ++jh) {
       const int col = col0 + 4 * tx + 64 * jh;
       if (!EDGE) {
         f32x4 v = {acc[i][4 * jh], acc[i][4 * jh + 1], acc[i][4 * jh + 2], acc[i][4 * jh + 3]};

@@ -13,7 +13,8 @@
 //
 // Kernel variant: environment variable MMULT_KERNEL = auto (default) | mfma | mfma256 |
 // mfma_256x256 | mfma_128x64 | mfma_64x64 | mfma_pipe | mfma_simple | valu | naive (the run-time form of the reference's
-// `NEW := MMult_xxx`, cuda/makefile:3).
+// `NEW := MMult_xxx`, cuda/makefile:3).  MMULT_HOST_PANELS = -1 (default, automatic) | 0 (plain staged
+// form) | 2..16: row panels of mmh_sgemm_host's copy/compute pipeline.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +29,8 @@ int kernel_from_env() {
   struct { const char *name; int id; } table[] = {
       {"mfma", MMH_KERNEL_MFMA}, {"mfma256", MMH_KERNEL_MFMA_256}, {"mfma_64x64", MMH_KERNEL_MFMA_64X64}, {"mfma_256x256", MMH_KERNEL_MFMA_256X256}, {"mfma_128x64", MMH_KERNEL_MFMA_128X64}, {"mfma_pipe", MMH_KERNEL_MFMA_PIPE},
       {"mfma_simple", MMH_KERNEL_MFMA_SIMPLE}, {"valu", MMH_KERNEL_VALU}, {"naive", MMH_KERNEL_NAIVE},
+      {"valu_128x128", MMH_KERNEL_VALU_128X128}, {"valu_64x64", MMH_KERNEL_VALU_64X64}, {"mfma_tiles", MMH_KERNEL_MFMA_TILES},
+      {"mfma_splitk", MMH_KERNEL_MFMA_SPLITK}, {"mfma_splitk_128x64", MMH_KERNEL_MFMA_SPLITK_128X64},
       {"auto", MMH_KERNEL_AUTO}};
   for (auto &t : table)
     if (!std::strcmp(e, t.name)) return t.id;
@@ -49,6 +52,10 @@ mmh_handle_t default_handle() {
     if (st != MMH_OK) die(st, "mmh_create");
     st = mmh_set_kernel(hh, kernel_from_env());
     if (st != MMH_OK) die(st, "mmh_set_kernel");
+    if (const char *e = std::getenv("MMULT_HOST_PANELS")) {   // row panels of the copy/compute pipeline
+      st = mmh_set_option(hh, MMH_OPT_HOST_PANELS, std::atoi(e));
+      if (st != MMH_OK) die(st, "mmh_set_option(MMH_OPT_HOST_PANELS)");
+    }
     return hh;
   }();
   return h;

@@ -18,18 +18,25 @@
 // (environment variable NAME or --NAME=value), defaults from parameters.h:
 //
 //   PFIRST PLAST PINC M N K NREPEATS LDA LDB LDC   sweep shape
-//   KERNEL=auto|mfma|mfma256|mfma_256x256|mfma_128x64|mfma_64x64|mfma_pipe|mfma_simple|valu|naive|rocblas
+//   KERNEL=auto|mfma|mfma256|mfma_256x256|mfma_128x64|mfma_64x64|mfma_pipe|mfma_simple|valu|valu_128x128|
+//          valu_64x64|naive|rocblas|mfma_splitk|mfma_splitk_128x64   (the last two: opt-in split-K)
+//   SPLITK=<n>                 MMH_OPT_SPLITK for KERNEL=auto (0 off, 1 auto, 2..16 parts)
 //   FLAVOUR=device|host|cpu|sharded
 //                                device: C=A*B on device pointers (cuda/ flavour)
 //                                host  : MY_MMult(m,n,k,a,lda,...) on host pointers, C+=A*B,
 //                                        best-of-NREPEATS with dclock (armv7/aarch64 flavour)
 //                                cpu   : MY_MMult := the serial triple loop, no GPU at all
 //                                        (BASELINE.json config 1, plumbing check: diff = 0)
-//                                sharded: C row panels over NGPUS devices of this process, B by
-//                                        one ncclBroadcast (BASELINE.json config 4); GFLOPS from
-//                                        the GEMM phase, EXTENDED adds h2d/bcast/gemm/d2h ms
+//                                sharded: C row panels over NGPUS devices of this process (ONE shard
+//                                        handle for the whole sweep: communicator, streams and
+//                                        buffers persist), B by one ncclBroadcast (BASELINE.json
+//                                        config 4); GFLOPS from the GEMM phase (NREPEATS launches
+//                                        per device), EXTENDED adds h2d/bcast/gemm/d2h ms
 //   INPUT=drand48|seed:<n>|mod3|mod2|ones           (cuda/random_matrix.cpp:9-15 variants)
-//   REF=threads|serial|skip    how cref is produced (skip: diff column is -1)
+//   REF=threads|serial|blas|skip  how cref is produced: the triple loop split over host threads
+//                                (default), the literal serial loop, the host BLAS's cblas_sgemm
+//                                (the cuda directory's oracle, cuda/REF_MMult.cpp:9-13), or not at
+//                                all (diff column is -1)
 //   WARMUP=<n>                 untimed launches before the timed loop (reference: 0)
 //   EXTENDED=1                 extra columns: pct_of_fp32_mfma_peak ref_gflops ref_cores
 #include <algorithm>
@@ -54,7 +61,7 @@ struct Options {
   int m = sweep_defaults::kM, n = sweep_defaults::kN, k = sweep_defaults::kK;
   int nrepeats = sweep_defaults::kRepeats;
   int lda = sweep_defaults::kLda, ldb = sweep_defaults::kLdb, ldc = sweep_defaults::kLdc;
-  int warmup = 0, extended = 0, ngpus = 1;
+  int warmup = 0, extended = 0, ngpus = 1, splitk = 0;
   std::string kernel = "auto", flavour = "device", input = "drand48", ref = "threads";
 };
 
@@ -81,6 +88,11 @@ int kernel_id(const std::string &s) {
   if (s == "mfma_pipe") return MMH_KERNEL_MFMA_PIPE;
   if (s == "mfma_simple") return MMH_KERNEL_MFMA_SIMPLE;
   if (s == "valu") return MMH_KERNEL_VALU;
+  if (s == "valu_128x128") return MMH_KERNEL_VALU_128X128;
+  if (s == "valu_64x64") return MMH_KERNEL_VALU_64X64;
+  if (s == "mfma_splitk") return MMH_KERNEL_MFMA_SPLITK;
+  if (s == "mfma_splitk_128x64") return MMH_KERNEL_MFMA_SPLITK_128X64;
+  if (s == "mfma_tiles") return MMH_KERNEL_MFMA_TILES;
   if (s == "naive") return MMH_KERNEL_NAIVE;
   if (s == "rocblas") return -100;
   std::fprintf(stderr, "unknown KERNEL=%s\n", s.c_str());
@@ -108,6 +120,7 @@ int main(int argc, char **argv) {
   opt_int(argc, argv, "LDC", o.ldc);        opt_int(argc, argv, "WARMUP", o.warmup);
   opt_int(argc, argv, "EXTENDED", o.extended);
   opt_int(argc, argv, "NGPUS", o.ngpus);
+  opt_int(argc, argv, "SPLITK", o.splitk);
   opt_str(argc, argv, "KERNEL", o.kernel);  opt_str(argc, argv, "FLAVOUR", o.flavour);
   opt_str(argc, argv, "INPUT", o.input);    opt_str(argc, argv, "REF", o.ref);
   if (o.pinc <= 0 || o.nrepeats <= 0) { std::fprintf(stderr, "bad PINC/NREPEATS\n"); return 2; }
@@ -117,6 +130,7 @@ int main(int argc, char **argv) {
   const bool host_flavour = o.flavour == "host";
   const bool sharded = o.flavour == "sharded";
   mmh_handle_t handle = nullptr;
+  mmh_shard_t shard = nullptr;
   hipEvent_t start{}, stop{};
   const int kid = kernel_id(o.kernel);
   if (!cpu_only) {
@@ -126,6 +140,12 @@ int main(int argc, char **argv) {
     MMH_CHECK(mmh_device_info(0, name, &cus, &mhz));
     std::printf("GPU Device %d: \"%s\" with %d CUs @ %d MHz\n\n", 0, name, cus, mhz);
     if (kid >= 0) MMH_CHECK(mmh_set_kernel(handle, kid));
+    if (o.splitk) MMH_CHECK(mmh_set_option(handle, MMH_OPT_SPLITK, o.splitk));
+    if (sharded) {
+      // fails (MMH_ERR_NO_DEVICE) when fewer than NGPUS devices are visible: never fewer, silently
+      MMH_CHECK(mmh_shard_create(&shard, o.ngpus, nullptr));
+      MMH_CHECK(mmh_shard_set_kernel(shard, kid >= 0 ? kid : MMH_KERNEL_AUTO));
+    }
     if (host_flavour) setenv("MMULT_KERNEL", o.kernel.c_str(), 1);
     HIP_CHECK(hipEventCreate(&start));
     HIP_CHECK(hipEventCreate(&stop));
@@ -162,6 +182,12 @@ int main(int argc, char **argv) {
       if (o.ref == "serial") {
         REF_MMult_serial(m, n, k, a.data(), lda, b.data(), ldb, cref.data(), ldc);
         ref_cores = 1;
+      } else if (o.ref == "blas") {
+        if (!REF_MMult_blas(m, n, k, a.data(), lda, b.data(), ldb, cref.data(), ldc)) {
+          std::fprintf(stderr, "REF=blas: no host BLAS with cblas_sgemm could be loaded (set MMULT_BLAS_LIB)\n");
+          return 2;
+        }
+        ref_cores = REF_MMult_threads();   // the BLAS's own threading; an upper bound
       } else {
         REF_MMult(m, n, k, a.data(), lda, b.data(), ldb, cref.data(), ldc);
         ref_cores = REF_MMult_threads();
@@ -172,14 +198,12 @@ int main(int argc, char **argv) {
     double seconds = 0.0;
     float phase_ms[4] = {0, 0, 0, 0};
     if (sharded) {
-      double best = 0.0;
-      for (int rep = 0; rep < o.nrepeats + o.warmup; ++rep) {
-        float t[4];
-        MMH_CHECK(mmh_sgemm_sharded(o.ngpus, m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc,
-                                    kid >= 0 ? kid : MMH_KERNEL_AUTO, t));
-        if (rep == 0 || t[2] < best) { best = t[2]; std::copy(t, t + 4, phase_ms); }
-      }
-      seconds = best * 1e-3;
+      // one call = h2d, ONE broadcast, NREPEATS back-to-back GEMM launches per device, d2h; the GEMM
+      // phase is reported per launch (the reference times NREPEATS launches, cuda/test_MMult.cpp:98-118)
+      for (int rep = 0; rep < o.warmup; ++rep)
+        MMH_CHECK(mmh_shard_sgemm(shard, m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc, 1, nullptr));
+      MMH_CHECK(mmh_shard_sgemm(shard, m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc, o.nrepeats, phase_ms));
+      seconds = phase_ms[2] * 1e-3;
     } else if (cpu_only) {
       double best = 0.0;
       for (int rep = 0; rep < o.nrepeats; ++rep) {
@@ -249,6 +273,7 @@ int main(int argc, char **argv) {
     std::fflush(stdout);
   }
 
+  if (shard) MMH_CHECK(mmh_shard_destroy(shard));
   if (handle) MMH_CHECK(mmh_destroy(handle));
   std::printf("];\n");
   return 0;

@@ -1,12 +1,15 @@
 // utils.cpp -- see utils.h.  Compiled with -ffp-contract=off (makefile).
 #include "utils.h"
 
+#include <dlfcn.h>
+#include <glob.h>
 #include <sys/time.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -53,6 +56,74 @@ void REF_MMult_serial(int m, int n, int k, float *a, int lda, float *b, int ldb,
       for (int p = 0; p < k; ++p) *cij = *cij + a[(size_t)i * lda + p] * b[(size_t)p * ldb + j];
     }
 }
+
+namespace {
+
+// cblas_sgemm with 32-bit and with 64-bit (ILP64 builds: numpy's bundled OpenBLAS) integer arguments
+using sgemm32_t = void (*)(int, int, int, int, int, int, float, const float *, int, const float *, int, float,
+                           float *, int);
+using sgemm64_t = void (*)(int, int, int, long long, long long, long long, float, const float *, long long,
+                           const float *, long long, float, float *, long long);
+struct HostBlas {
+  void *lib = nullptr;
+  sgemm32_t f32 = nullptr;
+  sgemm64_t f64 = nullptr;
+  std::string path;
+};
+
+bool try_blas(HostBlas &hb, const char *path) {
+  void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!lib) return false;
+  for (const char *sym : {"cblas_sgemm", "scipy_cblas_sgemm"})
+    if (void *p = dlsym(lib, sym)) {
+      hb.lib = lib, hb.f32 = reinterpret_cast<sgemm32_t>(p), hb.path = path;
+      return true;
+    }
+  for (const char *sym : {"cblas_sgemm64_", "scipy_cblas_sgemm64_"})
+    if (void *p = dlsym(lib, sym)) {
+      hb.lib = lib, hb.f64 = reinterpret_cast<sgemm64_t>(p), hb.path = path;
+      return true;
+    }
+  dlclose(lib);
+  return false;
+}
+
+HostBlas &host_blas() {
+  static HostBlas hb = [] {
+    HostBlas h;
+    if (const char *e = std::getenv("MMULT_BLAS_LIB"))
+      if (*e && try_blas(h, e)) return h;
+    for (const char *name : {"libopenblas.so.0", "libopenblas.so", "libmkl_rt.so.2", "libmkl_rt.so.1", "libmkl_rt.so",
+                             "libblis.so"})
+      if (try_blas(h, name)) return h;
+    for (const char *pat : {"/usr/local/lib/python3*/dist-packages/scipy.libs/libscipy_openblas*.so",
+                            "/usr/local/lib/python3*/dist-packages/numpy.libs/libscipy_openblas*.so",
+                            "/usr/lib/python3*/site-packages/scipy.libs/libscipy_openblas*.so",
+                            "/usr/lib/python3/dist-packages/numpy.libs/libscipy_openblas*.so",
+                            "/opt/conda/lib/libmkl_rt.so*", "/opt/conda/lib/libopenblas*.so*"}) {
+      glob_t g{};
+      if (glob(pat, 0, nullptr, &g) == 0)
+        for (size_t i = 0; i < g.gl_pathc && !h.lib; ++i) try_blas(h, g.gl_pathv[i]);
+      globfree(&g);
+      if (h.lib) return h;
+    }
+    return h;
+  }();
+  return hb;
+}
+
+}  // namespace
+
+bool REF_MMult_blas(int m, int n, int k, float *a, int lda, float *b, int ldb, float *c, int ldc) {
+  HostBlas &hb = host_blas();
+  constexpr int row_major = 101, no_trans = 111;   // CblasRowMajor, CblasNoTrans
+  if (hb.f32) hb.f32(row_major, no_trans, no_trans, m, n, k, 1.0f, a, lda, b, ldb, 0.0f, c, ldc);
+  else if (hb.f64) hb.f64(row_major, no_trans, no_trans, m, n, k, 1.0f, a, lda, b, ldb, 0.0f, c, ldc);
+  else return false;
+  return true;
+}
+
+const char *REF_MMult_blas_library() { return host_blas().path.c_str(); }
 
 float compare_matrices(int m, int n, float *a, int lda, float *b, int ldb) {
   float worst = 0.0f;

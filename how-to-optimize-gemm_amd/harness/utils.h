@@ -13,6 +13,16 @@ void REF_MMult(int m, int n, int k, float *a, int lda, float *b, int ldb, float 
 // Serial, literal triple loop (what is timed as the 1-core CPU baseline).
 void REF_MMult_serial(int m, int n, int k, float *a, int lda, float *b, int ldb, float *c, int ldc);
 int REF_MMult_threads();
+// The cuda directory's oracle (cuda/REF_MMult.cpp:9-13): C = A*B by a host BLAS,
+//   cblas_sgemm(CblasRowMajor, CblasNoTrans, CblasNoTrans, m, n, k, 1.0f, a, lda, b, ldb, 0.0f, c, ldc)
+// -- a blocked, FMA, multi-threaded summation order, which is what the published diff columns
+// (cuda/output_MMult_cuda_12.m:5-29: 7.2e-5 at 1024 ... 3.5e-4 at 4096) are measured against.
+// The reference links -lopenblas (cuda/makefile:16); no cblas.h exists in this image, so the symbol
+// is looked up at run time (dlopen) with a hand-declared prototype: $MMULT_BLAS_LIB if set, else
+// libopenblas / libmkl_rt on the loader path, else the OpenBLAS bundled with numpy / scipy.
+// Returns false (and leaves c alone) when no BLAS with a cblas_sgemm could be loaded.
+bool REF_MMult_blas(int m, int n, int k, float *a, int lda, float *b, int ldb, float *c, int ldc);
+const char *REF_MMult_blas_library();   // path of the library that was loaded ("" if none)
 
 // max |a - b| over an m x n window; prints the first element whose running max
 // exceeds 0.5 once (cuda/compare_matrices.cpp:7-30).

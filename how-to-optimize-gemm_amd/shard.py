@@ -58,11 +58,17 @@ class RowPanelShard:
             C  = A[:, k0:k1] @ B[k0:k1]        (first chunk, overwrite)
             C += A[:, k1:k2] @ B[k1:k2] ...    (accumulate: C's value continues each chain)
         Every C element is still one chain over ascending k, so the result is
-        bit-identical to broadcast-then-GEMM.  `gemm(a, b, out, accumulate)`."""
+        bit-identical to broadcast-then-GEMM.  `gemm(a, b, out, accumulate)`.
+        Chunks are whole 32-deep K-slices, so `chunks` larger than k/32 is reduced to that; k == 0
+        is the empty contraction -- one overwrite call, which zeroes C exactly as mmh_sgemm does."""
         import torch.distributed as dist
         step = -(-self.k // max(chunks, 1))
         step = max(32, (step + 31) // 32 * 32)             # whole K-slices per chunk
         bounds = [(k0, min(k0 + step, self.k)) for k0 in range(0, self.k, step)]
+        if not bounds:                                     # k == 0: nothing to broadcast, C = 0
+            if self.rows:
+                gemm(a_panel, b, c_panel, False)
+            return c_panel
         works = []
         if self.world > 1 or always:
             works = [dist.broadcast(b[k0:k1], src=src, async_op=True) for (k0, k1) in bounds]

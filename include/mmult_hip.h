@@ -25,7 +25,7 @@
  *                     (cuda/test_MMult.cpp:43-44,142).
  *   mmh_set_kernel    the makefile's `NEW := MMult_cuda_N` selection
  *                     (cuda/makefile:1-3,25), as a run-time switch.
- *   mmh_shard_rows / mmh_sgemm_sharded
+ *   mmh_shard_rows / mmh_shard_create, _sgemm, _destroy / mmh_sgemm_sharded
  *                     no reference analogue (single device only,
  *                     cuda/test_MMult.cpp:24-25); BASELINE.json config 4.
  *   mmh_igemm_s8      no reference code (aarch64-int8/ is an empty submodule,
@@ -61,7 +61,10 @@ typedef struct mmh_context *mmh_handle_t;
 
 /* kernel variants (the reference's "NEW := MMult_xxx" ladder, MI355X edition) */
 #define MMH_KERNEL_AUTO 0        /* 64x64 / 128x64 / 128x128 / 256x256 tiles chosen by how the shape fills the chip */
-#define MMH_KERNEL_VALU 1        /* K1: LDS-tiled 128x128, 8x8 per thread, VALU fma only   */
+#define MMH_KERNEL_VALU 1        /* K1: LDS-tiled, VALU fma only: 128x128 tile (8x8 per thread) from one
+                                    tile per CU up, the 64x64 tile (4x4 per thread) below         */
+#define MMH_KERNEL_VALU_128X128 13 /* K1 with the 128x128 tile always (the rung BASELINE config 2 names) */
+#define MMH_KERNEL_VALU_64X64 14   /* K1 with the 64x64 tile always                                      */
 #define MMH_KERNEL_MFMA 2        /* K2: 128x128 block tile on v_mfma_f32_16x16x4_f32; K-slice
                                     hand-over pipelined across the barrier, staging ops dealt
                                     out between MFMAs, buffer-descriptor loads; tile counts
@@ -76,10 +79,18 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_128X64 8 /* K2 with a 128x64 block tile, 4 waves of 64x32                   */
 #define MMH_KERNEL_MFMA_256X256 12 /* K2 with a 256x256 block tile, 8 waves of 128x64 (1 WG/CU)       */
 #define MMH_KERNEL_MFMA_64X64 11 /* K2 with a 64x64 block tile, 4 waves of 32x32, 128-deep K-slices  */
-/* ids 16-19 are A/B builds of K2 with valid results (staging cadence 3/4/1 MFMAs per op; 19 =
- * B staged by LDS-DMA, buffer_load ... lds); ids 21-24 (256x256 tile), 32-35 (128x128) and 36-40
- * (128x64) are timing-only ablation builds whose results are INVALID.  See
- * profiles/r01_ablation.md, tools/ab_bench.py. */
+/* OPT-IN split-K (sgemm_mfma.hpp K2s): the K range of every tile runs as S concurrent parts whose
+ * partial tiles are summed in part order.  Deterministic, inside the reference harness's tolerance,
+ * but NOT the one-chain-per-element bits every other variant returns; never chosen unless asked for
+ * (these ids, or MMH_OPT_SPLITK with MMH_KERNEL_AUTO).  Whole-tile, 16-byte-aligned shapes only,
+ * anything else runs the chain kernels. */
+#define MMH_KERNEL_MFMA_SPLITK 15        /* 128x128 tiles, MMH_OPT_SPLITK parts (<= 1: as many as fill the chip) */
+#define MMH_KERNEL_MFMA_SPLITK_128X64 20 /* the same on 128x64 tiles                                            */
+/* The product library accepts exactly the ids above: every one of them returns correct results.
+ * The scheduling A/B variants (ids 16-19) and the TIMING-ONLY ablation builds whose results are
+ * wrong (21-24, 32-44; int8 modes 10-13) exist only in libmmult_hip_ab.so, a tools-only build of the
+ * same sources (-DMMH_AB_BUILD; how_to_optimize_gemm_amd.build.build_ab_library(), tools/ab_bench.py).
+ * mmh_is_ab_build() tells the two apart.  See profiles/r01_ablation.md. */
 
 /* Library / device ------------------------------------------------------- */
 const char *mmh_strerror(int status);
@@ -89,14 +100,18 @@ const char *mmh_last_error(void);
  * grid, plain / stream-K / guarded) -- what MMH_KERNEL_AUTO chose. */
 const char *mmh_last_launch(void);
 int mmh_version(void);                 /* 100*major + minor */
+int mmh_is_ab_build(void);             /* 0: the product library; 1: libmmult_hip_ab.so (tools only) */
 int mmh_device_count(int *count);
 /* name must hold >= 256 bytes; cu_count / clock_mhz may be NULL. */
 int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
 
 /* A handle owns device workspaces (host-flavour staging, stream-K hand-off flags and partial-tile
- * slots, int8 / quantisation scratch) that consecutive calls reuse: use one handle per host thread AND
- * per stream that may run concurrently with another -- calls on ONE stream through one handle are
- * ordered by the stream and always safe (as cublasHandle_t with cublasSetStream). */
+ * slots, int8 / quantisation scratch) that consecutive calls reuse: use one handle per host thread.
+ * Calls on ONE stream through one handle are ordered by the stream (as cublasHandle_t with
+ * cublasSetStream); a stream-K / split-K launch on ANOTHER stream than the previous one first waits
+ * for that stream (so the hand-off workspaces are never in use twice), which costs the overlap --
+ * use one handle per stream that should run concurrently.  Every entry point runs on the handle's
+ * device and restores the caller's current device before it returns. */
 int mmh_create(mmh_handle_t *handle, int device);
 int mmh_destroy(mmh_handle_t handle);
 int mmh_set_kernel(mmh_handle_t handle, int kernel);
@@ -106,19 +121,33 @@ const char *mmh_kernel_name(int kernel);
 
 /* Options.  MMH_OPT_STREAMK (default 1): let MMH_KERNEL_MFMA/AUTO run tile counts
  * that do not divide the chip as ONE persistent chained stream-K launch (bit-identical
- * results; uses a per-handle flag buffer, so drive a handle from one stream at a
- * time).  MMH_OPT_STREAMK_TIMEOUTS (read-only): synchronises the device and returns
- * how many stream-K hand-off waits have timed out since the last launch (0 unless
- * something is badly wrong; a timed-out launch produced wrong results). */
+ * results).
+ * MMH_OPT_STREAMK_TIMEOUTS: the handle's STICKY error.  A stream-K / split-K hand-off wait that
+ * times out (never seen outside fault injection) adds to a host-visible word and the waiting
+ * workgroup stops; from then on EVERY mmh_* call on the handle returns MMH_ERR_HIP -- the launch
+ * that timed out produced an invalid result and nobody has to poll to learn it.  get: synchronises
+ * the device and returns the count; set 0: synchronises and clears it. */
 #define MMH_OPT_STREAMK 1
 #define MMH_OPT_STREAMK_TIMEOUTS 2
 /* MMH_OPT_IGEMM_MODE: 0 (default) B read in place (LDS-DMA of its row-major slices, fragments by
  * ds_read_b64_tr_b8; 256x256 tiles from one per CU up, else 128x128) for 4-byte aligned operands,
  * otherwise B packed once per call; 1 transpose B inside the GEMM kernel; 2 the correctness-first
  * kernel; 3 / 4 the packed-B kernel with 128x128 / 256x256 tiles, 5 / 6 the in-place kernel
- * likewise (A/B switches); 10..13 timing-only ablations of the packed 256x256 kernel with WRONG
- * results (no DMA / no fragment reads / neither / no C store; m, n multiples of 256 only). */
+ * likewise (A/B switches).  (Modes 10..13, timing-only ablations with wrong results, exist in
+ * libmmult_hip_ab.so only; the product library rejects them.) */
 #define MMH_OPT_IGEMM_MODE 3
+/* MMH_OPT_SPLITK (default 0 = off): 1 lets MMH_KERNEL_AUTO run shapes with fewer 128x128 tiles than
+ * CUs as a split-K launch with as many concurrent K parts as fill the chip; 2..16 asks for that many
+ * parts.  See MMH_KERNEL_MFMA_SPLITK: deterministic, within the harness tolerance, not the chain's bits. */
+#define MMH_OPT_SPLITK 4
+/* MMH_OPT_HOST_PANELS (default -1 = automatic): row panels of the host-pointer flavour's copy/compute
+ * pipeline (mmh_sgemm_host); 0 or 1 = the plain copy-in, GEMM, copy-out sequence; 2..16 panels. */
+#define MMH_OPT_HOST_PANELS 5
+/* Test hooks.  MMH_OPT_STREAMK_SPIN_LIMIT: hand-off wait bound in units of 1024 polls (default
+ * 65536, seconds).  MMH_OPT_FAULT_INJECT (default 0): 1 = stream-K producers do not publish their
+ * partial tiles, so that every dependent wait times out and the sticky error path can be exercised. */
+#define MMH_OPT_STREAMK_SPIN_LIMIT 6
+#define MMH_OPT_FAULT_INJECT 7
 int mmh_set_option(mmh_handle_t handle, int option, int value);
 int mmh_get_option(mmh_handle_t handle, int option, int *value);
 
@@ -138,14 +167,16 @@ int mmh_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, int lda
 
 /* Host-pointer flavour: stages A, B (and C when accumulating) to the device,
  * runs mmh_sgemm, copies C back, synchronises.  Staging buffers are cached in
- * the handle and grow on demand. */
+ * the handle and grow on demand.  Large problems run as a row-panel pipeline (copy-in of panel
+ * i+1, GEMM of panel i and copy-out of panel i-1 overlap on three streams; MMH_OPT_HOST_PANELS);
+ * row panels are independent, so the bits are those of the single launch. */
 int mmh_sgemm_host(mmh_handle_t handle, int m, int n, int k, const float *A, int lda,
                    const float *B, int ldb, float *C, int ldc, int accumulate);
 
 /* int8 x int8 -> int32, C = A*B (+ C), row-major, inputs expected in
- * [-127,127]; bit-exact integer arithmetic on v_mfma_i32_16x16x64_i8.  B is packed
- * (transposed, zero-padded) into a handle-owned workspace on every call -- one handle
- * per stream. */
+ * [-127,127]; bit-exact integer arithmetic on v_mfma_i32_16x16x64_i8.  4-byte aligned operands
+ * (bases and leading dimensions) are read in place; others are first copied into dense aligned
+ * images in a handle-owned workspace (or, for B only, packed transposed) -- see MMH_OPT_IGEMM_MODE. */
 int mmh_igemm_s8(mmh_handle_t handle, int m, int n, int k, const int8_t *dA, int lda,
                  const int8_t *dB, int ldb, int32_t *dC, int ldc, int accumulate,
                  void *stream);
@@ -173,10 +204,30 @@ int mmh_sgemm_rocblas(mmh_handle_t handle, int m, int n, int k, const float *dA,
  * remainder spread from rank 0 up.  Pure host arithmetic. */
 int mmh_shard_rows(int m, int nranks, int rank, int *row0, int *rows);
 
-/* Single-process form: host A, B, C; A row panels go to each of `ngpus`
- * devices, B goes to device 0 and is broadcast with ONE ncclBroadcast over
- * xGMI, one GEMM launch per device, C panels copied back.  ngpus == 1 skips
- * RCCL.  timings_ms (may be NULL) receives {h2d, bcast, gemm, d2h}. */
+/* Single-process form with a HANDLE (one RCCL communicator, one stream, one product handle and one
+ * set of device buffers per device, all created once): host A, B, C; A row panels go to their owning
+ * devices (one host thread per device: every device has its own PCIe link), B goes to the first
+ * device and is replicated with ONE ncclBroadcast over xGMI, the row-panel GEMMs run concurrently
+ * (stream-K and tile choice per device, as mmh_sgemm), C panels are copied back.
+ *   devices: `ngpus` distinct device ordinals, NULL = 0..ngpus-1.  MMH_ERR_NO_DEVICE when fewer are
+ *            visible (never a silent fallback to fewer), MMH_ERR_UNSUPPORTED without librccl (ngpus > 1).
+ *   mmh_shard_sgemm: gemm_reps >= 1 back-to-back GEMM launches per device (the reference harness's
+ *            NREPEATS loop); timings_ms (may be NULL) receives {h2d, bcast, gemm per rep, d2h}.
+ *   mmh_shard_info: rccl_ranks = ranks of the communicator (0 for ngpus == 1, where RCCL is not used). */
+typedef struct mmh_shard *mmh_shard_t;
+int mmh_shard_create(mmh_shard_t *shard, int ngpus, const int *devices);
+int mmh_shard_destroy(mmh_shard_t shard);
+int mmh_shard_set_kernel(mmh_shard_t shard, int kernel);
+int mmh_shard_info(mmh_shard_t shard, int *ngpus, int *rccl_ranks);
+int mmh_shard_sgemm(mmh_shard_t shard, int m, int n, int k, const float *A, int lda, const float *B,
+                    int ldb, float *C, int ldc, int gemm_reps, float *timings_ms);
+/* RCCL as this library sees it: loads librccl (dlopen) and returns ncclGetVersion's code in *version;
+ * MMH_ERR_UNSUPPORTED when the library or one of the entry points the shard needs is missing.
+ * Needs no GPU. */
+int mmh_rccl_version(int *version);
+
+/* One-shot convenience form of the above: creates a shard handle, runs once, destroys it (so it
+ * pays the communicator's creation on every call -- use the handle form in a loop). */
 int mmh_sgemm_sharded(int ngpus, int m, int n, int k, const float *A, int lda,
                       const float *B, int ldb, float *C, int ldc, int kernel,
                       float *timings_ms);
@@ -189,8 +240,15 @@ int mmh_time_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, in
                    const float *dB, int ldb, float *dC, int ldc, int warmup, int reps,
                    void *stream, float *ms_per_call);
 
+/* Per-launch milliseconds of `count` (<= 4096) back-to-back mmh_sgemm launches, one hipEvent pair
+ * each: the clock-ramp trace (profiles/r02_clock_ramp.csv). */
+int mmh_trace_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, int lda,
+                    const float *dB, int ldb, float *dC, int ldc, int count, void *stream,
+                    float *ms_each);
+
 /* Peak probes: sustained fp32 MFMA TFLOP/s (v_mfma_f32_16x16x4_f32 only, no
- * memory traffic) and HBM copy GB/s (float4 stream copy, read+write bytes). */
+ * memory traffic), HBM copy GB/s (float4 stream copy, four loads in flight per thread,
+ * non-temporal; read+write bytes) and HBM read GB/s (read-only twin, eight loads in flight). */
 int mmh_probe_mfma_f32(mmh_handle_t handle, float *tflops);
 int mmh_probe_mfma_i8(mmh_handle_t handle, float *tops);   /* v_mfma_i32_16x16x64_i8 only */
 /* The same loop run back to back for at least `min_ms` (0..2000), reporting the last 2.3 ms launch:
@@ -198,6 +256,7 @@ int mmh_probe_mfma_i8(mmh_handle_t handle, float *tops);   /* v_mfma_i32_16x16x6
  * manager sustains on real data), 0 keeps the constant operands of mmh_probe_mfma_i8. */
 int mmh_probe_mfma_i8_sustained(mmh_handle_t handle, int random_operands, float min_ms, float *tops);
 int mmh_probe_hbm_copy(mmh_handle_t handle, size_t bytes, float *gbps);
+int mmh_probe_hbm_read(mmh_handle_t handle, size_t bytes, float *gbps);
 
 #ifdef __cplusplus
 }

@@ -100,6 +100,56 @@ def test_options_and_kernel_ids_validate_without_a_device():
         assert H.KERNELS[{"mfma_256": "mfma256"}.get(name, name)] == kid, name
 
 
+def test_rccl_is_loadable_and_every_entry_point_the_shard_needs_resolves():
+    """mmh_rccl_version drives the library's own RCCL loader (dlopen + dlsym of ncclGetVersion,
+    ncclCommInitAll, ncclCommDestroy, ncclCommCount, ncclGroupStart/End, ncclBroadcast) without a GPU:
+    MMH_ERR_UNSUPPORTED here would mean the multi-GPU shard cannot run on this image at all."""
+    v = H.rccl_version()
+    assert v >= 20000, v                       # NCCL-style version code, e.g. 22707
+    L = H.lib()
+    assert L.mmh_rccl_version(None) == H.ERR_INVALID_ARG
+
+
+def test_shard_handle_argument_plumbing_without_a_device():
+    """mmh_shard_create validates before it touches a device: bad counts, NULL out-pointer, and --
+    on a box with fewer devices than asked for -- MMH_ERR_NO_DEVICE, never a smaller shard."""
+    L = H.lib()
+    h = ctypes.c_void_p()
+    assert L.mmh_shard_create(None, 1, None) == H.ERR_INVALID_ARG
+    assert L.mmh_shard_create(ctypes.byref(h), 0, None) == H.ERR_INVALID_ARG
+    assert L.mmh_shard_create(ctypes.byref(h), 65, None) == H.ERR_INVALID_ARG
+    n = H.device_count()
+    assert L.mmh_shard_create(ctypes.byref(h), n + 1, None) == H.ERR_NO_DEVICE
+    assert not h.value
+    assert b"fewer visible devices" in L.mmh_last_error()
+    assert L.mmh_shard_destroy(None) == H.OK
+    assert L.mmh_shard_set_kernel(None, 0) == H.ERR_INVALID_ARG
+    assert L.mmh_shard_info(None, None, None) == H.ERR_INVALID_ARG
+    assert L.mmh_shard_sgemm(None, 1, 1, 1, None, 1, None, 1, None, 1, 1, None) == H.ERR_INVALID_ARG
+    with pytest.raises(H.MMultError) as e:
+        H.ShardedMMult(n + 1)
+    assert e.value.status == H.ERR_NO_DEVICE
+    # the one-shot form goes through the same handle path
+    import numpy as np
+    with pytest.raises(H.MMultError) as e:
+        H.sgemm_sharded(n + 1, np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))
+    assert e.value.status == H.ERR_NO_DEVICE
+
+
+def test_product_library_carries_no_ablation_builds():
+    """The timing-only ablation kernels (wrong results) and scheduling A/B variants live in the
+    tools-only libmmult_hip_ab.so: the product library neither names nor contains them."""
+    L = H.lib()
+    assert L.mmh_is_ab_build() == 0
+    for kid in list(range(16, 20)) + list(range(21, 25)) + list(range(32, 45)):
+        assert H.kernel_name(kid) is None, kid
+    blob = open(H.LIB_PATH, "rb").read()
+    assert b"ablate" not in blob and b"cadence_" not in blob
+    # every id the Python mirror offers is a product kernel
+    assert sorted(H.KERNELS.values()) == sorted(set(H.KERNELS.values()))
+    assert all(v < 16 or v == 20 for v in H.KERNELS.values())
+
+
 def test_no_device_fails_loudly_without_fallback():
     """On a box without a gfx950 GPU the product path must refuse, not
     compute on the CPU."""

@@ -19,7 +19,8 @@ from conftest import golden_cases, load_golden
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "auto", "mfma_pipe", "mfma_simple", "valu", "naive"]
+KERNELS = ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "auto", "mfma_pipe", "mfma_simple", "valu",
+           "valu_128x128", "valu_64x64", "naive"]
 
 
 def tol(k):
@@ -77,7 +78,7 @@ SHAPES = [(256, 256, 256), (384, 640, 1024), (128, 128, 32), (128, 256, 4096), (
           (130, 129, 37), (3, 5, 7), (257, 255, 513), (512, 128, 2048), (1024, 1024, 1024)]
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "valu"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "valu", "valu_64x64"])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_seeded_inputs_vs_oracle(mm, oracle, shape, kernel):
     m, n, k = shape
@@ -103,10 +104,43 @@ def test_headline_size_4096(mm, oracle):
     # the GPU's error against fp64 is no worse than the reference loop's own
     c64 = oracle.ref_mmult_f64(a, b)
     assert np.abs(got - c64).max() <= 1.05 * np.abs(unfused - c64).max() + 1e-6
-    # every kernel variant is the same chain -> identical bits
-    for kern in ("mfma256", "valu"):
+    # every kernel variant is the same chain -> identical bits.  "auto" is what bench.py and the
+    # harness run at this size: it must launch the 256x256 tile, and that launch is checked here
+    # against the oracle on the FULL matrix, not on sampled rows.
+    import how_to_optimize_gemm_amd as H
+    for kern in ("auto", "mfma_256x256", "mfma256", "mfma_tiles", "mfma_128x64", "valu", "valu_128x128"):
         mm.set_kernel(kern)
-        assert np.array_equal(mm.matmul(dev(a), dev(b)).cpu().numpy(), got), kern
+        out = mm.matmul(dev(a), dev(b)).cpu().numpy()
+        if kern in ("auto", "mfma_256x256"):
+            assert "sgemm_mfma_kernel<256,256>" in H.last_launch(), (kern, H.last_launch())
+        assert np.array_equal(out, fused), kern
+    # accumulate mode at the headline size, through the headline kernel: C's value starts each chain
+    mm.set_kernel("auto")
+    c0 = np.random.default_rng(11).uniform(-1, 1, (n, n)).astype(np.float32)
+    out = dev(c0)
+    mm.matmul(dev(a), dev(b), out=out, accumulate=True)
+    assert np.array_equal(out.cpu().numpy(), oracle.ref_mmult(a, b, c0.copy(), fma=True))
+
+
+@pytest.mark.parametrize("shape,expect", [
+    ((4352, 4352, 4352), "streamk_kernel<256,256>"),    # 289 tiles on 256 workgroups: unguarded stream-K
+    ((5000, 5000, 256), "streamk_kernel<256,256>"),     # 400 ragged tiles: guarded stream-K
+    ((4000, 4000, 520), "sgemm_mfma_kernel<256,256>"),  # 256 ragged tiles: guarded plain launch, ragged K
+    ((4608, 4096, 1000), "streamk_kernel<256,256>"),    # 288 tiles, k not a multiple of the slice
+])
+def test_big_tile_full_matrix_vs_oracle(mm, oracle, shape, expect):
+    """The 256x256 configuration in all four launch forms (plain / stream-K x unguarded / guarded) at
+    sizes with at least one tile per CU, every element of C against the fused oracle chain."""
+    import how_to_optimize_gemm_amd as H
+    m, n, k = shape
+    a, b = oracle.harness_inputs(m, n, k, seed=3 * m + 5 * n + 7 * k)
+    mm.set_kernel("auto")
+    got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+    assert expect in H.last_launch(), H.last_launch()
+    assert mm.streamk_timeouts() == 0
+    assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
+    d, _ = oracle.compare_matrices(got, oracle.ref_mmult(a, b, fma=False))
+    assert d <= tol(k)
 
 
 def test_sweep_sizes_integer_pattern_exact(mm, oracle):
@@ -297,6 +331,37 @@ def test_invalid_arguments_return_codes(mm):
     assert L.mmh_sgemm(h, 4, 8, 4, p, 4, p, 8, p, 4, 0, None) == H.ERR_INVALID_ARG   # ldc < n
     assert L.mmh_sgemm(h, 4, 4, 4, None, 4, p, 4, p, 4, 0, None) == H.ERR_INVALID_ARG
     assert L.mmh_set_kernel(h, 99) == H.ERR_INVALID_ARG
+    # the scheduling A/B variants and the timing-only ablation builds (wrong results) are not part of
+    # the product library: their ids and int8 modes are rejected
+    assert L.mmh_is_ab_build() == 0
+    for kid in list(range(16, 20)) + list(range(21, 25)) + list(range(32, 45)):
+        assert L.mmh_set_kernel(h, kid) == H.ERR_INVALID_ARG, kid
+        assert H.kernel_name(kid) is None
+    for mode in (7, 10, 11, 12, 13, -1):
+        assert L.mmh_set_option(h, H.OPT_IGEMM_MODE, mode) == H.ERR_INVALID_ARG, mode
+    assert L.mmh_set_option(h, H.OPT_SPLITK, 17) == H.ERR_INVALID_ARG
+    assert L.mmh_set_option(h, H.OPT_HOST_PANELS, 99) == H.ERR_INVALID_ARG
+    assert L.mmh_set_option(h, 1234, 0) == H.ERR_INVALID_ARG
+    # the torch glue checks what the kernels take on trust (dtype, device, overlapping rows)
+    f = torch.zeros((8, 8), device="cuda")
+    with pytest.raises(H.MMultError):
+        mm.matmul(f.half(), f.half())
+    with pytest.raises(H.MMultError):
+        mm.matmul(f, f, out=torch.zeros((8, 8), device="cuda", dtype=torch.float16))
+    with pytest.raises(H.MMultError):
+        mm.matmul(torch.zeros((1, 8), device="cuda").expand(8, 8), f)          # stride(0) == 0
+    with pytest.raises(H.MMultError):
+        mm.igemm_s8(f.to(torch.int8), f.to(torch.int8), out=torch.zeros((8, 8), device="cuda"))   # fp32 out
+    with pytest.raises(H.MMultError):
+        mm.qgemm(f.double(), f.double())
+    with pytest.raises(H.MMultError):
+        mm.quantize_sym_s8(f.to(torch.int32))
+    with pytest.raises(H.MMultError):
+        mm.matmul_rocblas(f.half(), f)
+    with pytest.raises(H.MMultError):
+        mm.sgemm_host(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32), c=np.zeros((4, 4), np.float64))
+    with pytest.raises(H.MMultError):
+        mm.sgemm_host(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32), c=np.zeros((3, 4), np.float32))
     with pytest.raises(H.MMultError):
         mm.matmul(torch.zeros((4, 4)), torch.zeros((4, 4)))      # CPU tensors: no fallback
     # a second handle on a non-existent device
@@ -503,6 +568,30 @@ def test_single_process_shard_with_one_device(mm, oracle):
     assert t["bcast"] >= 0 and t["gemm"] > 0
 
 
+def test_shard_handle_is_persistent_and_refuses_missing_devices(mm, oracle):
+    """mmh_shard_create/_sgemm/_destroy: one handle, many calls (communicator, streams, buffers and the
+    per-device product handles persist; shapes may change from call to call), stream-K per device, and
+    a request for more devices than are visible FAILS (MMH_ERR_NO_DEVICE) -- it never runs on fewer."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    visible = torch.cuda.device_count()
+    with pytest.raises(H.MMultError) as e:
+        H.ShardedMMult(visible + 1)
+    assert e.value.status == H.ERR_NO_DEVICE and "fewer visible devices" in str(e.value)
+    with pytest.raises(H.MMultError):
+        H.ShardedMMult(1, devices=[visible])                       # ordinal out of range
+    for g in sorted({1, visible}):
+        with H.ShardedMMult(g, kernel="auto") as sh:
+            info = sh.info()
+            assert info["ngpus"] == g and info["rccl_ranks"] == (g if g > 1 else 0)
+            for (m, n, k) in [(300, 200, 96), (3072, 3072, 128), (1024, 512, 2048)]:
+                a, b = oracle.harness_inputs(m, n, k, seed=m + g)
+                c, t = sh.sgemm(a, b, gemm_reps=3)
+                assert np.array_equal(c, oracle.ref_mmult(a, b, fma=True)), (g, m, n, k)
+                assert t["gemm"] > 0 and t["h2d"] > 0 and t["d2h"] > 0
+                assert (t["bcast"] > 0) == (g > 1)
+
+
 def test_row_panel_shard_reassembles_full_product(mm, oracle):
     """What N ranks would each compute (their mmh_shard_rows panel, full B),
     run serially on one GPU, equals the unsharded product bit-for-bit."""
@@ -622,3 +711,189 @@ def test_peak_probes_are_sane(mm):
     assert 100.0 < tf < 165.0, tf          # 157.3 TFLOP/s is the fp32 MFMA peak
     gb = mm.probe_hbm_copy(1 << 30)
     assert 2000.0 < gb < 8000.0, gb
+
+
+def test_stream_k_timeout_is_a_sticky_error(oracle):
+    """Fault injection: stream-K producers do not publish, every dependent hand-off wait runs into the
+    (shortened) spin limit.  The waiting workgroups stop instead of continuing from an unpublished slot,
+    and the handle turns sticky: the NEXT mmh_* call -- and every one after it -- fails with
+    MMH_ERR_HIP, no polling needed.  Clearing the word makes the handle usable again, same bits."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    h = H.MMult(0, "mfma")
+    try:
+        m = n = 3072                                   # 576 tiles on 512 workgroup slots: stream-K
+        k = 256
+        a, b = oracle.harness_inputs(m, n, k, seed=5)
+        da, db = dev(a), dev(b)
+        good = h.matmul(da, db)
+        assert "streamk" in H.last_launch()
+        assert h.streamk_timeouts() == 0
+        h.set_option(H.OPT_STREAMK_SPIN_LIMIT, 4)      # 4096 polls instead of seconds
+        h.set_option(H.OPT_FAULT_INJECT, 1)
+        h.matmul(da, db)                               # asynchronous: the launch itself is accepted
+        torch.cuda.synchronize()
+        with pytest.raises(H.MMultError) as e:         # ... and the next call on the handle reports it
+            h.matmul(da, db)
+        assert e.value.status == H.ERR_HIP and "timed out" in str(e.value)
+        with pytest.raises(H.MMultError):              # sticky: still failing, whatever the entry point
+            h.probe_mfma_f32()
+        h.set_option(H.OPT_FAULT_INJECT, 0)
+        with pytest.raises(H.MMultError):
+            h.matmul(da, db)
+        assert h.streamk_timeouts() > 0
+        h.clear_error()
+        h.set_option(H.OPT_STREAMK_SPIN_LIMIT, 65536)
+        assert torch.equal(h.matmul(da, db), good) and h.streamk_timeouts() == 0
+        # time_sgemm synchronises, so it reports a timeout of its OWN launches
+        h.set_option(H.OPT_STREAMK_SPIN_LIMIT, 4)
+        h.set_option(H.OPT_FAULT_INJECT, 1)
+        c = torch.empty((m, n), device="cuda")
+        with pytest.raises(H.MMultError):
+            h.time_sgemm(m, n, k, da.data_ptr(), k, db.data_ptr(), n, c.data_ptr(), n, warmup=0, reps=1)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024, 1024), (1152, 1152, 1152), (1536, 1536, 1536), (1792, 1792, 1792),
+                                   (1024, 2048, 4096), (1280, 1024, 512)])
+@pytest.mark.parametrize("kernel,parts", [("mfma_splitk", 0), ("mfma_splitk", 2), ("mfma_splitk", 4),
+                                          ("mfma_splitk_128x64", 0), ("mfma_splitk_128x64", 2), ("auto", 1)])
+def test_opt_in_split_k_meets_the_harness_tolerance(mm, oracle, shape, kernel, parts):
+    """MMH_OPT_SPLITK / MMH_KERNEL_MFMA_SPLITK trade the one-chain-per-element bits for concurrency on
+    shapes with fewer tiles than the chip has slots.  Its own bar: |diff| vs the UNFUSED REF_MMult
+    <= tol(k) = 2e-7 k + 1e-6 (the harness's is 0.5, cuda/test_MMult.cpp:123-127), error vs fp64 no
+    worse than 1.05x the reference loop's, deterministic run to run, exact on integer-valued inputs,
+    and never used unless asked for."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    m, n, k = shape
+    a, b = oracle.harness_inputs(m, n, k, seed=m + n + k + parts)
+    da, db = dev(a), dev(b)
+    mm.set_kernel(kernel)
+    mm.set_splitk(parts)
+    try:
+        got = mm.matmul(da, db)
+        launched = H.last_launch()
+        if "128x64" in kernel and "splitk" not in launched:
+            # more 128x64 tiles x parts than workgroup slots: the launcher keeps the chain kernel
+            assert np.array_equal(got.cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
+            return
+        assert "splitk" in launched, launched
+        assert mm.streamk_timeouts() == 0
+        assert torch.equal(got, mm.matmul(da, db)), "split-K must be deterministic run to run"
+        g = got.cpu().numpy()
+        unfused = oracle.ref_mmult(a, b, fma=False)
+        d, _ = oracle.compare_matrices(g, unfused)
+        assert d <= tol(k), (d, launched)
+        c64 = oracle.ref_mmult_f64(a, b)
+        assert np.abs(g - c64).max() <= 1.05 * np.abs(unfused - c64).max() + 1e-6
+        # accumulate: part 0 starts from C
+        c0 = np.random.default_rng(2).uniform(-1, 1, (m, n)).astype(np.float32)
+        out = dev(c0)
+        mm.matmul(da, db, out=out, accumulate=True)
+        d, _ = oracle.compare_matrices(out.cpu().numpy(), oracle.ref_mmult(a, b, c0.copy(), fma=False))
+        assert d <= tol(k)
+        # integer-valued inputs: every partial sum is exact, so the split changes nothing
+        ai, bi = oracle.harness_inputs(m, n, k, pattern=3)
+        want = torch.from_numpy(ai).cuda().double() @ torch.from_numpy(bi).cuda().double()
+        assert torch.equal(mm.matmul(dev(ai), dev(bi)).double(), want)
+    finally:
+        mm.set_splitk(0)
+    # default mode never splits: AUTO without the option is the chain, bit for bit
+    mm.set_kernel("auto")
+    assert np.array_equal(mm.matmul(da, db).cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
+    assert "splitk" not in H.last_launch()
+
+
+def test_split_k_falls_back_to_the_chain_on_shapes_it_does_not_take(mm, oracle):
+    import how_to_optimize_gemm_amd as H
+    mm.set_splitk(4)
+    try:
+        for kernel in ("mfma_splitk", "mfma_splitk_128x64", "auto"):
+            mm.set_kernel(kernel)
+            for (m, n, k) in [(1000, 1000, 1000), (130, 129, 37), (1024, 1024, 32)]:   # ragged, or one K-slice
+                a, b = oracle.harness_inputs(m, n, k, seed=m + k)
+                got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+                assert "splitk" not in H.last_launch(), (kernel, m, n, k, H.last_launch())
+                assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
+    finally:
+        mm.set_splitk(0)
+        mm.set_kernel("mfma")
+
+
+@pytest.mark.parametrize("panels", [-1, 0, 2, 5, 16])
+def test_host_flavour_pipeline_keeps_the_bits(oracle, panels):
+    """mmh_sgemm_host's row-panel pipeline (copy-in / GEMM / copy-out on three streams) against the
+    plain staged form and the oracle: C += A*B on host buffers with padded leading dimensions."""
+    import how_to_optimize_gemm_amd as H
+    h = H.MMult(0, "auto")
+    try:
+        h.set_host_panels(panels)
+        for (m, n, k, lda, ldb, ldc) in [(2048, 1024, 512, 520, 1032, 1024), (1100, 640, 300, 300, 640, 648)]:
+            rng = np.random.default_rng(m + panels)
+            a = rng.uniform(-1, 1, (m, lda)).astype(np.float32)
+            b = rng.uniform(-1, 1, (k, ldb)).astype(np.float32)
+            c0 = rng.uniform(-1, 1, (m, ldc)).astype(np.float32)
+            c = c0.copy()
+            h.MY_MMult(m, n, k, a, lda, b, ldb, c, ldc)
+            want = oracle.ref_mmult(a[:, :k], b[:, :n], c0.copy()[:, :n], fma=True)
+            assert np.array_equal(c[:, :n], want), (panels, m)
+            assert np.array_equal(c[:, n:], c0[:, n:])           # padding columns untouched
+            for _ in range(2):                                    # the events are reused call after call
+                c = c0.copy()
+                h.MY_MMult(m, n, k, a, lda, b, ldb, c, ldc)
+                assert np.array_equal(c[:, :n], want)
+            # overwrite form
+            got = h.sgemm_host(np.ascontiguousarray(a[:, :k]), np.ascontiguousarray(b[:, :n]))
+            assert np.array_equal(got, oracle.ref_mmult(a[:, :k], b[:, :n], fma=True))
+    finally:
+        h.close()
+
+
+def test_entry_points_restore_the_callers_device(mm):
+    """Every entry point runs on the handle's device and leaves the thread's current device alone
+    (with one visible GPU: the current device is 0 before and after, and a handle for another
+    ordinal cannot be created)."""
+    import torch
+    before = torch.cuda.current_device()
+    a = torch.rand((256, 256), device="cuda")
+    mm.set_kernel("auto")
+    mm.matmul(a, a)
+    mm.probe_hbm_read(1 << 26)
+    mm.sgemm_host(np.ones((64, 64), np.float32), np.ones((64, 64), np.float32))
+    assert torch.cuda.current_device() == before
+    if torch.cuda.device_count() > 1:
+        import how_to_optimize_gemm_amd as H
+        with H.MMult(1, "mfma") as h1:
+            b = torch.rand((256, 256), device="cuda:1")
+            torch.cuda.set_device(0)
+            out = h1.matmul(b, b)
+            assert torch.cuda.current_device() == 0 and out.device.index == 1
+            with pytest.raises(H.MMultError):
+                h1.matmul(a, a)                                   # tensors of another device
+
+
+def test_quantiser_handles_tiny_and_non_finite_inputs(mm, oracle):
+    """The contract's edge cases (quant_s8.hpp): the scale is taken over the FINITE elements, is
+    clamped when 127 / max|x| would overflow, NaN quantises to 0 and +-inf to +-127."""
+    import torch
+    rng = np.random.default_rng(8)
+    x = rng.uniform(-1, 1, (64, 96)).astype(np.float32)
+    for case in ("tiny", "subnormal", "nonfinite", "zeros"):
+        y = x.copy()
+        if case == "tiny":
+            y *= np.float32(1e-38)
+        elif case == "subnormal":
+            y = (y * np.float32(1e-30)).astype(np.float32) * np.float32(1e-12)
+        elif case == "nonfinite":
+            y[0, 0], y[1, 1], y[2, 2] = np.nan, np.inf, -np.inf
+        else:
+            y[:] = 0
+        q, s = mm.quantize_sym_s8(dev(y))
+        want_q, want_s = oracle.quantize_sym_s8(y)
+        assert np.array_equal(q.cpu().numpy(), want_q), case
+        assert float(s.item()) == want_s and np.isfinite(want_s) and want_s > 0, (case, want_s)
+        if case == "nonfinite":
+            assert want_q[0, 0] == 0 and want_q[1, 1] == 127 and want_q[2, 2] == -127
+            assert np.abs(want_q).max() == 127 and (np.abs(want_q) == 127).sum() >= 3

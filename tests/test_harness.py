@@ -76,6 +76,39 @@ def test_cpu_sweep_format_and_threaded_ref_identical():
     assert rc == 0 and "64 " in out
 
 
+def test_blas_order_oracle_reproduces_the_published_diff_magnitudes():
+    """the cuda directory's REF_MMult is cblas_sgemm (cuda/REF_MMult.cpp:9-13), and the
+    diff column of every published cuda/output_MMult_cuda_*.m is a k-ordered fp32 chain against THAT
+    blocked summation order: 7.2e-5 at p=1024, 1.07e-4 at 1280 (cuda/output_MMult_cuda_12.m:5,7).
+    Here MY_MMult := the serial triple loop (FLAVOUR=cpu, the same chain up to FMA contraction) and
+    REF=blas := the host BLAS found at run time; the diff must land in the published band (an
+    order-of-magnitude pin: it depends on the BLAS build and the CPU)."""
+    build()
+    rc, out, err = run({"FLAVOUR": "cpu", "PFIRST": 1024, "PLAST": 1280, "PINC": 256, "NREPEATS": 1, "REF": "blas"},
+                       timeout=600)
+    assert rc == 0, err
+    rows = parse(out)
+    assert [r[0] for r in rows] == [1024, 1280]
+    published = {1024: 7.247925e-05, 1280: 1.068115e-04}
+    for p, _, diff in rows:
+        assert published[p] / 4 <= diff <= published[p] * 4, (p, diff)
+    # and the two oracles agree with each other far inside the harness tolerance (0.5)
+    assert all(d < 1e-3 for _, _, d in rows)
+
+
+@pytest.mark.gpu
+def test_gpu_sweep_against_the_blas_order_oracle():
+    """The same column with the GPU behind MY_MMult: the reference's own published magnitudes
+    (cuda/output_MMult_cuda_12.m:5,13: 7.2e-5 at 1024, 1.6e-4 at 2048) within a factor of 4."""
+    build()
+    rc, out, err = run({"PFIRST": 1024, "PLAST": 2048, "PINC": 1024, "NREPEATS": 3, "REF": "blas"})
+    assert rc == 0, err + out
+    rows = parse(out)
+    published = {1024: 7.247925e-05, 2048: 1.564026e-04}
+    for p, _, diff in rows:
+        assert published[p] / 4 <= diff <= published[p] * 4, (p, diff)
+
+
 @pytest.mark.gpu
 def test_device_flavour_sweep_on_gpu():
     build()
@@ -88,7 +121,7 @@ def test_device_flavour_sweep_on_gpu():
         assert 0.0 <= diff <= 2e-7 * p + 1e-6        # vs the unfused triple loop
         assert gflops > 5000
     # known-answer inputs: exactly zero, every kernel on the ladder
-    for kern in ("mfma", "mfma256", "mfma_pipe", "mfma_simple", "valu", "naive", "rocblas"):
+    for kern in ("mfma", "mfma256", "mfma_pipe", "mfma_simple", "valu", "valu_64x64", "naive", "rocblas", "mfma_splitk"):
         rc, out, err = run({"PFIRST": 1024, "PLAST": 1024, "INPUT": "mod3", "KERNEL": kern, "NREPEATS": 3})
         assert rc == 0, kern + err
         assert parse(out)[0][2] == 0.0, kern
@@ -115,6 +148,10 @@ def test_sharded_flavour_single_process_on_gpu():
     assert rc == 0, err
     rows = parse(out)
     assert [r[0] for r in rows] == [512, 1024] and all(r[2] == 0.0 for r in rows)
+    # more devices than the box has: the harness exits non-zero (MMH_CHECK), it does not shrink the job
+    import torch
+    rc, out, err = run({"FLAVOUR": "sharded", "NGPUS": torch.cuda.device_count() + 1, "PFIRST": 512, "PLAST": 512})
+    assert rc != 0 and "fewer visible devices" in err
 
 
 @pytest.mark.gpu

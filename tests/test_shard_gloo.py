@@ -63,6 +63,25 @@ def _worker(rank, world, port, m, n, k, chunks, q):
         dist.destroy_process_group()
 
 
+def test_streamed_form_with_an_empty_contraction_zeroes_c():
+    """k == 0: nothing to broadcast; the streamed form makes the one overwrite call that mmh_sgemm
+    answers with C = 0 (the same contract as local_gemm / mmh_sgemm), instead of leaving C as it was."""
+    sys.path.insert(0, REPO)
+    from how_to_optimize_gemm_amd.shard import RowPanelShard
+    sh = RowPanelShard(256, 8, 0, 0, 1)
+    calls = []
+
+    def gemm(x, y, out, accumulate):
+        calls.append((tuple(x.shape), tuple(y.shape), accumulate))
+        if not accumulate:
+            out.zero_()
+        return out
+
+    c = torch.full((256, 8), float("nan"))
+    sh.gemm_with_streamed_b(gemm, torch.empty((256, 0)), torch.empty((0, 8)), c)
+    assert calls == [((256, 0), (0, 8), False)] and torch.equal(c, torch.zeros_like(c))
+
+
 @pytest.mark.parametrize("world,m,n,k,chunks", [(2, 256, 96, 64, 1), (2, 300, 72, 40, 1),
                                                (3, 520, 64, 48, 2), (2, 100, 33, 17, 1)])
 def test_row_panel_shard_over_gloo(world, m, n, k, chunks):

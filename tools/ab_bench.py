@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Within-process interleaved A/B of kernel variants (cdna guide rule 24):
 N variants x R rounds, report median / best TFLOP/s per variant.
-usage: python tools/ab_bench.py [--n 4096] [--rounds 7] [--reps 10] mfma mfma_simple 16 17 ..."""
+usage: python tools/ab_bench.py [--n 4096] [--rounds 7] [--reps 10] [--splitk S] mfma mfma_simple 16 17 ...
+Loads libmmult_hip_ab.so (built on demand): numeric ids 16-19 are scheduling variants with valid
+results, 21-24 / 32-44 TIMING-ONLY ablation builds whose results are wrong (profiles/r01_ablation.md).
+A variant written name:S (e.g. mfma_splitk:4) runs with MMH_OPT_SPLITK = S."""
 import argparse
 import os
 import statistics
@@ -10,6 +13,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import how_to_optimize_gemm_amd as H  # noqa: E402
+
+if os.environ.get("MMH_AB", "1") != "0":   # the A/B variants and ablation builds live in the tools-only library
+    H.use_ab_library()
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=4096)
@@ -36,7 +42,12 @@ stream = torch.cuda.current_stream().cuda_stream
 
 
 def vid(v):
+    v = v.split(":")[0]
     return H.KERNELS[v] if v in H.KERNELS else int(v)
+
+
+def vsplit(v):
+    return int(v.split(":")[1]) if ":" in v else 0
 
 
 ref = None
@@ -44,6 +55,7 @@ res = {v: [] for v in args.variants}
 for r in range(args.rounds):
     for v in args.variants:
         H.lib().mmh_set_kernel(mm._h, vid(v))
+        mm.set_splitk(vsplit(v))
         if v == "rocblas":
             continue
         ms = mm.time_sgemm(m, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, warmup=1,

@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import how_to_optimize_gemm_amd as H  # noqa: E402
 
+if os.environ.get("MMH_AB", "1") != "0":   # the A/B variants and ablation builds live in the tools-only library
+    H.use_ab_library()
+
 mm = H.MMult(0, "mfma")
 stream = torch.cuda.current_stream().cuda_stream
 
