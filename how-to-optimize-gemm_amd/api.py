@@ -31,7 +31,8 @@ OPT_SPLITK, OPT_HOST_PANELS, OPT_STREAMK_SPIN_LIMIT, OPT_FAULT_INJECT = 4, 5, 6,
 KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
            "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11, "mfma_256x256": 12,
-           "valu_128x128": 13, "valu_64x64": 14, "mfma_splitk": 15, "mfma_splitk_128x64": 20}
+           "valu_128x128": 13, "valu_64x64": 14, "mfma_splitk": 15, "mfma_splitk_128x64": 20,
+           "mfma_64x64_dma": 25, "mfma_128x64_dma": 27, "mfma_128x128_dma": 28}
 # kernels that keep the one-chain-per-element contract (bit-identical results); the split-K ids do not
 CHAIN_KERNELS = [k for k in KERNELS if "splitk" not in k]
 

@@ -32,6 +32,7 @@
 #include "igemm_s8.hpp"
 #include "probes.hpp"
 #include "quant_s8.hpp"
+#include "sgemm_dma.hpp"
 #include "sgemm_mfma.hpp"
 #include "sgemm_valu.hpp"
 
@@ -230,48 +231,37 @@ int resident_per_cu(mmh_context *ctx, K kernel, int threads, size_t lds) {
 }
 
 // The hand-off workspaces (flags, partial tiles) belong to the handle.  Launches on ONE stream are
-// ordered by the stream; a launch on ANOTHER stream than the last one first waits for that stream, so
-// two streams can never have the workspaces in use at once.
+// ordered by the stream; an eager launch on ANOTHER stream than the last eager one first waits for
+// that stream, so two streams can never have the workspaces in use at once.  A launch that is being
+// CAPTURED into a hipGraph executes nothing now and may not synchronise anything: it is recorded as
+// it is, and whoever replays the graph orders it against other work on the handle (as for any buffer
+// a graph owns) -- include/mmult_hip.h says so.
 int claim_workspaces(mmh_context *ctx, hipStream_t s) {
-  if (ctx->ws_used && ctx->ws_stream != s) {
-    hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &a);
-    (void)hipStreamIsCapturing(ctx->ws_stream, &b);
-    if (a != hipStreamCaptureStatusNone || b != hipStreamCaptureStatusNone) {
-      g_last_error = "the handle's stream-K workspaces were last used on another stream and one of the two is "
-                     "being captured: use one handle per stream";
-      return MMH_ERR_INVALID_ARG;
-    }
-    HIP_TRY(hipStreamSynchronize(ctx->ws_stream));
-  }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  if (cap != hipStreamCaptureStatusNone) return MMH_OK;
+  if (ctx->ws_used && ctx->ws_stream != s) HIP_TRY(hipStreamSynchronize(ctx->ws_stream));
   ctx->ws_stream = s;
   ctx->ws_used = true;
   return MMH_OK;
 }
 
-// Persistent chained stream-K launch (sgemm_mfma.hpp, K2p) of tile config
-// <BM, BN, WTN>.  Returns MMH_OK if it launched, 1 if the shape does not qualify
-// (caller then uses the plain one-tile-per-workgroup launch).
-template <int BM, int BN, int WTN, int WTM = 4, int KB = mmh::BK>
-int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, int lda,
-                       const float *B, int ldb, float *C, int ldc, int acc, hipStream_t s) {
-  if (!ctx || !ctx->streamk || !ctx->sticky_dev) return 1;
-  if (!window_ok(BM, BN, k, lda, ldb)) return 1;   // descriptor window
-  // whole, 16-byte-aligned shapes run the unguarded kernel; everything else the guarded one (partial
-  // tiles travel through a workspace, not through C, so C's alignment and ragged edges do not matter)
-  const bool fast = fast_shape(BM, BN, KB, m, n, k, A, lda, B, ldb, C, ldc);
+// Persistent chained stream-K launch (sgemm_mfma.hpp, K2p): what is common to every tile code.  `kern`
+// is the instantiation to launch (`occ_kern` the one whose residency bounds the grid).  Returns MMH_OK
+// if it launched, 1 if the shape does not qualify (caller then uses the plain one-tile-per-workgroup
+// launch).
+template <typename K>
+int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int threads, size_t lds, const char *what,
+                   int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int acc,
+                   hipStream_t s) {
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
   const long tiles = (long)nbm * nbn;
   const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-  constexpr size_t lds = lds_bytes(BM, BN, KB);
-  constexpr int threads = (BM / (16 * WTM)) * (BN / (16 * WTN)) * 64;
-  auto kern_fast = mmh::sgemm_mfma_streamk_kernel<BM, BN, false, WTN, WTM, KB>;
-  auto kern_edge = mmh::sgemm_mfma_streamk_kernel<BM, BN, true, WTN, WTM, KB>;
   {
-    const int ok = allow_big_lds(fast ? kern_fast : kern_edge, lds);
+    const int ok = allow_big_lds(kern, lds);
     if (ok != MMH_OK) return ok;
   }
-  const int per_cu = resident_per_cu(ctx, kern_edge, threads, lds);
+  const int per_cu = resident_per_cu(ctx, occ_kern, threads, lds);
   // the largest grid (whole CUs' worth of workgroups) that still gives every
   // workgroup at least one full tile, so that chains never stall.  (Shorter ranges
   // are legal for the kernel -- tiles then have three or more parts -- but measured
@@ -282,6 +272,12 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
     if (tiles >= (long)w * cus) { grid = w * cus; break; }
   if (grid == 0 || tiles % grid == 0) return 1;   // too few tiles, or already balanced
   if (tiles > (1L << 24)) return 1;
+  // nearly full rounds: the plain launch idles less than the hand-overs cost (measured, N = 1408 on
+  // 64x64 tiles: 484 tiles for 512 slots run 119 TFLOP/s plain, 109 under stream-K)
+  {
+    const long slots = (long)per_cu * cus, rounds = (tiles + slots - 1) / slots;
+    if (tiles * 100 >= rounds * slots * 93) return 1;
+  }
   int rc = claim_workspaces(ctx, s);
   if (rc != MMH_OK) return rc;
   rc = ctx->flags.reserve((size_t)tiles * sizeof(int));
@@ -291,21 +287,49 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
   int *flags = static_cast<int *>(ctx->flags.p);
   float *parts = static_cast<float *>(ctx->parts.p);
   HIP_TRY(hipMemsetAsync(flags, 0, (size_t)tiles * sizeof(int), s));
-  if (fast)
-    hipLaunchKernelGGL(kern_fast, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
-                       acc, nbm, nbn, flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault);
-  else
-    hipLaunchKernelGGL(kern_edge, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc,
-                       acc, nbm, nbn, flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm, nbn,
+                     flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault);
   HIP_TRY(hipGetLastError());
   {
-    char buf[176];
-    snprintf(buf, sizeof buf,
-             "sgemm_mfma_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d, %s%ld tiles on %d persistent workgroups",
-             BM, BN, 16 * WTM, 16 * WTN, KB, fast ? "" : "guarded, ", tiles, grid);
+    char buf[200];
+    snprintf(buf, sizeof buf, "%s, %ld tiles on %d persistent workgroups", what, tiles, grid);
     g_last_launch = buf;
   }
   return MMH_OK;
+}
+
+// ... of the register-staged tile config <BM, BN, WTN>
+template <int BM, int BN, int WTN, int WTM = 4, int KB = mmh::BK>
+int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, int lda,
+                       const float *B, int ldb, float *C, int ldc, int acc, hipStream_t s) {
+  if (!ctx || !ctx->streamk || !ctx->sticky_dev) return 1;
+  if (!window_ok(BM, BN, k, lda, ldb)) return 1;   // descriptor window
+  // whole, 16-byte-aligned shapes run the unguarded kernel; everything else the guarded one (partial
+  // tiles travel through a workspace, not through C, so C's alignment and ragged edges do not matter)
+  const bool fast = fast_shape(BM, BN, KB, m, n, k, A, lda, B, ldb, C, ldc);
+  constexpr size_t lds = lds_bytes(BM, BN, KB);
+  constexpr int threads = (BM / (16 * WTM)) * (BN / (16 * WTN)) * 64;
+  auto kern_fast = mmh::sgemm_mfma_streamk_kernel<BM, BN, false, WTN, WTM, KB>;
+  auto kern_edge = mmh::sgemm_mfma_streamk_kernel<BM, BN, true, WTN, WTM, KB>;
+  char what[160];
+  snprintf(what, sizeof what, "sgemm_mfma_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d%s", BM, BN, 16 * WTM,
+           16 * WTN, KB, fast ? "" : ", guarded");
+  return launch_streamk(ctx, fast ? kern_fast : kern_edge, kern_edge, BM, BN, threads, lds, what, m, n, k, A, lda, B, ldb,
+                        C, ldc, acc, s);
+}
+
+// ... of the LDS-DMA tile (sgemm_dma.hpp): whole-tile, 16-byte aligned shapes only
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
+int try_launch_streamk_dma(mmh_context *ctx, int m, int n, int k, const float *A, int lda, const float *B, int ldb,
+                           float *C, int ldc, int acc, hipStream_t s) {
+  using T = mmh::DmaTile<BM, BN, KB, WTM, WTN, NBUF>;
+  if (!ctx || !ctx->streamk || !ctx->sticky_dev) return 1;
+  if (!fast_shape(BM, BN, KB, m, n, k, A, lda, B, ldb, C, ldc) || !window_ok(BM, BN, k, lda, ldb)) return 1;
+  auto kern = mmh::sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF>;
+  char what[160];
+  snprintf(what, sizeof what, "sgemm_dma_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by LDS-DMA", BM,
+           BN, 16 * WTM, 16 * WTN, KB, NBUF);
+  return launch_streamk(ctx, kern, kern, BM, BN, T::THREADS, T::LDS_BYTES, what, m, n, k, A, lda, B, ldb, C, ldc, acc, s);
 }
 
 // Opt-in split-K launch (sgemm_mfma.hpp, K2s) of tile config <BM, BN, WTN> with S concurrent K parts.
@@ -349,6 +373,27 @@ int try_launch_splitk(mmh_context *ctx, int S, int m, int n, int k, const float 
              BM, BN, 16 * WTM, 16 * WTN, KB, tiles, S);
     g_last_launch = buf;
   }
+  return MMH_OK;
+}
+
+// K2L (sgemm_dma.hpp): both operands by LDS-DMA.  Whole-tile, 16-byte aligned shapes inside the descriptor
+// window only; returns 1 when the shape does not qualify (the caller then runs the register-staged kernel).
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
+int try_launch_dma(int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int acc,
+                   hipStream_t s) {
+  using T = mmh::DmaTile<BM, BN, KB, WTM, WTN, NBUF>;
+  if (!fast_shape(BM, BN, KB, m, n, k, A, lda, B, ldb, C, ldc) || !window_ok(BM, BN, k, lda, ldb)) return 1;
+  const int nbm = m / BM, nbn = n / BN;
+  auto kern = mmh::sgemm_mfma_dma_kernel<BM, BN, KB, WTM, WTN, NBUF>;
+  const int ok = allow_big_lds(kern, T::LDS_BYTES);
+  if (ok != MMH_OK) return ok;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(T::THREADS), T::LDS_BYTES, s, m, n, k, A, lda, B, ldb, C,
+                     ldc, acc, nbm, nbn);
+  HIP_TRY(hipGetLastError());
+  char buf[176];
+  snprintf(buf, sizeof buf, "sgemm_mfma_dma_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by LDS-DMA, %d workgroups of %d threads",
+           BM, BN, 16 * WTM, 16 * WTN, KB, NBUF, nbm * nbn, T::THREADS);
+  g_last_launch = buf;
   return MMH_OK;
 }
 
@@ -462,6 +507,21 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
           if (sk <= 0) return sk;
         }
       }
+      // Below one 256x256 tile per CU (N < 4096 on the reference sweep) whole-tile, 16-byte aligned
+      // shapes run on the LDS-DMA tiles (sgemm_dma.hpp) -- the largest of 128x128 / 128x64 / 64x64 that
+      // still gives (nearly) every CU a tile, measured on the sweep (profiles/r02_sweep.md): 128x128 from
+      // 0.85 tiles per CU up (N >= 1920), 128x64 from 0.78 of those per CU (N >= 1280), 64x64 below --
+      // each as a chained stream-K launch when its tile count leaves a round more than 7 % empty.
+      if (window_ok(128, 128, k, lda, ldb)) {
+        if (tiles128 * 100 >= cus * 85 && fast_shape(128, 128, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
+          return sgemm_on(ctx, MMH_KERNEL_MFMA_128X128_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+        if (tiles128 < cus) {
+          if (tiles128x64 * 100 >= cus * 78 && fast_shape(128, 64, 64, m, n, k, dA, lda, dB, ldb, dC, ldc))
+            return sgemm_on(ctx, MMH_KERNEL_MFMA_128X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+          if (fast_shape(64, 64, 64, m, n, k, dA, lda, dB, ldb, dC, ldc))
+            return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+        }
+      }
       if (tiles128x64 * 2 <= cus)
         return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
       if (tiles128 * 10 < cus * 8)
@@ -490,6 +550,27 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       const int sk = try_launch_streamk<128, 64, 2>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
       if (sk <= 0) return sk;
       return launch_mfma<128, 64, false, 4, 0, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    }
+    case MMH_KERNEL_MFMA_64X64_DMA: {   // K2L: 64x64 tile, both operands by LDS-DMA, 3 ring buffers of 64-deep slices
+      const int sk = try_launch_streamk_dma<64, 64, 64, 2, 2, 3>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      const int d = try_launch_dma<64, 64, 64, 2, 2, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (d <= 0) return d;
+      return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+    }
+    case MMH_KERNEL_MFMA_128X64_DMA: {  // K2L on the 128x64 tile (4 waves of 64x32)
+      const int sk = try_launch_streamk_dma<128, 64, 64, 4, 2, 3>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      const int d = try_launch_dma<128, 64, 64, 4, 2, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (d <= 0) return d;
+      return sgemm_on(ctx, MMH_KERNEL_MFMA_128X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+    }
+    case MMH_KERNEL_MFMA_128X128_DMA: {  // K2L on the 128x128 tile (4 waves of 64x64), 32-deep slices
+      const int sk = try_launch_streamk_dma<128, 128, 32, 4, 4, 3>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      const int d = try_launch_dma<128, 128, 32, 4, 4, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (d <= 0) return d;
+      return sgemm_on(ctx, MMH_KERNEL_MFMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
     }
     case MMH_KERNEL_MFMA_SPLITK: {   // K2s forced: 128x128 tiles, ctx->splitk parts (auto when <= 1)
       int S = ctx ? ctx->splitk : 0;
@@ -924,6 +1005,9 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_128X64: return "MMult_hip_mfma_128x64";
     case MMH_KERNEL_MFMA_64X64: return "MMult_hip_mfma_64x64";
     case MMH_KERNEL_MFMA_256X256: return "MMult_hip_mfma_256x256";
+    case MMH_KERNEL_MFMA_64X64_DMA: return "MMult_hip_mfma_64x64_dma";
+    case MMH_KERNEL_MFMA_128X64_DMA: return "MMult_hip_mfma_128x64_dma";
+    case MMH_KERNEL_MFMA_128X128_DMA: return "MMult_hip_mfma_128x128_dma";
     case MMH_KERNEL_MFMA_SPLITK: return "MMult_hip_mfma_splitk";
     case MMH_KERNEL_MFMA_SPLITK_128X64: return "MMult_hip_mfma_splitk_128x64";
 #ifdef MMH_AB_BUILD
@@ -1064,11 +1148,10 @@ int mmh_quantize_sym_s8(mmh_handle_t h, int rows, int cols, const float *dX, int
   unsigned *amax = static_cast<unsigned *>(h->qs.p) + 2 * mmh::AMAX_WORDS + 16;
   HIP_TRY(hipMemsetAsync(amax, 0, 2 * mmh::AMAX_WORDS * sizeof(unsigned), s));
   const mmh::QuantTensor t{dX, rows, cols, ldx, dQ, ldq}, none{nullptr, 0, 0, 0, nullptr, 0};
-  const dim3 g(mmh::quant_rows_grid(rows, 0), 1), gmax(mmh::quant_rows_grid(rows, 0, 2048), 1);
-  hipLaunchKernelGGL(mmh::absmax_kernel, gmax, dim3(256), 0, s, t, none, mmh::quant_vec_ok(t, false) ? 1 : 0, 0,
-                     amax);
-  hipLaunchKernelGGL(mmh::quantize_kernel, g, dim3(256), 0, s, t, none, mmh::quant_vec_ok(t, true) ? 1 : 0, 0, amax,
-                     d_scale);
+  const bool v_in = mmh::quant_vec_ok(t, false), v_out = mmh::quant_vec_ok(t, true);
+  hipLaunchKernelGGL(mmh::absmax_kernel, dim3(mmh::quant_grid(t, v_in), 1), dim3(256), 0, s, t, none, v_in ? 1 : 0, 0, amax);
+  hipLaunchKernelGGL(mmh::quantize_kernel, dim3(mmh::quant_grid(t, v_out), 1), dim3(256), 0, s, t, none, v_out ? 1 : 0, 0,
+                     amax, d_scale);
   HIP_TRY(hipGetLastError());
   return MMH_OK;
 }
@@ -1097,11 +1180,12 @@ int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
   HIP_TRY(hipMemsetAsync(amax, 0, 2 * mmh::AMAX_WORDS * sizeof(unsigned), s));
   // A and B share one abs-max launch and one quantisation launch (blockIdx.y picks the tensor)
   const mmh::QuantTensor ta{dA, m, k, lda, qa, ka}, tb{dB, k, n, ldb, qb, nb};
-  const dim3 g(mmh::quant_rows_grid(m, k), 2), gmax(mmh::quant_rows_grid(m, k, 2048), 2);
-  hipLaunchKernelGGL(mmh::absmax_kernel, gmax, dim3(256), 0, s, ta, tb, mmh::quant_vec_ok(ta, false) ? 1 : 0,
-                     mmh::quant_vec_ok(tb, false) ? 1 : 0, amax);
-  hipLaunchKernelGGL(mmh::quantize_kernel, g, dim3(256), 0, s, ta, tb, mmh::quant_vec_ok(ta, true) ? 1 : 0,
-                     mmh::quant_vec_ok(tb, true) ? 1 : 0, amax, scales);
+  const bool va_in = mmh::quant_vec_ok(ta, false), vb_in = mmh::quant_vec_ok(tb, false);
+  const bool va_out = mmh::quant_vec_ok(ta, true), vb_out = mmh::quant_vec_ok(tb, true);
+  const dim3 gmax(std::max(mmh::quant_grid(ta, va_in), mmh::quant_grid(tb, vb_in)), 2);
+  const dim3 g(std::max(mmh::quant_grid(ta, va_out), mmh::quant_grid(tb, vb_out)), 2);
+  hipLaunchKernelGGL(mmh::absmax_kernel, gmax, dim3(256), 0, s, ta, tb, va_in ? 1 : 0, vb_in ? 1 : 0, amax);
+  hipLaunchKernelGGL(mmh::quantize_kernel, g, dim3(256), 0, s, ta, tb, va_out ? 1 : 0, vb_out ? 1 : 0, amax, scales);
   const int cus = h->cu_count > 0 ? h->cu_count : 256;
   if (h->igemm_mode == 0 && mmh::igemm_s8_inplace_ok(qa, ka, qb, nb, k)) {
     // the int8 GEMM dequantises in its epilogue: no int32 image of C at all

@@ -165,42 +165,34 @@ inline int probe_mfma_i8(int cu_count, float *tops, std::string *err, int random
 }
 
 // -------------------------------------------------------------- HBM probe --
-// Stream copy with the memory-level parallelism a streaming kernel needs on this part: every thread
-// keeps FOUR 16-byte loads in flight per trip (issued before the first store), non-temporal on both
-// sides (the data is touched once), 8 workgroups per CU.  The guide's reference figure for a float4
-// copy is 6.29 TB/s (MI355X_MICROARCH.md, chip-level parameters); the round-1 form of this probe
-// (one load in flight per thread) read 4.96.
+// Stream copy / read in the access pattern that streams fastest on this part (measured with
+// tools/probes/hbm_patterns.hip, profiles/r02_hbm_patterns.txt): every workgroup owns ONE contiguous
+// 16 KiB chunk -- thread t moves the float4s base + t + 256 j, j = 0..3, all four loads issued before
+// the first store -- and exits; the grid is as large as the buffer (65536 workgroups per GiB).  A
+// persistent grid-stride loop over the same buffer (the round-1 form of this probe, and of the
+// abs-max / quantise passes) reads 4.3-5.3 TB/s; the chunk form reads 6.3 TB/s for the copy (the
+// guide's figure for a float4 copy, MI355X_MICROARCH.md chip-level parameters) and 6.5 TB/s read-only.
+constexpr int PROBE_U = 4;   // float4 per thread
 __global__ void __launch_bounds__(256) probe_copy_kernel(const f32x4 *__restrict__ src,
                                                          f32x4 *__restrict__ dst, size_t n) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {
-    const f32x4 v0 = __builtin_nontemporal_load(src + i);
-    const f32x4 v1 = __builtin_nontemporal_load(src + i + stride);
-    const f32x4 v2 = __builtin_nontemporal_load(src + i + 2 * stride);
-    const f32x4 v3 = __builtin_nontemporal_load(src + i + 3 * stride);
-    __builtin_nontemporal_store(v0, dst + i);
-    __builtin_nontemporal_store(v1, dst + i + stride);
-    __builtin_nontemporal_store(v2, dst + i + 2 * stride);
-    __builtin_nontemporal_store(v3, dst + i + 3 * stride);
-  }
-  for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  const size_t base = (size_t)blockIdx.x * 256 * PROBE_U + threadIdx.x;
+  f32x4 v[PROBE_U];
+#pragma unroll
+  for (int j = 0; j < PROBE_U; ++j)
+    if (base + j * 256 < n) v[j] = __builtin_nontemporal_load(src + base + j * 256);
+#pragma unroll
+  for (int j = 0; j < PROBE_U; ++j)
+    if (base + j * 256 < n) __builtin_nontemporal_store(v[j], dst + base + j * 256);
 }
 
-// Read-only twin (what an abs-max style reduction can reach): eight loads in flight per thread.
+// Read-only twin (what an abs-max style reduction can reach).
 __global__ void __launch_bounds__(256) probe_read_kernel(const f32x4 *__restrict__ src, float *__restrict__ out,
                                                          size_t n) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * 256 * PROBE_U + threadIdx.x;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (; i + 7 * stride < n; i += 8 * stride) {
-    f32x4 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = src[i + j * stride];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += v[j];
-  }
-  for (; i < n; i += stride) s += src[i];
+  for (int j = 0; j < PROBE_U; ++j)
+    if (base + j * 256 < n) s += src[base + j * 256];
   if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];   // keep the loads live
 }
 
@@ -218,8 +210,9 @@ inline int probe_hbm_copy(size_t bytes, float *gbps, std::string *err, int cu_co
   hipEvent_t t0, t1;
   MMH_HIP_TRY(hipEventCreate(&t0), err);
   MMH_HIP_TRY(hipEventCreate(&t1), err);
-  if (cu_count <= 0) cu_count = 256;
-  const int blocks = cu_count * 8, reps = 10;
+  (void)cu_count;
+  const unsigned blocks = (unsigned)((n + 256 * PROBE_U - 1) / (256 * PROBE_U));
+  const int reps = 10;
   auto launch = [&] {
     if (mode == 0) hipLaunchKernelGGL(probe_copy_kernel, dim3(blocks), dim3(256), 0, 0, src, dst, n);
     else hipLaunchKernelGGL(probe_read_kernel, dim3(blocks), dim3(256), 0, 0, src, reinterpret_cast<float *>(dst), n);

@@ -8,10 +8,9 @@
 //   q     = clamp(rint(x * scale), -127, 127)          round-half-even, never -128;
 //                           NaN -> 0, +-inf -> +-127 (non-finite inputs never poison the scale)
 //   C_f32 = (float)acc_i32 * (1 / (scale_a * scale_b))
-// The kernels are HBM-bound streaming passes: rows to workgroups, 16-byte loads (eight in flight per
-// thread in the abs-max pass), one atomic per workgroup for the abs-max, spread over AMAX_WORDS words
-// per tensor so that thousands of workgroups do not serialise on one; A and B of a quantised GEMM
-// share one launch each.  The dequantisation
+// The kernels are HBM-bound streaming passes: QG contiguous 16 KiB row chunks per workgroup, 16-byte loads, one
+// atomic per workgroup for the abs-max, spread over AMAX_WORDS words per tensor so that thousands of
+// workgroups do not serialise on one; A and B of a quantised GEMM share one launch each.  The dequantisation
 // normally runs inside the int8 GEMM's epilogue (igemm_s8.hpp, `deq`); dequantize_kernel is the
 // stand-alone form.
 #pragma once
@@ -42,33 +41,67 @@ struct QuantTensor {
   int ldq;
 };
 
-// Rows are dealt out to workgroups, columns to threads: no division per element, and when the rows
-// are 16-byte aligned (`vec`: x 16-byte aligned, ld % 4 == 0) four columns per float4 load.
+// Access pattern (both passes): with 16-byte aligned rows (`vec`: x 16-byte aligned, ld % 4 == 0) every
+// workgroup owns QG consecutive 16 KiB chunks of the tensor (a chunk = 256 threads x QU float4 of one
+// row) and walks them with the loads of chunk g+1 issued before chunk g is consumed; the grid is as
+// large as the tensor needs and nobody loops further.  Contiguous chunks per workgroup are what streams
+// fastest on this part (tools/probes/hbm_patterns.hip: 6.0-6.5 TB/s against 5.0 for a persistent
+// grid-stride loop); QG > 1 because a workgroup that lives for ONE 16 KiB chunk spends as long in its
+// reduction / scale prologue as in its loads (measured: 35 us for the 134 MB abs-max pass of a 4096^3
+// quantised GEMM with QG = 1, 26.8 us for the round-1 row loop).  Unaligned tensors take the scalar row loop.
+constexpr int QU = 4;                    // float4 per thread and chunk
+constexpr int QCHUNK = 256 * QU;         // float4 per chunk
+constexpr int QG = 4;                    // chunks per workgroup
+
+__host__ __device__ inline int quant_chunks_per_row(int cols) { return (cols / 4 + QCHUNK - 1) / QCHUNK; }
+
+// chunk `id` (0 .. rows * cpr - 1) of tensor t -> its row pointer offset and first float4 column of this thread
+struct QuantChunk {
+  int row, c0;
+  bool live;
+};
+__device__ __forceinline__ QuantChunk quant_chunk(const QuantTensor &t, int cpr, long id) {
+  QuantChunk q;
+  q.row = (int)(id / cpr);
+  q.c0 = (int)(id - (long)q.row * cpr) * QCHUNK + threadIdx.x;
+  q.live = q.row < t.rows;
+  return q;
+}
+__device__ __forceinline__ void quant_load(const QuantTensor &t, const QuantChunk &q, int c4, qf32x4 (&v)[QU]) {
+  const float *row = t.x + (size_t)q.row * t.ld;
+#pragma unroll
+  for (int j = 0; j < QU; ++j)
+    v[j] = (q.live && q.c0 + 256 * j < c4) ? *reinterpret_cast<const qf32x4 *>(row + 4 * (q.c0 + 256 * j))
+                                            : qf32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 __global__ void __launch_bounds__(256) absmax_kernel(QuantTensor ta, QuantTensor tb, int vec_a, int vec_b,
                                                      unsigned *__restrict__ out_bits) {
   const QuantTensor t = blockIdx.y ? tb : ta;
   const bool vec = blockIdx.y ? vec_b : vec_a;
   float best = 0.0f;
-  const int c4 = vec ? t.cols / 4 : 0;
-  for (int r = blockIdx.x; r < t.rows; r += gridDim.x) {
-    const float *row = t.x + (size_t)r * t.ld;
-    int c = threadIdx.x;
-    for (; c + 1792 < c4; c += 2048) {   // eight independent 16-byte loads in flight per thread
-      qf32x4 v[8];
+  if (vec) {
+    const int c4 = t.cols / 4, cpr = quant_chunks_per_row(t.cols);
+    const long first = (long)blockIdx.x * QG;
+    if (first >= (long)t.rows * cpr) return;
+    qf32x4 cur[QU], nxt[QU];
+    quant_load(t, quant_chunk(t, cpr, first), c4, cur);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const qf32x4 *>(row + 4 * (c + 256 * j));
+    for (int g = 0; g < QG; ++g) {
+      const QuantChunk q = quant_chunk(t, cpr, first + g);
+      if (g + 1 < QG) quant_load(t, quant_chunk(t, cpr, first + g + 1), c4, nxt);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) best = fmaxf(best, abs4(v[j]));
+      for (int j = 0; j < QU; ++j) best = fmaxf(best, abs4(cur[j]));
+      if (q.live && q.c0 - (int)threadIdx.x == 0)       // first chunk of a row: the (< 4) columns past the float4s
+        for (int c = 4 * c4 + threadIdx.x; c < t.cols; c += 256) best = fmaxf(best, finite_abs(t.x[(size_t)q.row * t.ld + c]));
+#pragma unroll
+      for (int j = 0; j < QU; ++j) cur[j] = nxt[j];
     }
-    for (; c + 768 < c4; c += 1024) {    // four
-      qf32x4 v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const qf32x4 *>(row + 4 * (c + 256 * j));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) best = fmaxf(best, abs4(v[j]));
+  } else {
+    for (int r = blockIdx.x; r < t.rows; r += gridDim.x) {
+      const float *row = t.x + (size_t)r * t.ld;
+      for (int c = threadIdx.x; c < t.cols; c += 256) best = fmaxf(best, finite_abs(row[c]));
     }
-    for (; c < c4; c += 256) best = fmaxf(best, abs4(*reinterpret_cast<const qf32x4 *>(row + 4 * c)));
-    for (c = 4 * c4 + threadIdx.x; c < t.cols; c += 256) best = fmaxf(best, finite_abs(row[c]));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_down(best, off, 64));
@@ -77,8 +110,9 @@ __global__ void __launch_bounds__(256) absmax_kernel(QuantTensor ta, QuantTensor
   __syncthreads();
   if (threadIdx.x == 0) {
     best = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-    // non-negative floats order like their bits; AMAX_WORDS words per tensor share the arrivals
-    atomicMax(out_bits + blockIdx.y * AMAX_WORDS + (blockIdx.x % AMAX_WORDS), __float_as_uint(best));
+    // non-negative floats order like their bits; AMAX_WORDS words per tensor share the arrivals, and a
+    // workgroup whose maximum is 0 has nothing to say
+    if (best > 0.0f) atomicMax(out_bits + blockIdx.y * AMAX_WORDS + (blockIdx.x % AMAX_WORDS), __float_as_uint(best));
   }
 }
 
@@ -98,25 +132,49 @@ __device__ __forceinline__ int quantize_one(float x, float scale) {
 }
 
 // `vec`: additionally q 4-byte aligned and ldq % 4 == 0 -> one dword of four int8 per float4.
+__device__ __forceinline__ unsigned quantize4(qf32x4 v, float scale) {
+  return (unsigned)(quantize_one(v[0], scale) & 255) | ((unsigned)(quantize_one(v[1], scale) & 255) << 8) |
+         ((unsigned)(quantize_one(v[2], scale) & 255) << 16) | ((unsigned)(quantize_one(v[3], scale) & 255) << 24);
+}
+
 __global__ void __launch_bounds__(256) quantize_kernel(QuantTensor ta, QuantTensor tb, int vec_a, int vec_b,
                                                        const unsigned *__restrict__ amax_bits,
                                                        float *__restrict__ scale_out) {
   const QuantTensor t = blockIdx.y ? tb : ta;
   const bool vec = blockIdx.y ? vec_b : vec_a;
-  const float scale = quant_scale(amax_bits, blockIdx.y);
-  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[blockIdx.y] = scale;
-  const int c4 = vec ? t.cols / 4 : 0;
-  for (int r = blockIdx.x; r < t.rows; r += gridDim.x) {
-    const float *row = t.x + (size_t)r * t.ld;
-    int8_t *qrow = t.q + (size_t)r * t.ldq;
-    for (int c = threadIdx.x; c < c4; c += 256) {
-      const qf32x4 v = *reinterpret_cast<const qf32x4 *>(row + 4 * c);
-      const unsigned w = (unsigned)(quantize_one(v[0], scale) & 255) | ((unsigned)(quantize_one(v[1], scale) & 255) << 8) |
-                         ((unsigned)(quantize_one(v[2], scale) & 255) << 16) |
-                         ((unsigned)(quantize_one(v[3], scale) & 255) << 24);
-      *reinterpret_cast<unsigned *>(qrow + 4 * c) = w;
+  if (vec) {
+    const int c4 = t.cols / 4, cpr = quant_chunks_per_row(t.cols);
+    const long first = (long)blockIdx.x * QG;
+    qf32x4 cur[QU], nxt[QU];
+    const bool any = first < (long)t.rows * cpr;
+    if (any) quant_load(t, quant_chunk(t, cpr, first), c4, cur);   // the first loads go out before the scale is needed
+    const float scale = quant_scale(amax_bits, blockIdx.y);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[blockIdx.y] = scale;
+    if (!any) return;
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      const QuantChunk q = quant_chunk(t, cpr, first + g);
+      if (g + 1 < QG) quant_load(t, quant_chunk(t, cpr, first + g + 1), c4, nxt);
+      if (q.live) {
+        int8_t *qrow = t.q + (size_t)q.row * t.ldq;
+#pragma unroll
+        for (int j = 0; j < QU; ++j)
+          if (q.c0 + 256 * j < c4) *reinterpret_cast<unsigned *>(qrow + 4 * (q.c0 + 256 * j)) = quantize4(cur[j], scale);
+        if (q.c0 - (int)threadIdx.x == 0)
+          for (int c = 4 * c4 + threadIdx.x; c < t.cols; c += 256)
+            qrow[c] = (int8_t)quantize_one(t.x[(size_t)q.row * t.ld + c], scale);
+      }
+#pragma unroll
+      for (int j = 0; j < QU; ++j) cur[j] = nxt[j];
     }
-    for (int c = 4 * c4 + threadIdx.x; c < t.cols; c += 256) qrow[c] = (int8_t)quantize_one(row[c], scale);
+  } else {
+    const float scale = quant_scale(amax_bits, blockIdx.y);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[blockIdx.y] = scale;
+    for (int r = blockIdx.x; r < t.rows; r += gridDim.x) {
+      const float *row = t.x + (size_t)r * t.ld;
+      int8_t *qrow = t.q + (size_t)r * t.ldq;
+      for (int c = threadIdx.x; c < t.cols; c += 256) qrow[c] = (int8_t)quantize_one(row[c], scale);
+    }
   }
 }
 
@@ -124,10 +182,15 @@ inline bool quant_vec_ok(const QuantTensor &t, bool with_q) {
   return ((reinterpret_cast<uintptr_t>(t.x) & 15) == 0) && (t.ld % 4 == 0) &&
          (!with_q || (((reinterpret_cast<uintptr_t>(t.q) & 3) == 0) && (t.ldq % 4 == 0)));
 }
-// workgroups per tensor: enough to fill the chip several times over, never more than rows.  The
-// abs-max pass ends in one atomicMax per workgroup (8192 of them on ONE word serialised into ~80 us
-// at N = 4096; they are spread over AMAX_WORDS words and the pass runs with `cap` = 2048).
-inline unsigned quant_rows_grid(int rows_a, int rows_b, int cap = 4096) {
+// grid.x of a pass over (up to) two tensors: one workgroup per QG 16 KiB row chunks for aligned tensors, a
+// few thousand row-striding workgroups for unaligned ones; the larger of the two counts (surplus
+// workgroups of the smaller tensor exit at once)
+inline unsigned quant_grid(const QuantTensor &t, bool vec) {
+  if (t.rows <= 0 || t.cols <= 0) return 1;
+  if (vec) return (unsigned)(((long)t.rows * quant_chunks_per_row(t.cols) + QG - 1) / QG);
+  return (unsigned)(t.rows < 4096 ? t.rows : 4096);
+}
+inline unsigned quant_rows_grid(int rows_a, int rows_b, int cap = 4096) {   // dequantize_kernel's row loop
   const int r = rows_a > rows_b ? rows_a : rows_b;
   return (unsigned)(r < 1 ? 1 : (r < cap ? r : cap));
 }

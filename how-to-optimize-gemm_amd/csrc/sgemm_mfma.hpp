@@ -26,6 +26,7 @@
 #pragma once
 #include <type_traits>
 
+#include "sgemm_dma.hpp"
 #include "sgemm_tile.hpp"
 
 namespace mmh {
@@ -163,17 +164,6 @@ sgemm_mfma_simple_kernel(int m, int n, int k, const float *__restrict__ A, int l
 // Arithmetic order per C element is unchanged (ascending k), so the result is
 // bit-identical to the simple kernel and to the fmaf-chain oracle.
 // ---------------------------------------------------------------------------
-
-// What a split-K finisher adds to its accumulators before it stores the tile (sgemm_mfma_splitk_kernel):
-// `count` dense BM x BN partial tiles, `stride` floats apart, published by `count` arrivals on `*flag`.
-struct SplitFix {
-  const float *parts = nullptr;
-  size_t stride = 0;
-  int count = 0;
-  int *flag = nullptr;
-  int *err = nullptr;
-  long long spin_limit = 0;
-};
 
 template <int BM, int BN, bool EDGE, int SCHED, int ABL, bool BUFLD, int WTN = 4, int WTM = 4, int KB = BK,
           bool DMAB = false, bool PART_WT = false>
@@ -555,17 +545,33 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 // relaxed counter store; consumer = one lane relaxed poll (bounded), agent-scope
 // acquire fence, barrier, plain loads.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool EDGE, int WTN = 4, int WTM = 4, int KB = BK>
-__global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)
-sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
-                          const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
-                          int accumulate, int nbm, int nbn, int *__restrict__ flags,
-                          int *__restrict__ err, float *__restrict__ parts, long long spin_limit, int fault) {
+// The stream-K control flow is written once, over a SEGMENT policy -- how one (tile, K-slice range) is
+// computed: Seg::BM, BN, KB, THREADS and Seg::run(lds, ..., tm, tn, kb, ke, init_from_c, part_in,
+// part_out).  RegSeg = the register-staged tile code above; DmaSeg (sgemm_dma.hpp) = the LDS-DMA tile.
+template <int BM_, int BN_, bool EDGE, int WTN = 4, int WTM = 4, int KB_ = BK>
+struct RegSeg {
+  static constexpr int BM = BM_, BN = BN_, KB = KB_;
+  static constexpr int THREADS = (BM / (16 * WTM)) * (BN / (16 * WTN)) * 64;
+  static __device__ __forceinline__ void run(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
+                                             const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                                             int tm, int tn, int kb, int ke, bool init_from_c, const float *part_in,
+                                             float *part_out) {
+    mfma_tile_segment<BM, BN, EDGE, 4, 0, true, WTN, WTM, KB>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke,
+                                                              init_from_c, part_in, part_out);
+  }
+};
+
+template <class Seg>
+__device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
+                                             const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                                             int accumulate, int nbm, int nbn, int *__restrict__ flags,
+                                             int *__restrict__ err, float *__restrict__ parts, long long spin_limit,
+                                             int fault) {
   // err: the handle's STICKY error word (host-mapped): a hand-off wait that runs into `spin_limit`
   // adds to it and the workgroup stops -- it never continues a chain from a slot that was not
   // published -- and every later mmh_* call on the handle fails until the word is cleared.
   // fault != 0 (MMH_OPT_FAULT_INJECT, tests): producers do not publish, so every consumer times out.
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = Seg::BM, BN = Seg::BN, KB = Seg::KB;
   const int nk = (k + KB - 1) / KB;
   const int T = nbm * nbn, G = gridDim.x;
   // XCD-contiguous ranges: workgroup p (on XCD p % 8) takes range index q
@@ -619,9 +625,7 @@ sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
     // no alignment and tiles that share cache lines at ragged edges never exchange data through them
     const float *part_in = kb > 0 ? parts + (size_t)(q - 1) * BM * BN : nullptr;
     float *part_out = ke < nk ? parts + (size_t)q * BM * BN : nullptr;
-    mfma_tile_segment<BM, BN, EDGE, 4, 0, true, WTN, WTM, KB>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn,
-                                                              kb, ke, kb == 0 && accumulate != 0, part_in,
-                                                              part_out);
+    Seg::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke, kb == 0 && accumulate != 0, part_in, part_out);
     if (ke < nk) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -642,6 +646,28 @@ sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
   for (int t = t_first + (first_partial ? 1 : 0); t <= t_last - (last_partial ? 1 : 0); ++t)
     if (!run(t, 0, nk)) return;                                          // 2. whole tiles
   if (first_partial) run(t_first, k_first, nk);                           // 3. rest of the first tile
+}
+
+template <int BM, int BN, bool EDGE, int WTN = 4, int WTM = 4, int KB = BK>
+__global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)
+sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
+                          const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                          int accumulate, int nbm, int nbn, int *__restrict__ flags,
+                          int *__restrict__ err, float *__restrict__ parts, long long spin_limit, int fault) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  streamk_body<RegSeg<BM, BN, EDGE, WTN, WTM, KB>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn, flags, err,
+                                                   parts, spin_limit, fault);
+}
+
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
+__global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64)
+sgemm_dma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B,
+                         int ldb, float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn,
+                         int *__restrict__ flags, int *__restrict__ err, float *__restrict__ parts,
+                         long long spin_limit, int fault) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  streamk_body<DmaSeg<BM, BN, KB, WTM, WTN, NBUF>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn, flags,
+                                                   err, parts, spin_limit, fault);
 }
 
 // ---------------------------------------------------------------------------

@@ -100,6 +100,17 @@ __device__ __forceinline__ void block_to_tile(int bid, int nblk, int nbm, int nb
   tn = in_group / gsize;
 }
 
+// What a split-K finisher adds to its accumulators before it stores the tile (sgemm_mfma_splitk_kernel):
+// `count` dense BM x BN partial tiles, `stride` floats apart, published by `count` arrivals on `*flag`.
+struct SplitFix {
+  const float *parts = nullptr;
+  size_t stride = 0;
+  int count = 0;
+  int *flag = nullptr;
+  int *err = nullptr;
+  long long spin_limit = 0;
+};
+
 // ---------------------------------------------------------------------------
 // Staging registers for one K-slice of a BM x BK A panel and BK x BN B panel,
 // THREADS threads.  Each thread owns A_BLKS 4x4 blocks of A and B_VECS float4

@@ -60,7 +60,8 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_ERR_COMM (-6)        /* RCCL call failed                             */
 
 /* kernel variants (the reference's "NEW := MMult_xxx" ladder, MI355X edition) */
-#define MMH_KERNEL_AUTO 0        /* 64x64 / 128x64 / 128x128 / 256x256 tiles chosen by how the shape fills the chip */
+#define MMH_KERNEL_AUTO 0        /* 64x64 / 128x64 / 128x128 (LDS-DMA or register-staged) / 256x256 tiles chosen by how
+                                    the shape fills the chip */
 #define MMH_KERNEL_VALU 1        /* K1: LDS-tiled, VALU fma only: 128x128 tile (8x8 per thread) from one
                                     tile per CU up, the 64x64 tile (4x4 per thread) below         */
 #define MMH_KERNEL_VALU_128X128 13 /* K1 with the 128x128 tile always (the rung BASELINE config 2 names) */
@@ -79,6 +80,14 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_128X64 8 /* K2 with a 128x64 block tile, 4 waves of 64x32                   */
 #define MMH_KERNEL_MFMA_256X256 12 /* K2 with a 256x256 block tile, 8 waves of 128x64 (1 WG/CU)       */
 #define MMH_KERNEL_MFMA_64X64 11 /* K2 with a 64x64 block tile, 4 waves of 32x32, 128-deep K-slices  */
+/* K2L (sgemm_dma.hpp): tiles fed entirely by LDS-DMA (buffer_load ... lds for both operands, a ring of
+ * three K-slice buffers, counted vmcnt waits, no registers -> LDS stores at all) -- the register-staged
+ * packing stage is what bounds the small tiles.  Same chain, same bits; what MMH_KERNEL_AUTO runs on
+ * whole-tile 16-byte-aligned shapes below one 256x256 tile per CU (stream-K for ragged tile counts);
+ * anything else runs the register-staged kernel of the same tile. */
+#define MMH_KERNEL_MFMA_64X64_DMA 25
+#define MMH_KERNEL_MFMA_128X64_DMA 27
+#define MMH_KERNEL_MFMA_128X128_DMA 28
 /* OPT-IN split-K (sgemm_mfma.hpp K2s): the K range of every tile runs as S concurrent parts whose
  * partial tiles are summed in part order.  Deterministic, inside the reference harness's tolerance,
  * but NOT the one-chain-per-element bits every other variant returns; never chosen unless asked for
@@ -110,7 +119,9 @@ int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
  * Calls on ONE stream through one handle are ordered by the stream (as cublasHandle_t with
  * cublasSetStream); a stream-K / split-K launch on ANOTHER stream than the previous one first waits
  * for that stream (so the hand-off workspaces are never in use twice), which costs the overlap --
- * use one handle per stream that should run concurrently.  Every entry point runs on the handle's
+ * use one handle per stream that should run concurrently.  A launch captured into a hipGraph is
+ * recorded without that wait (nothing may synchronise during capture): a graph that contains
+ * stream-K launches owns the handle's workspaces while it runs, like any buffer it was captured with.  Every entry point runs on the handle's
  * device and restores the caller's current device before it returns. */
 int mmh_create(mmh_handle_t *handle, int device);
 int mmh_destroy(mmh_handle_t handle);

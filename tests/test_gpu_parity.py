@@ -20,7 +20,7 @@ from conftest import golden_cases, load_golden
 pytestmark = pytest.mark.gpu
 
 KERNELS = ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "auto", "mfma_pipe", "mfma_simple", "valu",
-           "valu_128x128", "valu_64x64", "naive"]
+           "valu_128x128", "valu_64x64", "naive", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma"]
 
 
 def tol(k):
@@ -87,6 +87,68 @@ def test_seeded_inputs_vs_oracle(mm, oracle, shape, kernel):
     got = mm.matmul(dev(a), dev(b)).cpu().numpy()
     assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
     assert oracle.compare_matrices(got, oracle.ref_mmult(a, b, fma=False))[0] <= tol(k)
+
+
+@pytest.mark.parametrize("kernel", ["mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma"])
+def test_lds_dma_small_tile_kernel_is_the_same_chain(mm, oracle, kernel):
+    """K2L (sgemm_dma.hpp): both operands by LDS-DMA into a ring of K-slice buffers, A as a ROW-major
+    image read with ds_read2st64_b32.  Same MFMA, same k order -> the oracle's bits, for one slice, for
+    slice counts on every phase of the ring (1 .. 7, 16, 18 slices of 64), overwrite and accumulate;
+    shapes it does not take (ragged, k not a multiple of 64) fall back to the register-staged kernel."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    mm.set_kernel(kernel)
+    bm = 128 if "128x" in kernel else 64
+    bn = 128 if "x128" in kernel else 64
+    for (m, n, k) in [(bm, bn, 64), (bm, bn, 128), (bm, 2 * bn, 192), (2 * bm, 3 * bn, 256), (256, 256, 320), (128, 128, 384),
+                      (128, bn, 448), (1024, 1024, 1024), (1152, 1152, 1152), (256, 2048, 64), (128, bn, 4096),
+                      (bm, bn, 32 if bn == 128 else 64), (bm, bn, 96 if bn == 128 else 192)]:
+        a, b = oracle.harness_inputs(m, n, k, seed=m + 3 * n + 5 * k)
+        got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+        assert "LDS-DMA" in H.last_launch(), (m, n, k, H.last_launch())     # plain or stream-K launch of the DMA tile
+        assert mm.streamk_timeouts() == 0
+        want = oracle.ref_mmult(a, b, fma=True)
+        assert np.array_equal(got, want), (kernel, m, n, k, float(np.abs(got - want).max()))
+        c0 = np.random.default_rng(k).uniform(-1, 1, (m, n)).astype(np.float32)
+        out = dev(c0)
+        mm.matmul(dev(a), dev(b), out=out, accumulate=True)
+        assert np.array_equal(out.cpu().numpy(), oracle.ref_mmult(a, b, c0.copy(), fma=True)), (kernel, m, n, k)
+    # views with leading dimensions larger than the rows (multiples of 4 floats keep it on the DMA path)
+    a, b = oracle.harness_inputs(256, 384, 128, seed=3)
+    abuf = torch.zeros((256, 136), device="cuda")
+    bbuf = torch.zeros((128, 388), device="cuda")
+    cbuf = torch.full((256, 392), float("nan"), device="cuda")
+    abuf[:, :128] = dev(a)
+    bbuf[:, :384] = dev(b)
+    mm.matmul(abuf[:, :128], bbuf[:, :384], out=cbuf[:, :384])
+    assert "LDS-DMA" in H.last_launch()
+    assert np.array_equal(cbuf[:, :384].cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
+    assert torch.isnan(cbuf[:, 384:]).all()
+    for (m, n, k) in [(130, 129, 37), (128, 128, 100), (1000, 1000, 1000)]:     # not taken: falls back, same bits
+        a, b = oracle.harness_inputs(m, n, k, seed=m)
+        got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+        assert "LDS-DMA" not in H.last_launch()
+        assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
+    # ragged tile counts: the same tile under the chained stream-K control flow, with and without
+    if True:
+        for (m, n, k) in [(1152, 1152, 512), (1536, 1536, 256), (1792, 1280, 192), (2176, 2176, 128), (2944, 2432, 64)]:
+            a, b = oracle.harness_inputs(m, n, k, seed=m + n)
+            da, db = dev(a), dev(b)
+            mm.set_streamk(True)
+            got = mm.matmul(da, db)
+            launched = H.last_launch()
+            c0 = torch.rand((m, n), device="cuda")
+            acc = c0.clone()
+            mm.matmul(da, db, out=acc, accumulate=True)
+            mm.set_streamk(False)
+            plain = mm.matmul(da, db)
+            assert "LDS-DMA" in H.last_launch() and "streamk" not in H.last_launch()
+            mm.set_streamk(True)
+            assert torch.equal(got, plain), (kernel, m, n, k, launched)
+            assert mm.streamk_timeouts() == 0
+            assert np.array_equal(got.cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
+            assert np.array_equal(acc.cpu().numpy(), oracle.ref_mmult(a, b, c0.cpu().numpy(), fma=True))
+
 
 
 def test_headline_size_4096(mm, oracle):

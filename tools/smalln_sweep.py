@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sizes", default="1024,1152,1280,1408,1536,1664,1792,1920,2048")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--reps", type=int, default=20)
-ap.add_argument("--variants", default="auto,mfma_64x64,mfma_128x64,mfma_tiles,mfma_splitk:0,mfma_splitk:2,mfma_splitk:3,"
+ap.add_argument("--variants", default="auto,mfma_64x64,mfma_64x64_dma,mfma_128x64,mfma_128x64_dma,mfma_tiles,mfma_splitk:0,mfma_splitk:2,mfma_splitk:3,"
                                        "mfma_splitk:4,mfma_splitk_128x64:2,mfma_splitk_128x64:4,auto:1,rocblas,hipblaslt,"
                                        "valu,valu_128x128,valu_64x64")
 args = ap.parse_args()
@@ -61,13 +61,16 @@ for n in sizes:
                 ms = timed(lambda: mm.matmul_rocblas(a, b, out=c), args.reps)
             else:
                 name, _, s = v.partition(":")
-                mm.set_kernel(name)
+                nosk = name.endswith("/nosk")            # name/nosk: the same kernel without stream-K
+                mm.set_kernel(name[:-5] if nosk else name)
+                mm.set_streamk(not nosk)
                 mm.set_splitk(int(s) if s else 0)
                 ms = mm.time_sgemm(n, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, warmup=5,
                                    reps=args.reps, stream=stream)
                 launch[v] = H.last_launch()
             res[v].append(2.0 * n ** 3 / (ms * 1e-3) / 1e12)
     mm.set_splitk(0)
+    mm.set_streamk(True)
     print(f"| {n} | " + " | ".join(f"{statistics.median(res[v]):.1f}" for v in variants) + " |", flush=True)
     if n == sizes[0]:
         for v in variants:
