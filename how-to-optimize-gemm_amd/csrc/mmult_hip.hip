@@ -460,8 +460,9 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
   const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
   switch (kernel) {
     case MMH_KERNEL_VALU:
-      // K1: the 128x128 rung while there is at least one such tile per CU, the 64x64 tile below
-      if (tiles128 < cus) return launch_valu_tile<64, 64, 64>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      // K1: the 128x128 rung from half a tile per CU up, the 64x64 tile below (measured, N = 1024 ..
+      // 2048: 33 / 54 TFLOP/s against 17 / 33 at N = 1024 / 1408, level at 1536, behind from 1664)
+      if (tiles128 * 2 <= cus) return launch_valu_tile<64, 64, 64>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
       return launch_valu_tile<128, 128, 32>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case MMH_KERNEL_VALU_128X128:
       return launch_valu_tile<128, 128, 32>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);

@@ -24,7 +24,7 @@
 //             of the 32 dword banks), 8 LDS cycles per read instead of 4;
 //   Bs[k][n]  as in the other kernels (BN floats per k-row); with 8-byte fragments (wave tiles 32
 //             columns wide) odd k-rows have their two halves swapped, again on the source side.
-// A ring of NBUF >= 3 K-slice buffers: while slice kt is consumed, the DMA pieces of slice kt + NBUF - 1
+// A ring of NBUF = 3 K-slice buffers: while slice kt is consumed, the DMA pieces of slice kt + NBUF - 1
 // are dealt out between its MFMAs (the buffer they land in was last read in slice kt - 1, and every
 // wave passed the barrier that ended that slice), and the wait before the barrier that ends slice kt is
 // a COUNTED `s_waitcnt vmcnt((NBUF - 2) * pieces)` -- never 0 in the steady state, the newest slices stay
@@ -35,6 +35,11 @@
 // other kernel here -- one fp32 fmaf chain per C element, bit-identical results.  Whole-tile,
 // 16-byte-aligned shapes only (a ragged K tail of A cannot be masked on its way into LDS); the
 // launcher sends everything else to the register-staged kernels.
+//
+// What was tried and dropped (profiles/r02_ablation.md): four ring buffers (no faster); a run-time ring
+// index instead of the unrolled ring (-17 %: an address v_add per fragment read); 8-wave tiles, 256x128
+// with three buffers and 256x256 with two -- under the 256-register budget they need the run-time
+// ring and then trail the register-staged 256x256 kernel (143-147 vs 149-150 TFLOP/s at N >= 4096).
 #pragma once
 #include <type_traits>
 
@@ -61,7 +66,7 @@ struct DmaTile {
   static_assert((WTM == 2 || WTM == 4) && (WTN == 2 || WTN == 4), "wave tile is 32|64 x 32|64");
   static_assert(KB == 32 || KB == 64 || KB == 128, "a K-slice row of A is 128, 256 or 512 bytes");
   static_assert(BN == 64 || BN == 128 || BN == 256, "a k-row of B is 256, 512 or 1024 bytes");
-  static_assert(NBUF >= 3, "the DMA of a later slice needs a buffer nobody reads");
+  static_assert(NBUF == 3, "a ring of three K-slice buffers");
   static constexpr int WAVES_M = BM / (16 * WTM), WAVES_N = BN / (16 * WTN), WAVES = WAVES_M * WAVES_N;
   static constexpr int THREADS = 64 * WAVES;
   static constexpr int A_FLOATS = BM * KB, B_FLOATS = KB * BN, STAGE = A_FLOATS + B_FLOATS;
@@ -77,12 +82,16 @@ struct DmaTile {
 };
 
 // One C tile (tm, tn), K-slices [kb, ke) of it; same contract as mfma_tile_segment (sgemm_mfma.hpp).
+// (A static member of a class template, not a function template: hipcc's host pass mishandles function
+// templates whose bodies hold buffer descriptors in generic lambdas -- igemm_s8.hpp has the same note --
+// and the 8-wave instantiations then fail to resolve from a second __global__ template.)
 template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool PART_WT = false>
-__device__ __forceinline__ void mfma_dma_segment(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
-                                                 const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
-                                                 int tm, int tn, int kb, int ke, bool init_from_c,
-                                                 const float *part_in = nullptr, float *part_out = nullptr,
-                                                 const SplitFix fix = SplitFix{}) {
+struct DmaSegment {
+static __device__ __forceinline__ void run(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
+                                           const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                                           int tm, int tn, int kb, int ke, bool init_from_c,
+                                           const float *part_in = nullptr, float *part_out = nullptr,
+                                           const SplitFix fix = SplitFix{}) {
   using T = DmaTile<BM, BN, KB, WTM, WTN, NBUF>;
   constexpr int KS = T::KS, STAGE = T::STAGE, A_FLOATS = T::A_FLOATS, CA = T::CA, CB = T::CB, ND = T::ND, LA = T::LA;
   typedef float bfrag_t __attribute__((ext_vector_type(WTN)));
@@ -195,10 +204,14 @@ __device__ __forceinline__ void mfma_dma_segment(float *lds, int m, int n, int k
 
   // One K-slice out of ring buffer CUR.  Branch-free and written in issue order (sched_barrier pins it:
   // with so few MFMAs per k-step the order IS the schedule): per k-step the two fragment reads for
-  // k-step ks + D, then the four MFMAs of k-step ks with at most one DMA piece of slice kt + LA behind
-  // the first of them (into the buffer slice kt-1 was read from).  The counted wait and the barrier sit
+  // k-step ks + D, then the MFMAs of k-step ks with at most a few DMA pieces of slice kt + LA behind the
+  // first of them (into the buffer slice kt-1 was read from).  The counted wait and the barrier sit
   // before k-step KS - D: from there on the reads go to the NEXT buffer, and every read of this one
-  // has been issued by every wave.
+  // has been issued by every wave.  The ring index is a compile-time constant (the slice loop below is
+  // unrolled over the ring): with a run-time index every fragment read needs a v_add for its address,
+  // and beside four MFMAs per k-step that costs 64x64 tiles 17 % (measured: 138 -> 115 TFLOP/s at
+  // 4096^3) -- the price is that the compiler renames the accumulators from slice to slice, which is
+  // why only the 4-wave tiles (one wave per SIMD, 512 registers) are built this way.
   auto slice = [&](int kt, auto cur_c) {
     constexpr int CUR = decltype(cur_c)::value, NXT = (CUR + 1) % NBUF, DST = (CUR + LA) % NBUF;
     const float *buf = lds + CUR * STAGE;
@@ -237,17 +250,13 @@ __device__ __forceinline__ void mfma_dma_segment(float *lds, int m, int n, int k
   };
   int kt = kb;
   for (;;) {
-    static_assert(NBUF == 3 || NBUF == 4, "the slice loop is unrolled over the ring (4 was measured: no faster)");
+    static_assert(NBUF == 3, "the slice loop is unrolled over a ring of three (four was measured: no faster)");
     slice(kt, std::integral_constant<int, 0>{});
     if (++kt >= ke) break;
     slice(kt, std::integral_constant<int, 1>{});
     if (++kt >= ke) break;
     slice(kt, std::integral_constant<int, 2>{});
     if (++kt >= ke) break;
-    if constexpr (NBUF == 4) {
-      slice(kt, std::integral_constant<int, 3>{});
-      if (++kt >= ke) break;
-    }
   }
   // keep the fragments prefetched past the last slice formally alive: otherwise the compiler sinks the
   // reads that follow each slice's barrier into the NEXT slice's block (they are dead on the exit path)
@@ -313,6 +322,7 @@ __device__ __forceinline__ void mfma_dma_segment(float *lds, int m, int n, int k
       }
     }
 }
+};
 
 // One workgroup per C tile (XCD-aware block -> tile map), whole K range.
 template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
@@ -322,7 +332,7 @@ sgemm_mfma_dma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int tm, tn;
   block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
-  mfma_dma_segment<BM, BN, KB, WTM, WTN, NBUF>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0, k / KB, accumulate != 0);
+  DmaSegment<BM, BN, KB, WTM, WTN, NBUF>::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0, k / KB, accumulate != 0);
 }
 
 // Segment policy of this tile for the chained stream-K control flow (streamk_body in sgemm_mfma.hpp,
@@ -336,8 +346,8 @@ struct DmaSeg {
                                              const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                              int tm, int tn, int kb, int ke, bool init_from_c, const float *part_in,
                                              float *part_out) {
-    mfma_dma_segment<BM, BN, KB, WTM, WTN, NBUF>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke, init_from_c,
-                                                 part_in, part_out);
+    DmaSegment<BM, BN, KB, WTM, WTN, NBUF>::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke, init_from_c, part_in,
+                                                part_out);
   }
 };
 

@@ -98,10 +98,9 @@ def test_lds_dma_small_tile_kernel_is_the_same_chain(mm, oracle, kernel):
     import torch
     import how_to_optimize_gemm_amd as H
     mm.set_kernel(kernel)
-    bm = 128 if "128x" in kernel else 64
-    bn = 128 if "x128" in kernel else 64
-    for (m, n, k) in [(bm, bn, 64), (bm, bn, 128), (bm, 2 * bn, 192), (2 * bm, 3 * bn, 256), (256, 256, 320), (128, 128, 384),
-                      (128, bn, 448), (1024, 1024, 1024), (1152, 1152, 1152), (256, 2048, 64), (128, bn, 4096),
+    bm, bn = (int(x) for x in kernel.split("_")[1].split("x"))
+    for (m, n, k) in [(bm, bn, 64), (bm, bn, 128), (bm, 2 * bn, 192), (2 * bm, 3 * bn, 256), (256, 256, 320), (bm, 256, 384),
+                      (bm, bn, 448), (1024, 1024, 1024), (1152 if bm <= 128 else 1280,) * 3, (256, 2048, 64), (bm, bn, 4096),
                       (bm, bn, 32 if bn == 128 else 64), (bm, bn, 96 if bn == 128 else 192)]:
         a, b = oracle.harness_inputs(m, n, k, seed=m + 3 * n + 5 * k)
         got = mm.matmul(dev(a), dev(b)).cpu().numpy()
@@ -124,14 +123,17 @@ def test_lds_dma_small_tile_kernel_is_the_same_chain(mm, oracle, kernel):
     assert "LDS-DMA" in H.last_launch()
     assert np.array_equal(cbuf[:, :384].cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
     assert torch.isnan(cbuf[:, 384:]).all()
-    for (m, n, k) in [(130, 129, 37), (128, 128, 100), (1000, 1000, 1000)]:     # not taken: falls back, same bits
+    for (m, n, k) in [(130, 129, 37), (256, 256, 100), (1000, 1000, 1000)]:     # not taken: falls back, same bits
         a, b = oracle.harness_inputs(m, n, k, seed=m)
         got = mm.matmul(dev(a), dev(b)).cpu().numpy()
         assert "LDS-DMA" not in H.last_launch()
         assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
     # ragged tile counts: the same tile under the chained stream-K control flow, with and without
     if True:
-        for (m, n, k) in [(1152, 1152, 512), (1536, 1536, 256), (1792, 1280, 192), (2176, 2176, 128), (2944, 2432, 64)]:
+        for (m, n, k) in [(1152, 1152, 512), (1536, 1536, 256), (1792, 1280, 192), (2176, 2176, 128), (2944, 2432, 64),
+                          (4352, 4352, 64)]:
+            if m % bm or n % bn:
+                continue
             a, b = oracle.harness_inputs(m, n, k, seed=m + n)
             da, db = dev(a), dev(b)
             mm.set_streamk(True)
@@ -248,7 +250,7 @@ def test_size_independent_properties_at_full_size(mm):
 
 
 @pytest.mark.parametrize("shape", [(2176, 2176, 2176), (3072, 3072, 1024), (2560, 3200, 512),
-                                   (2944, 2944, 2944), (3328, 2176, 96),
+                                   (2944, 2944, 2944), (3328, 2304, 96),
                                    # guarded stream-K: ragged edges, ragged K, odd leading dimensions
                                    (2049, 2049, 200), (2177, 2305, 333), (4097, 4095, 70)])
 def test_stream_k_is_bit_identical(mm, oracle, shape):
