@@ -38,6 +38,10 @@
 //                                (the cuda directory's oracle, cuda/REF_MMult.cpp:9-13), or not at
 //                                all (diff column is -1)
 //   WARMUP=<n>                 untimed launches before the timed loop (reference: 0)
+//   WARMUP_MS=<ms>             keep launching untimed until this many milliseconds have passed (the
+//                              sustained-clock form: between two sizes the driver spends seconds on
+//                              the host -- inputs, REF -- and the GPU falls back to its idle clock;
+//                              30 launches of a 0.1 ms kernel do not bring it back, 50 ms do)
 //   EXTENDED=1                 extra columns: pct_of_fp32_mfma_peak ref_gflops ref_cores
 #include <algorithm>
 #include <cmath>
@@ -61,7 +65,7 @@ struct Options {
   int m = sweep_defaults::kM, n = sweep_defaults::kN, k = sweep_defaults::kK;
   int nrepeats = sweep_defaults::kRepeats;
   int lda = sweep_defaults::kLda, ldb = sweep_defaults::kLdb, ldc = sweep_defaults::kLdc;
-  int warmup = 0, extended = 0, ngpus = 1, splitk = 0;
+  int warmup = 0, warmup_ms = 0, extended = 0, ngpus = 1, splitk = 0;
   std::string kernel = "auto", flavour = "device", input = "drand48", ref = "threads";
 };
 
@@ -119,6 +123,7 @@ int main(int argc, char **argv) {
   opt_int(argc, argv, "LDA", o.lda);        opt_int(argc, argv, "LDB", o.ldb);
   opt_int(argc, argv, "LDC", o.ldc);        opt_int(argc, argv, "WARMUP", o.warmup);
   opt_int(argc, argv, "EXTENDED", o.extended);
+  opt_int(argc, argv, "WARMUP_MS", o.warmup_ms);
   opt_int(argc, argv, "NGPUS", o.ngpus);
   opt_int(argc, argv, "SPLITK", o.splitk);
   opt_str(argc, argv, "KERNEL", o.kernel);  opt_str(argc, argv, "FLAVOUR", o.flavour);
@@ -239,6 +244,13 @@ int main(int argc, char **argv) {
           MY_MMult(handle, m, n, k, d_A, lda, d_B, ldb, d_C, ldc);
       };
       for (int rep = 0; rep < o.warmup; ++rep) call();
+      if (o.warmup_ms > 0) {
+        const double t_end = dclock() + o.warmup_ms * 1e-3;
+        do {
+          for (int rep = 0; rep < 8; ++rep) call();
+          HIP_CHECK(hipDeviceSynchronize());
+        } while (dclock() < t_end);
+      }
       HIP_CHECK(hipEventRecord(start, nullptr));
       for (int rep = 0; rep < o.nrepeats; ++rep) call();
       HIP_CHECK(hipEventRecord(stop, nullptr));
