@@ -29,7 +29,7 @@ Cold vs sustained.  The reference times NREPEATS = 20 launches with no warm-up
 (cuda/test_MMult.cpp:98-118).  An idle MI355X starts a launch train below its
 sustained clock, so that convention and the contract's (W warm-ups, K timed
 steps at steady state) give different numbers; both are reported:
-  * the run opens with a per-launch trace of the first RAMP launches
+  * the run opens with a per-launch trace of the first launches (up to 400, about half a second)
     (mmh_trace_sgemm, one hipEvent pair each) -> `cold`: launch #1 (code-object
     load, attribute calls), the mean of launches 2..21 (= the reference
     convention without the one-off), and where the ramp ends;
@@ -53,7 +53,8 @@ if REPO not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 METRIC = "GFLOPS vs N (square SGEMM sweep); % of MI355X fp32 MFMA peak at N=4096"
-RAMP = 400                        # per-launch traced launches that open the run (the clock ramp)
+RAMP = 400                        # per-launch traced launches that open the run (the clock ramp), at most
+RAMP_SECONDS = 0.5                # ... and about this long (a 16384-row panel takes tens of ms per launch)
 
 
 def parse_args():
@@ -215,8 +216,13 @@ def main():
     # ---- the clock ramp, traced: the first RAMP launches of this process, one event pair each ----
     # (before the broadcast on purpose: B's contents do not matter for timing, and the chip is as
     # cold here as it will ever be)
-    trace = mm.trace_sgemm(rows, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, count=RAMP,
-                           stream=stream) if rows else []
+    trace = []
+    if rows:
+        trace = mm.trace_sgemm(rows, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, count=25, stream=stream)
+        more = max(0, min(RAMP - 25, int(RAMP_SECONDS / (max(trace[-1], 1e-3) * 1e-3)) - 25))
+        if more:
+            trace += mm.trace_sgemm(rows, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, count=more,
+                                    stream=stream)
     if args.ramp_csv and rank == 0 and trace:
         with open(args.ramp_csv, "w") as f:
             f.write("launch,ms,tflops\n")
@@ -337,9 +343,9 @@ def main():
             "data": "synthetic uniform [-1,1) fp32, seeded on device",
             "config": {"workload": workload, "m": m, "n": n, "k": n, "kernel": H.kernel_name(mm.get_kernel()),
                        "parallelism": parallelism, "rows_per_rank": rows},
-            "untimed_launches": RAMP + args.warmup,
+            "untimed_launches": len(trace) + args.warmup,
             "cold": {
-                "what": f"per-launch hipEvent trace of this process's first {RAMP} launches (rank 0's panel)",
+                "what": f"per-launch hipEvent trace of this process's first {len(trace)} launches (rank 0's panel)",
                 "launch_1_ms": round(trace[0], 4) if trace else None,
                 "reference_convention_20_launches_no_warmup_tflops": tf(ref20),
                 "launches_2_to_21_tflops": tf(cold20),
