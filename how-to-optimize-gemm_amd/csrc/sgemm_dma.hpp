@@ -47,15 +47,9 @@
 
 namespace mmh {
 
-template <int N>
-struct DmaPieces {   // N consecutive 1 KiB pieces; lane L's 16 bytes land at dst + 1024 j + 16 L
-  static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, float *dst, const uint32_t (&voff)[N],
-                                               uint32_t soff) {
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + 256 * j), 16,
-                                               voff[j], soff, 0, 0);
-  }
+// One 1 KiB LDS-DMA piece: lane L's 16 bytes land at dst + 16 L.  (A static member of a class, like
+// LdsDma in igemm_s8.hpp: buffer descriptors in the signature of a function template trip hipcc's host pass.)
+struct DmaPiece {
   static __device__ __forceinline__ void one(__amdgpu_buffer_rsrc_t rsrc, float *dst, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)dst, 16, voff, soff, 0, 0);
   }
@@ -156,9 +150,9 @@ static __device__ __forceinline__ void run(float *lds, int m, int n, int k, cons
     constexpr int I = decltype(i_c)::value;
     const bool live = kt < ke;
     if constexpr (I < CA)
-      DmaPieces<1>::one(live ? rsrc_a : null_a, buf + 256 * (CA * wave + I), voff_a[I], (uint32_t)(kt * KB) * 4u);
+      DmaPiece::one(live ? rsrc_a : null_a, buf + 256 * (CA * wave + I), voff_a[I], (uint32_t)(kt * KB) * 4u);
     else
-      DmaPieces<1>::one(live ? rsrc_b : null_b, buf + A_FLOATS + 256 * (CB * wave + (I - CA)), voff_b[I - CA],
+      DmaPiece::one(live ? rsrc_b : null_b, buf + A_FLOATS + 256 * (CB * wave + (I - CA)), voff_b[I - CA],
                         (uint32_t)(kt * KB) * (uint32_t)ldb * 4u);
   };
   auto dma_slice = [&](float *buf, int kt) { static_for<ND>([&](auto i_c) { dma_piece(buf, kt, i_c); }); };
