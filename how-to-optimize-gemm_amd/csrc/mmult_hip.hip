@@ -104,7 +104,9 @@ struct mmh_context {
   DevBuf bt;               // int8 GEMM: packed (transposed, padded) B
   int igemm_mode = 0;      // 0 auto (B in place / packed-B + LDS-DMA), 1 in-kernel transpose, 2 simple
   DevBuf qa, qb, qc, qs;   // quantised GEMM workspace: int8 A, int8 B, int32 C, {amax bits, scales}
-  DevBuf flags;            // stream-K / split-K per-tile hand-off words
+  DevBuf flags;            // stream-K / split-K per-tile hand-off words; every launch leaves them ZERO (the
+                           // last reader of a word resets it), so only a fresh or suspect buffer is memset
+  bool flags_dirty = true;
   DevBuf parts;            // stream-K / split-K partial tiles
   int streamk = 1;         // allow the persistent stream-K launch for ragged tile counts
   int splitk = 0;          // opt-in split-K: 0 off (default), 1 auto, >= 2 that many parts
@@ -246,6 +248,27 @@ int claim_workspaces(mmh_context *ctx, hipStream_t s) {
   return MMH_OK;
 }
 
+// The hand-off words of `tiles` tiles, all zero.  The kernels restore the zeros themselves (the part that
+// finishes a tile resets its counter), so the fill runs only when the buffer is new, has grown, or a
+// launch may have died half-way (a sticky error was cleared).
+int prepare_flags(mmh_context *ctx, long tiles, hipStream_t s, int **flags) {
+  const size_t need = (size_t)tiles * sizeof(int);
+  if (need > ctx->flags.bytes) {
+    const int rc = ctx->flags.reserve(std::max(need, (size_t)(64u << 10)));
+    if (rc != MMH_OK) return rc;
+    ctx->flags_dirty = true;
+  }
+  if (ctx->flags_dirty) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    HIP_TRY(hipMemsetAsync(ctx->flags.p, 0, ctx->flags.bytes, s));
+    // a fill recorded into a graph does not clean the buffer NOW: stay dirty until an eager launch
+    if (cap == hipStreamCaptureStatusNone) ctx->flags_dirty = false;
+  }
+  *flags = static_cast<int *>(ctx->flags.p);
+  return MMH_OK;
+}
+
 // Persistent chained stream-K launch (sgemm_mfma.hpp, K2p): what is common to every tile code.  `kern`
 // is the instantiation to launch (`occ_kern` the one whose residency bounds the grid).  Returns MMH_OK
 // if it launched, 1 if the shape does not qualify (caller then uses the plain one-tile-per-workgroup
@@ -280,13 +303,11 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int thr
   }
   int rc = claim_workspaces(ctx, s);
   if (rc != MMH_OK) return rc;
-  rc = ctx->flags.reserve((size_t)tiles * sizeof(int));
-  if (rc != MMH_OK) return rc;
+  int *flags = nullptr;
+  if ((rc = prepare_flags(ctx, tiles, s, &flags)) != MMH_OK) return rc;
   rc = ctx->parts.reserve((size_t)grid * BM * BN * sizeof(float));   // one partial-tile slot per range
   if (rc != MMH_OK) return rc;
-  int *flags = static_cast<int *>(ctx->flags.p);
   float *parts = static_cast<float *>(ctx->parts.p);
-  HIP_TRY(hipMemsetAsync(flags, 0, (size_t)tiles * sizeof(int), s));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm, nbn,
                      flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault);
   HIP_TRY(hipGetLastError());
@@ -356,13 +377,11 @@ int try_launch_splitk(mmh_context *ctx, int S, int m, int n, int k, const float 
   if (S < 2) return 1;
   int rc = claim_workspaces(ctx, s);
   if (rc != MMH_OK) return rc;
-  rc = ctx->flags.reserve((size_t)tiles * sizeof(int));
-  if (rc != MMH_OK) return rc;
+  int *flags = nullptr;
+  if ((rc = prepare_flags(ctx, tiles, s, &flags)) != MMH_OK) return rc;
   rc = ctx->parts.reserve((size_t)tiles * (S - 1) * BM * BN * sizeof(float));
   if (rc != MMH_OK) return rc;
-  int *flags = static_cast<int *>(ctx->flags.p);
   float *parts = static_cast<float *>(ctx->parts.p);
-  HIP_TRY(hipMemsetAsync(flags, 0, (size_t)tiles * sizeof(int), s));
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc,
                      nbm, nbn, S, flags, ctx->sticky_dev, parts, ctx->spin_limit);
   HIP_TRY(hipGetLastError());
@@ -930,6 +949,7 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
         HIP_TRY(hipDeviceSynchronize());
       }
       if (h->sticky) *reinterpret_cast<volatile int *>(h->sticky) = 0;
+      h->flags_dirty = true;   // a launch that timed out may have left hand-off counters behind
       return MMH_OK;
     case MMH_OPT_IGEMM_MODE:
       if ((value >= 0 && value <= 6)
@@ -955,6 +975,7 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       return MMH_OK;
     case MMH_OPT_FAULT_INJECT:
       h->fault = value ? 1 : 0;
+      h->flags_dirty = true;
       return MMH_OK;
     default:
       return MMH_ERR_INVALID_ARG;

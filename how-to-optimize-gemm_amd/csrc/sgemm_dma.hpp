@@ -271,6 +271,7 @@ static __device__ __forceinline__ void run(float *lds, int m, int n, int k, cons
       }
       if (bad) __hip_atomic_fetch_add(fix.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (!bad) __hip_atomic_store(fix.flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // last reader: leave it zero
       reinterpret_cast<volatile int *>(lds)[0] = bad;
     }
     __syncthreads();

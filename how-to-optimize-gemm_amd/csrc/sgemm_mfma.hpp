@@ -452,6 +452,7 @@ __device__ __forceinline__ void mfma_tile_segment(float *lds, int m, int n, int 
       }
       if (bad) __hip_atomic_fetch_add(fix.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (!bad) __hip_atomic_store(fix.flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // last reader: leave it zero
       reinterpret_cast<volatile int *>(lds)[0] = bad;   // every wave is past its last LDS read (the
     }                                                   // slice loop ends in a barrier)
     __syncthreads();
@@ -610,6 +611,11 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
       }
       if (bad) __hip_atomic_fetch_add(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // The part that finishes a tile is the last reader of its counter: it puts the 0 back, so that
+      // the NEXT launch finds every counter zero without a memset dispatch in front of it (3-4 us of
+      // fill kernel and launch boundaries -- 10 % of a 34 us N = 1152 launch).  A launch that timed
+      // out may leave counters behind; the host zeroes the buffer again before the handle is reused.
+      if (!bad && ke == nk) __hip_atomic_store(&flags[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     int tm, tn;
     tile_of(t, tm, tn);

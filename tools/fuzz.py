@@ -18,7 +18,8 @@ seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rng = np.random.default_rng(seed)
 mm = H.MMult(0)
 stream = torch.cuda.current_stream().cuda_stream
-VARIANTS = ["auto", "mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "mfma_pipe", "mfma_simple", "valu"]
+VARIANTS = ["auto", "mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "mfma_pipe", "mfma_simple", "valu",
+            "valu_64x64", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma"]
 
 
 def strided(rows, cols, ld, off, fill=None):
@@ -31,8 +32,12 @@ def strided(rows, cols, ld, off, fill=None):
 
 bad = 0
 for case in range(cases):
-    kind = rng.integers(0, 4)
-    if kind == 0:      # tile multiples
+    kind = rng.integers(0, 5)
+    aligned = kind == 4
+    if kind == 4:      # whole tiles, 16-byte aligned bases and leading dimensions: what the LDS-DMA tiles take
+        m, n = (int(rng.integers(1, 12)) * 128 for _ in range(2))
+        k = int(rng.integers(1, 24)) * 64
+    elif kind == 0:    # tile multiples
         m, n, k = (int(rng.integers(1, 9)) * 128 for _ in range(3))
     elif kind == 1:    # ragged small
         m, n, k = (int(rng.integers(1, 400)) for _ in range(3))
@@ -42,6 +47,9 @@ for case in range(cases):
         m, n, k = int(rng.integers(1, 40)), int(rng.integers(1, 2000)), int(rng.integers(1, 1500))
     lda, ldb, ldc = k + int(rng.integers(0, 9)), n + int(rng.integers(0, 9)), n + int(rng.integers(0, 9))
     offs = [int(rng.integers(0, 4)) for _ in range(3)]
+    if aligned:
+        lda, ldb, ldc = k + 4 * int(rng.integers(0, 3)), n + 4 * int(rng.integers(0, 3)), n + 4 * int(rng.integers(0, 3))
+        offs = [4 * int(rng.integers(0, 2)) for _ in range(3)]
     acc = bool(rng.integers(0, 2))
     a = torch.rand((m, k), device="cuda") * 2 - 1
     b = torch.rand((k, n), device="cuda") * 2 - 1
@@ -69,21 +77,23 @@ print(f"fuzz: {cases} cases x {len(VARIANTS)} variants, {bad} failures")
 
 # stream-K stress
 sk_bad = 0
-for n in (2176, 2432, 2944, 3072, 3456, 3712, 4352, 4608, 2049, 2305, 3001):   # the last three: guarded stream-K
+for n in (1152, 1536, 1792, 2176, 2432, 2944, 3072, 3456, 3712, 4352, 4608, 2049, 2305, 3001):   # the last three: guarded stream-K
     a = torch.rand((n, n), device="cuda") * 2 - 1
     b = torch.rand((n, n), device="cuda") * 2 - 1
     mm.set_kernel("mfma_tiles")
     ref = mm.matmul(a, b)
-    mm.set_kernel("auto" if n > 4096 else "mfma")     # > 4096: the 256x256 tile under stream-K
-    c = torch.empty_like(ref)
-    for rep in range(stress):
-        c.fill_(float("nan"))
-        mm.matmul(a, b, out=c)
-        if not torch.equal(c, ref):
+    # "auto": the LDS-DMA tiles under stream-K below 4096, the 256x256 tile above; "mfma": the register-staged 128x128 tile
+    for kern in ("auto", "mfma"):
+        mm.set_kernel(kern)
+        c = torch.empty_like(ref)
+        for rep in range(stress):
+            c.fill_(float("nan"))
+            mm.matmul(a, b, out=c)
+            if not torch.equal(c, ref):
+                sk_bad += 1
+                print(f"stream-K {kern} N={n} rep {rep}: mismatch, max diff {(c - ref).abs().max().item()}")
+        if mm.streamk_timeouts():
             sk_bad += 1
-            print(f"stream-K N={n} rep {rep}: mismatch, max diff {(c - ref).abs().max().item()}")
-    if mm.streamk_timeouts():
-        sk_bad += 1
-        print(f"stream-K N={n}: hand-off timeouts reported")
+            print(f"stream-K {kern} N={n}: hand-off timeouts reported")
 print(f"stream-K stress: {sk_bad} failures")
 sys.exit(1 if bad or sk_bad else 0)

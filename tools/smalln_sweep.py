@@ -16,9 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sizes", default="1024,1152,1280,1408,1536,1664,1792,1920,2048")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--reps", type=int, default=20)
-ap.add_argument("--variants", default="auto,mfma_64x64,mfma_64x64_dma,mfma_128x64,mfma_128x64_dma,mfma_tiles,mfma_splitk:0,mfma_splitk:2,mfma_splitk:3,"
-                                       "mfma_splitk:4,mfma_splitk_128x64:2,mfma_splitk_128x64:4,auto:1,rocblas,hipblaslt,"
-                                       "valu,valu_128x128,valu_64x64")
+ap.add_argument("--variants", default="auto,mfma_64x64_dma,mfma_128x64_dma,mfma_128x128_dma,mfma_64x64,mfma_128x64,mfma_tiles,"
+                                       "mfma_splitk:0,auto:1,rocblas,hipblaslt,valu,valu_128x128,valu_64x64")
 args = ap.parse_args()
 sizes = [int(x) for x in args.sizes.split(",")]
 variants = args.variants.split(",")
