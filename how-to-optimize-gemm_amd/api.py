@@ -239,8 +239,9 @@ class MMult:
         _check(lib().mmh_get_kernel(self._h, C.byref(k)), "mmh_get_kernel")
         return k.value
 
-    def set_streamk(self, on: bool) -> None:
-        _check(lib().mmh_set_option(self._h, OPT_STREAMK, int(bool(on))), "mmh_set_option")
+    def set_streamk(self, on) -> None:
+        """False / 0 never, True / 1 when a round would be > 7 % empty (default), 2 whenever ragged."""
+        _check(lib().mmh_set_option(self._h, OPT_STREAMK, int(on)), "mmh_set_option")
 
     def set_igemm_mode(self, mode: int) -> None:
         """0 B read in place (default; packed B for unaligned operands), tile picked by size; 1 in-kernel

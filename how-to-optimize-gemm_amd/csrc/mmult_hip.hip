@@ -295,9 +295,11 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int thr
     if (tiles >= (long)w * cus) { grid = w * cus; break; }
   if (grid == 0 || tiles % grid == 0) return 1;   // too few tiles, or already balanced
   if (tiles > (1L << 24)) return 1;
-  // nearly full rounds: the plain launch idles less than the hand-overs cost (measured, N = 1408 on
-  // 64x64 tiles: 484 tiles for 512 slots run 119 TFLOP/s plain, 109 under stream-K)
-  {
+  // Small tiles in nearly full rounds: the plain launch idles less than the hand-overs cost (measured,
+  // N = 1408 on 64x64 tiles: 484 tiles for 512 slots run 119 TFLOP/s plain, 109 under stream-K).  From
+  // 128x128 tiles up a hand-over is small beside a tile's work and stream-K wins whenever the count is
+  // ragged (N = 2816 / 3456 / 3968: 143 / 145 / 146.5 against 138 / 139 / 138 plain).
+  if (ctx->streamk != 2 && BM * BN < 128 * 128) {   // MMH_OPT_STREAMK = 2: whenever ragged (A/B switch)
     const long slots = (long)per_cu * cus, rounds = (tiles + slots - 1) / slots;
     if (tiles * 100 >= rounds * slots * 93) return 1;
   }
@@ -939,7 +941,8 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
   if (!h) return MMH_ERR_INVALID_ARG;
   switch (option) {
     case MMH_OPT_STREAMK:
-      h->streamk = value ? 1 : 0;
+      if (value < 0 || value > 2) return MMH_ERR_INVALID_ARG;
+      h->streamk = value;
       return MMH_OK;
     case MMH_OPT_STREAMK_TIMEOUTS:   // writing 0 clears the sticky error
       if (value != 0) return MMH_ERR_INVALID_ARG;

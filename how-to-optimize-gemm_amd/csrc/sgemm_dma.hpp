@@ -341,8 +341,8 @@ struct DmaSeg {
                                              const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                              int tm, int tn, int kb, int ke, bool init_from_c, const float *part_in,
                                              float *part_out) {
-    DmaSegment<BM, BN, KB, WTM, WTN, NBUF>::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke, init_from_c, part_in,
-                                                part_out);
+    DmaSegment<BM, BN, KB, WTM, WTN, NBUF, true>::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke, init_from_c,
+                                                      part_in, part_out);   // partial tiles write-through
   }
 };
 

@@ -541,9 +541,9 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 // shorter ranges (>= half a tile, two workgroups per CU) a waiting workgroup
 // leaves its CU to its partner, which is still better than an idle CU.
 // Dependencies only ever point to lower range indices.
-// Visibility across CUs/XCDs (cdna guide G16): producer = plain stores, every
-// wave drains vmcnt, barrier, one lane agent-scope release fence + drained
-// relaxed counter store; consumer = one lane relaxed poll (bounded), agent-scope
+// Visibility across CUs/XCDs (cdna guide G16, recipe R1): producer = write-through (sc1)
+// stores of the partial tile, every wave drains vmcnt, barrier, one lane relaxed
+// agent-scope counter store; consumer = one lane relaxed poll (bounded), agent-scope
 // acquire fence, barrier, plain loads.
 // ---------------------------------------------------------------------------
 // The stream-K control flow is written once, over a SEGMENT policy -- how one (tile, K-slice range) is
@@ -557,8 +557,9 @@ struct RegSeg {
                                              const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                              int tm, int tn, int kb, int ke, bool init_from_c, const float *part_in,
                                              float *part_out) {
-    mfma_tile_segment<BM, BN, EDGE, 4, 0, true, WTN, WTM, KB>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke,
-                                                              init_from_c, part_in, part_out);
+    // partial tiles go out WRITE-THROUGH (PART_WT: sc1 buffer stores), see the publish step in streamk_body
+    mfma_tile_segment<BM, BN, EDGE, 4, 0, true, WTN, WTM, KB, false, true>(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn,
+                                                                           kb, ke, init_from_c, part_in, part_out);
   }
 };
 
@@ -633,13 +634,15 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
     float *part_out = ke < nk ? parts + (size_t)q * BM * BN : nullptr;
     Seg::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke, kb == 0 && accumulate != 0, part_in, part_out);
     if (ke < nk) {
+      // Publish (cdna guide G16, recipe R1): the partial tile was stored write-through (sc1), so there is
+      // nothing for a release fence to write back -- every storing wave drains its stores, the
+      // workgroup meets, ONE lane stores the counter.  (Round 1 used plain stores + an agent release
+      // fence: `buffer_wbl2` on 64 KiB of freshly dirtied lines stalls the publisher ~6 us, which every
+      // wave then waits out at the next segment's barrier.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (threadIdx.x == 0 && !fault) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0 && !fault)
         __hip_atomic_store(&flags[t], part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
     }
     return true;
   };

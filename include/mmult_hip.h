@@ -132,7 +132,8 @@ const char *mmh_kernel_name(int kernel);
 
 /* Options.  MMH_OPT_STREAMK (default 1): let MMH_KERNEL_MFMA/AUTO run tile counts
  * that do not divide the chip as ONE persistent chained stream-K launch (bit-identical
- * results).
+ * results) -- from 128x128 tiles up whenever the count is ragged, for smaller tiles when the plain
+ * launch would leave a round more than 7 % empty; 0 never, 2 whenever the count is ragged.
  * MMH_OPT_STREAMK_TIMEOUTS: the handle's STICKY error.  A stream-K / split-K hand-off wait that
  * times out (never seen outside fault injection) adds to a host-visible word and the waiting
  * workgroup stops; from then on EVERY mmh_* call on the handle returns MMH_ERR_HIP -- the launch

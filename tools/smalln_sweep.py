@@ -60,9 +60,9 @@ for n in sizes:
                 ms = timed(lambda: mm.matmul_rocblas(a, b, out=c), args.reps)
             else:
                 name, _, s = v.partition(":")
-                nosk = name.endswith("/nosk")            # name/nosk: the same kernel without stream-K
-                mm.set_kernel(name[:-5] if nosk else name)
-                mm.set_streamk(not nosk)
+                nosk, sk2 = name.endswith("/nosk"), name.endswith("/sk2")   # without stream-K / stream-K whenever ragged
+                mm.set_kernel(name[:-5] if nosk else (name[:-4] if sk2 else name))
+                mm.set_streamk(0 if nosk else (2 if sk2 else 1))
                 mm.set_splitk(int(s) if s else 0)
                 ms = mm.time_sgemm(n, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, warmup=5,
                                    reps=args.reps, stream=stream)
