@@ -299,9 +299,10 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int thr
   // N = 1408 on 64x64 tiles: 484 tiles for 512 slots run 119 TFLOP/s plain, 109 under stream-K).  From
   // 128x128 tiles up a hand-over is small beside a tile's work and stream-K wins whenever the count is
   // ragged (N = 2816 / 3456 / 3968: 143 / 145 / 146.5 against 138 / 139 / 138 plain).
+  // (Balance is a matter of CUs, not of workgroup slots: co-resident workgroups share their CU's matrix pipe.)
   if (ctx->streamk != 2 && BM * BN < 128 * 128) {   // MMH_OPT_STREAMK = 2: whenever ragged (A/B switch)
-    const long slots = (long)per_cu * cus, rounds = (tiles + slots - 1) / slots;
-    if (tiles * 100 >= rounds * slots * 93) return 1;
+    const long rounds = (tiles + cus - 1) / cus;
+    if (tiles * 100 >= rounds * cus * 93) return 1;
   }
   int rc = claim_workspaces(ctx, s);
   if (rc != MMH_OK) return rc;
@@ -530,19 +531,16 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
         }
       }
       // Below one 256x256 tile per CU (N < 4096 on the reference sweep) whole-tile, 16-byte aligned
-      // shapes run on the LDS-DMA tiles (sgemm_dma.hpp) -- the largest of 128x128 / 128x64 / 64x64 that
-      // still gives (nearly) every CU a tile, measured on the sweep (profiles/r02_sweep.md): 128x128 from
-      // 0.85 tiles per CU up (N >= 1920), 128x64 from 0.78 of those per CU (N >= 1280), 64x64 below --
-      // each as a chained stream-K launch when its tile count leaves a round more than 7 % empty.
+      // shapes run on the LDS-DMA tiles (sgemm_dma.hpp), the choice measured on the sweep
+      // (profiles/r02_ablation.md): 128x128 from 1.15 tiles per CU (N >= 2304), 128x64 from 1.25 of
+      // those per CU (N >= 1664), 64x64 below -- each as a chained stream-K launch when worthwhile.
       if (window_ok(128, 128, k, lda, ldb)) {
-        if (tiles128 * 100 >= cus * 85 && fast_shape(128, 128, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
+        if (tiles128 * 100 >= cus * 115 && fast_shape(128, 128, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
           return sgemm_on(ctx, MMH_KERNEL_MFMA_128X128_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
-        if (tiles128 < cus) {
-          if (tiles128x64 * 100 >= cus * 78 && fast_shape(128, 64, 64, m, n, k, dA, lda, dB, ldb, dC, ldc))
-            return sgemm_on(ctx, MMH_KERNEL_MFMA_128X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
-          if (fast_shape(64, 64, 64, m, n, k, dA, lda, dB, ldb, dC, ldc))
-            return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
-        }
+        if (tiles128x64 * 100 >= cus * 125 && fast_shape(128, 64, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
+          return sgemm_on(ctx, MMH_KERNEL_MFMA_128X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+        if (fast_shape(64, 64, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
+          return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
       }
       if (tiles128x64 * 2 <= cus)
         return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
@@ -573,17 +571,17 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       if (sk <= 0) return sk;
       return launch_mfma<128, 64, false, 4, 0, true, 2>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     }
-    case MMH_KERNEL_MFMA_64X64_DMA: {   // K2L: 64x64 tile, both operands by LDS-DMA, 3 ring buffers of 64-deep slices
-      const int sk = try_launch_streamk_dma<64, 64, 64, 2, 2, 3>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_MFMA_64X64_DMA: {   // K2L: 64x64 tile, both operands by LDS-DMA, 3 ring buffers of 32-deep slices (48 KiB: 3 WG/CU)
+      const int sk = try_launch_streamk_dma<64, 64, 32, 2, 2, 3>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
       if (sk <= 0) return sk;
-      const int d = try_launch_dma<64, 64, 64, 2, 2, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      const int d = try_launch_dma<64, 64, 32, 2, 2, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
       if (d <= 0) return d;
       return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
     }
-    case MMH_KERNEL_MFMA_128X64_DMA: {  // K2L on the 128x64 tile (4 waves of 64x32)
-      const int sk = try_launch_streamk_dma<128, 64, 64, 4, 2, 3>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    case MMH_KERNEL_MFMA_128X64_DMA: {  // K2L on the 128x64 tile (4 waves of 64x32; 72 KiB ring: 2 WG/CU)
+      const int sk = try_launch_streamk_dma<128, 64, 32, 4, 2, 3>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
       if (sk <= 0) return sk;
-      const int d = try_launch_dma<128, 64, 64, 4, 2, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      const int d = try_launch_dma<128, 64, 32, 4, 2, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
       if (d <= 0) return d;
       return sgemm_on(ctx, MMH_KERNEL_MFMA_128X64, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
     }
