@@ -30,6 +30,10 @@
 // a COUNTED `s_waitcnt vmcnt((NBUF - 2) * pieces)` -- never 0 in the steady state, the newest slices stay
 // in flight across it (cdna guide section 5, "what does break it").  Past the last slice the same DMA
 // instructions run against zero-length descriptors, so the loop body has no branches.
+// All product instantiations use 32-deep slices (KB = 32): rings of 48 KiB (64x64), 72 KiB (128x64) and
+// 96 KiB (128x128), so three / two / one workgroup(s) share a CU and one workgroup's pipeline fill,
+// hand-over wait or epilogue runs under another's loop (64-deep slices, one workgroup per CU, were 2-7 %
+// slower at N <= 1664, profiles/r02_ablation.md section 2).
 //
 // Arithmetic: the same MFMA (v_mfma_f32_16x16x4_f32) fed the same k's in ascending order as every
 // other kernel here -- one fp32 fmaf chain per C element, bit-identical results.  Whole-tile,

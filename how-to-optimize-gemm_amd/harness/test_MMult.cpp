@@ -42,6 +42,10 @@
 //                              sustained-clock form: between two sizes the driver spends seconds on
 //                              the host -- inputs, REF -- and the GPU falls back to its idle clock;
 //                              30 launches of a 0.1 ms kernel do not bring it back, 50 ms do)
+//   TRIALS=<n>                 device flavour: time the NREPEATS launches n times and report the MEDIAN of
+//                              the n means (default 1 = the reference's single measurement); the sustained
+//                              sweeps under profiles/ use 3, so that one transient (another process's
+//                              burst, a clock dip) does not own a point
 //   EXTENDED=1                 extra columns: pct_of_fp32_mfma_peak ref_gflops ref_cores
 #include <algorithm>
 #include <cmath>
@@ -65,7 +69,7 @@ struct Options {
   int m = sweep_defaults::kM, n = sweep_defaults::kN, k = sweep_defaults::kK;
   int nrepeats = sweep_defaults::kRepeats;
   int lda = sweep_defaults::kLda, ldb = sweep_defaults::kLdb, ldc = sweep_defaults::kLdc;
-  int warmup = 0, warmup_ms = 0, extended = 0, ngpus = 1, splitk = 0;
+  int warmup = 0, warmup_ms = 0, extended = 0, ngpus = 1, splitk = 0, trials = 1;
   std::string kernel = "auto", flavour = "device", input = "drand48", ref = "threads";
 };
 
@@ -124,6 +128,8 @@ int main(int argc, char **argv) {
   opt_int(argc, argv, "LDC", o.ldc);        opt_int(argc, argv, "WARMUP", o.warmup);
   opt_int(argc, argv, "EXTENDED", o.extended);
   opt_int(argc, argv, "WARMUP_MS", o.warmup_ms);
+  opt_int(argc, argv, "TRIALS", o.trials);
+  if (o.trials < 1) o.trials = 1;
   opt_int(argc, argv, "NGPUS", o.ngpus);
   opt_int(argc, argv, "SPLITK", o.splitk);
   opt_str(argc, argv, "KERNEL", o.kernel);  opt_str(argc, argv, "FLAVOUR", o.flavour);
@@ -251,13 +257,18 @@ int main(int argc, char **argv) {
           HIP_CHECK(hipDeviceSynchronize());
         } while (dclock() < t_end);
       }
-      HIP_CHECK(hipEventRecord(start, nullptr));
-      for (int rep = 0; rep < o.nrepeats; ++rep) call();
-      HIP_CHECK(hipEventRecord(stop, nullptr));
-      HIP_CHECK(hipEventSynchronize(stop));
-      float ms = 0.f;
-      HIP_CHECK(hipEventElapsedTime(&ms, start, stop));
-      seconds = ms * 1e-3 / o.nrepeats;
+      std::vector<float> trial_ms;
+      for (int trial = 0; trial < o.trials; ++trial) {
+        HIP_CHECK(hipEventRecord(start, nullptr));
+        for (int rep = 0; rep < o.nrepeats; ++rep) call();
+        HIP_CHECK(hipEventRecord(stop, nullptr));
+        HIP_CHECK(hipEventSynchronize(stop));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, start, stop));
+        trial_ms.push_back(ms);
+      }
+      std::sort(trial_ms.begin(), trial_ms.end());
+      seconds = trial_ms[trial_ms.size() / 2] * 1e-3 / o.nrepeats;
       HIP_CHECK(hipMemcpy(cold.data(), d_C, cold.size() * sizeof(float), hipMemcpyDeviceToHost));
       HIP_CHECK(hipFree(d_A));
       HIP_CHECK(hipFree(d_B));

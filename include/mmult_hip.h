@@ -81,7 +81,8 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_256X256 12 /* K2 with a 256x256 block tile, 8 waves of 128x64 (1 WG/CU)       */
 #define MMH_KERNEL_MFMA_64X64 11 /* K2 with a 64x64 block tile, 4 waves of 32x32, 128-deep K-slices  */
 /* K2L (sgemm_dma.hpp): tiles fed entirely by LDS-DMA (buffer_load ... lds for both operands, a ring of
- * three K-slice buffers, counted vmcnt waits, no registers -> LDS stores at all) -- the register-staged
+ * three 32-deep K-slice buffers = 48 / 72 / 96 KiB, i.e. 3 / 2 / 1 workgroups per CU, counted vmcnt waits,
+ * no registers -> LDS stores at all) -- the register-staged
  * packing stage is what bounds the small tiles.  Same chain, same bits; what MMH_KERNEL_AUTO runs on
  * whole-tile 16-byte-aligned shapes below one 256x256 tile per CU (stream-K for ragged tile counts);
  * anything else runs the register-staged kernel of the same tile. */

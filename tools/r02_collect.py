@@ -31,7 +31,7 @@ cp("hbm_patterns.txt", "r02_hbm_patterns.txt")
 cp("host_flavour.txt", "r02_host_flavour.txt")
 cp("prof4096_kernel_stats.csv", "r02_sgemm4096_kernel_stats.csv")
 cp("prof4096_summary.json", "r02_sgemm4096_auto256_rocprofv3.json")
-cp("prof2048_summary.json", "r02_sgemm2048_dma128x128_rocprofv3.json")
+cp("prof2048_summary.json", "r02_sgemm2048_dma128x64_rocprofv3.json")
 cp("prof1024_summary.json", "r02_sgemm1024_dma64x64_rocprofv3.json")
 cp(os.path.join("qprof", "summary.json"), "r02_qgemm_rocprofv3.json")
 cp(os.path.join("i8prof", "summary.json"), "r02_igemm_s8_rocprofv3.json")
