@@ -431,6 +431,8 @@ def main():
                 extras["probe_mfma_f32_tflops"] = round(mm.probe_mfma_f32(), 1)
                 extras["probe_hbm_copy_gbps"] = round(mm.probe_hbm_copy(1 << 30), 1)
                 extras["probe_hbm_read_gbps"] = round(mm.probe_hbm_read(1 << 30), 1)
+                extras["probe_lds_read_gbps"] = {w: round(mm.probe_lds_read(v), 1) for w, v in
+                                                 (("b128", 16), ("b64", 8), ("b32", 4), ("b64_tr_b8", -8))}
                 # configs[4]: int8 x int8 -> int32 at N=4096 (end to end), beside
                 # what the matrix pipe sustains on constant and on random operands
                 try:

@@ -42,12 +42,12 @@ EXPORTS = [
     "mmh_device_info",
     "mmh_create", "mmh_destroy", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name",
     "mmh_set_option", "mmh_get_option",
-    "mmh_sgemm", "mmh_sgemm_host", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
+    "mmh_sgemm", "mmh_sgemm_host", "mmh_sgemm_host_timed", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
     "mmh_sgemm_rocblas", "mmh_shard_rows",
     "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm",
     "mmh_rccl_version",
     "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
-    "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy", "mmh_probe_hbm_read",
+    "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy", "mmh_probe_hbm_read", "mmh_probe_lds_read",
 ]
 
 
@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
     gemm = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]
     L.mmh_sgemm.argtypes = gemm + [C.c_int, vp]
     L.mmh_sgemm_host.argtypes = gemm + [C.c_int]
+    L.mmh_sgemm_host_timed.argtypes = gemm + [C.c_int, C.POINTER(C.c_float)]
     L.mmh_igemm_s8.argtypes = gemm + [C.c_int, vp]
     L.mmh_sgemm_rocblas.argtypes = gemm + [vp]
     L.mmh_qgemm_f32.argtypes = gemm + [vp]
@@ -146,6 +147,7 @@ def lib() -> C.CDLL:
     L.mmh_time_sgemm.argtypes = gemm + [C.c_int, C.c_int, vp, fp]
     L.mmh_trace_sgemm.argtypes = gemm + [C.c_int, vp, fp]
     L.mmh_probe_hbm_read.argtypes = [vp, C.c_size_t, fp]
+    L.mmh_probe_lds_read.argtypes = [vp, C.c_int, fp]
     L.mmh_probe_mfma_f32.argtypes = [vp, fp]
     L.mmh_probe_mfma_i8.argtypes = [vp, fp]
     L.mmh_probe_mfma_i8_sustained.argtypes = [vp, C.c_int, C.c_float, fp]
@@ -309,6 +311,19 @@ class MMult:
             raise MMultError(ERR_INVALID_ARG, "MY_MMult", "C buffer smaller than (m-1)*ldc+n")
         _check(lib().mmh_sgemm_host(self._h, m, n, k, _np_ptr(a), lda, _np_ptr(b), ldb, _np_ptr(c),
                                     ldc, 1), "mmh_sgemm_host")
+
+    def MY_MMult_ms(self, m, n, k, a: np.ndarray, b: np.ndarray, c: np.ndarray) -> float:
+        """vulkan/test_MMult.cpp:10,55 semantics: dense row-major host buffers (lda = k, ldb = n,
+        ldc = n), C = A*B, returns the device time of the GEMM in milliseconds."""
+        for x in (a, b, c):
+            if x.dtype != np.float32 or not x.flags["C_CONTIGUOUS"]:
+                raise MMultError(ERR_INVALID_ARG, "MY_MMult_ms", "need C-contiguous float32 buffers")
+        if a.size < m * k or b.size < k * n or c.size < m * n:
+            raise MMultError(ERR_INVALID_ARG, "MY_MMult_ms", "buffer smaller than rows*cols")
+        ms = C.c_float(0.0)
+        _check(lib().mmh_sgemm_host_timed(self._h, m, n, k, _np_ptr(a), max(k, 1), _np_ptr(b), max(n, 1),
+                                          _np_ptr(c), max(n, 1), 0, C.byref(ms)), "mmh_sgemm_host_timed")
+        return float(ms.value)
 
     def sgemm_host(self, a: np.ndarray, b: np.ndarray, c: Optional[np.ndarray] = None,
                    accumulate: bool = False) -> np.ndarray:
@@ -481,6 +496,13 @@ class MMult:
         v = C.c_float(0)
         _check(lib().mmh_probe_hbm_read(self._h, nbytes, C.byref(v)), "mmh_probe_hbm_read")
         return v.value
+
+    def probe_lds_read(self, width: int = 16) -> float:
+        """LDS fragment-read rate summed over the chip, GB/s (width 16 / 8 / 4 bytes per lane, -8 = the
+        transposing ds_read_b64_tr_b8)."""
+        v = C.c_float(0.0)
+        _check(lib().mmh_probe_lds_read(self._h, int(width), C.byref(v)), "mmh_probe_lds_read")
+        return float(v.value)
 
 
 class ShardedMMult:

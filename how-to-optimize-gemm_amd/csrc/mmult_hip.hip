@@ -128,6 +128,7 @@ struct mmh_context {
   hipStream_t hs_in = nullptr, hs_run = nullptr, hs_out = nullptr;
   hipEvent_t ev_in[kMaxHostPanels] = {}, ev_run[kMaxHostPanels] = {}, ev_b = nullptr;
   bool pipeline_ready = false;
+  hipEvent_t t0 = nullptr, t1 = nullptr;   // mmh_sgemm_host_timed
 };
 
 namespace {
@@ -744,6 +745,8 @@ void destroy_context(mmh_context *h) {
     if (h->hs_run) (void)hipStreamDestroy(h->hs_run);
     if (h->hs_out) (void)hipStreamDestroy(h->hs_out);
   }
+  if (h->t0) (void)hipEventDestroy(h->t0);
+  if (h->t1) (void)hipEventDestroy(h->t1);
   if (h->sticky) (void)hipHostFree(h->sticky);
   mmh::rocblas_release(h->rocblas);
   delete h;
@@ -769,6 +772,12 @@ int ensure_pipeline(mmh_context *h) {
   }
   HIP_TRY(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
   h->pipeline_ready = true;
+  return MMH_OK;
+}
+
+int ensure_timing_events(mmh_context *h) {
+  if (!h->t0) HIP_TRY(hipEventCreate(&h->t0));
+  if (!h->t1) HIP_TRY(hipEventCreate(&h->t1));
   return MMH_OK;
 }
 
@@ -1070,9 +1079,15 @@ int mmh_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, con
 
 int mmh_sgemm_host(mmh_handle_t h, int m, int n, int k, const float *A, int lda, const float *B,
                    int ldb, float *C, int ldc, int accumulate) {
+  return mmh_sgemm_host_timed(h, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nullptr);
+}
+
+int mmh_sgemm_host_timed(mmh_handle_t h, int m, int n, int k, const float *A, int lda, const float *B,
+                         int ldb, float *C, int ldc, int accumulate, float *kernel_ms) {
   if (!h) return MMH_ERR_INVALID_ARG;
   int rc = check_gemm_args(m, n, k, A, lda, B, ldb, C, ldc);
   if (rc != MMH_OK) return rc;
+  if (kernel_ms) *kernel_ms = 0.0f;
   if (m == 0 || n == 0) return MMH_OK;
   ENTER(h);
   // Device images are dense (lda=k, ldb=n, ldc=n) whatever the host strides.
@@ -1090,7 +1105,9 @@ int mmh_sgemm_host(mmh_handle_t h, int m, int n, int k, const float *A, int lda,
     panels = 0;
     if (k > 0 && m >= 1024 && (ab + bb + cb) >= (16u << 20)) panels = std::min(8, m / 512);
   }
-  if (panels >= 2 && k > 0 && m >= 2 * 128)
+  // the timed form wants the device time of the GEMM alone (what the Vulkan flavour's timestamps
+  // bracket, vulkan/MMult_vk_3.cpp:38-46): one launch between two events, no overlapping copies
+  if (!kernel_ms && panels >= 2 && k > 0 && m >= 2 * 128)
     return sgemm_host_pipelined(h, std::min(panels, kMaxHostPanels), m, n, k, A, lda, B, ldb, C, ldc, accumulate, dA,
                                 dB, dC);
   if (k > 0) {
@@ -1102,10 +1119,19 @@ int mmh_sgemm_host(mmh_handle_t h, int m, int n, int k, const float *A, int lda,
   if (accumulate)
     HIP_TRY(hipMemcpy2D(dC, (size_t)n * 4, C, (size_t)ldc * 4, (size_t)n * 4, m,
                         hipMemcpyHostToDevice));
+  if (kernel_ms) {
+    if ((rc = ensure_timing_events(h)) != MMH_OK) return rc;
+    HIP_TRY(hipEventRecord(h->t0, nullptr));
+  }
   rc = sgemm_on(h, h->kernel, m, n, k, dA, k, dB, n, dC, n, accumulate, nullptr);
   if (rc != MMH_OK) return rc;
+  if (kernel_ms) HIP_TRY(hipEventRecord(h->t1, nullptr));
   HIP_TRY(hipMemcpy2D(C, (size_t)ldc * 4, dC, (size_t)n * 4, (size_t)n * 4, m,
                       hipMemcpyDeviceToHost));
+  if (kernel_ms) {
+    HIP_TRY(hipEventSynchronize(h->t1));
+    HIP_TRY(hipEventElapsedTime(kernel_ms, h->t0, h->t1));
+  }
   return MMH_OK;
 }
 
@@ -1562,6 +1588,12 @@ int mmh_probe_hbm_read(mmh_handle_t h, size_t bytes, float *gbps) {
   if (!h || !gbps || bytes < (1u << 20)) return MMH_ERR_INVALID_ARG;
   ENTER(h);
   return mmh::probe_hbm_copy(bytes, gbps, &g_last_error, h->cu_count, 1);
+}
+
+int mmh_probe_lds_read(mmh_handle_t h, int width, float *gbps) {
+  if (!h || !gbps || (width != 16 && width != 8 && width != 4 && width != -8)) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return mmh::probe_lds_read(width, gbps, &g_last_error, h->cu_count);
 }
 
 }  // extern "C"

@@ -72,6 +72,8 @@ inline int probe_mfma_f32(int cu_count, float *tflops, std::string *err) {
 
 // int8 twin: v_mfma_i32_16x16x64_i8 only (what K3 issues), 8 accumulators per wave
 typedef int pi32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) probe_mfma_i8_kernel(int *out, int iters, int seed) {
   // The MFMAs are spelled in inline asm: with the builtin, hipcc 7.2 allocates the eight
   // int accumulators in overlapping AGPR windows and shuffles ~50 registers per iteration,
@@ -230,6 +232,82 @@ inline int probe_hbm_copy(size_t bytes, float *gbps, std::string *err, int cu_co
   (void)hipEventDestroy(t1);
   (void)hipFree(src);
   (void)hipFree(dst);
+  return MMH_OK;
+}
+
+// --------------------------------------------------------------- LDS read --
+// The third denominator (the idea of vulkan/benchmark/smem_bandwidth.cpp:30-42): fragment reads out
+// of LDS and nothing else.  Two waves per SIMD, eight reads in flight per wave, conflict-free
+// lane-linear addresses (roof: 256 B/clk/CU for the 8- and 16-byte reads, 128 for ds_read_b32);
+// WIDTH = bytes per lane (16: ds_read_b128, 8: ds_read_b64, 4: ds_read_b32,
+// -8: ds_read_b64_tr_b8, the transposing read of the in-place int8 kernel).
+template <int WIDTH>
+__global__ void __launch_bounds__(512) probe_lds_read_kernel(float *__restrict__ out, int iters) {
+  __shared__ __attribute__((aligned(16))) uint32_t lbuf[16384];   // 64 KiB
+  for (int i = threadIdx.x; i < 16384; i += 512) lbuf[i] = (uint32_t)i * 2654435761u;
+  __syncthreads();
+  constexpr int W = WIDTH < 0 ? -WIDTH : WIDTH;
+  const uint32_t addr = (uint32_t)(uintptr_t)lbuf + (threadIdx.x & 63) * W + (threadIdx.x >> 6) * 4096;
+  uint32_t acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (WIDTH == 16) {
+      u32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(addr), "n"(j * 1024));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc ^= v[j][0] ^ v[j][3];
+    } else if constexpr (W == 8) {
+      u32x2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (WIDTH > 0) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[j]) : "v"(addr), "n"(j * 512));
+        else asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(v[j]) : "v"(addr), "n"(j * 512));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc ^= v[j][0] ^ v[j][1];
+    } else {
+      uint32_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[j]) : "v"(addr), "n"(j * 256));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc ^= v[j];
+    }
+  }
+  if (acc == 0x12345u) out[0] = 1.0f;   // keep the reads live
+}
+
+// bytes per clock per CU are derived by the caller from the device clock; this returns aggregate GB/s
+inline int probe_lds_read(int width, float *gbps, std::string *err, int cu_count) {
+  float *out = nullptr;
+  MMH_HIP_TRY(hipMalloc(&out, 64), err);
+  hipEvent_t t0, t1;
+  MMH_HIP_TRY(hipEventCreate(&t0), err);
+  MMH_HIP_TRY(hipEventCreate(&t1), err);
+  const int iters = 4096, blocks = 2 * cu_count;
+  auto launch = [&] {
+    switch (width) {
+      case 16: hipLaunchKernelGGL(probe_lds_read_kernel<16>, dim3(blocks), dim3(512), 0, 0, out, iters); break;
+      case 8: hipLaunchKernelGGL(probe_lds_read_kernel<8>, dim3(blocks), dim3(512), 0, 0, out, iters); break;
+      case -8: hipLaunchKernelGGL(probe_lds_read_kernel<-8>, dim3(blocks), dim3(512), 0, 0, out, iters); break;
+      default: hipLaunchKernelGGL(probe_lds_read_kernel<4>, dim3(blocks), dim3(512), 0, 0, out, iters); break;
+    }
+  };
+  launch();
+  const int reps = 10;
+  MMH_HIP_TRY(hipEventRecord(t0, 0), err);
+  for (int r = 0; r < reps; ++r) launch();
+  MMH_HIP_TRY(hipEventRecord(t1, 0), err);
+  MMH_HIP_TRY(hipEventSynchronize(t1), err);
+  float ms = 0.f;
+  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
+  const int w = width < 0 ? -width : width;
+  *gbps = (float)((double)blocks * 512 * 8 * w * iters * reps / (ms * 1e-3) / 1e9);
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  (void)hipFree(out);
   return MMH_OK;
 }
 

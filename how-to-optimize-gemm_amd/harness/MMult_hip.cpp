@@ -9,7 +9,9 @@
 // ABI (mmh_sgemm_host); all arithmetic happens in the gfx950 kernels.
 //
 // A second overload mirrors the CUDA directory's device-pointer flavour
-// (cuda/test_MMult.cpp:13-14: leading handle argument, C = A*B, asynchronous).
+// (cuda/test_MMult.cpp:13-14: leading handle argument, C = A*B, asynchronous); a third the
+// vulkan directory's (vulkan/test_MMult.cpp:10,55: six arguments, host pointers, dense row-major,
+// C = A*B, returns the device milliseconds of the GEMM -- _Z8MY_MMultiiiPfS_S_).
 //
 // Kernel variant: environment variable MMULT_KERNEL = auto (default) | mfma | mfma256 |
 // mfma_256x256 | mfma_128x64 | mfma_64x64 | mfma_pipe | mfma_simple | valu | naive (the run-time form of the reference's
@@ -74,4 +76,12 @@ void MY_MMult(mmh_handle_t handle, int m, int n, int k, float *d_A, int lda, flo
               float *d_C, int ldc) {
   const int st = mmh_sgemm(handle, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, /*accumulate=*/0, nullptr);
   if (st != MMH_OK) die(st, "mmh_sgemm");
+}
+
+// vulkan-directory flavour: C = A*B on dense row-major host buffers; returns the GEMM's device time in ms
+float MY_MMult(int m, int n, int k, float *a, float *b, float *c) {
+  float ms = 0.0f;
+  const int st = mmh_sgemm_host_timed(default_handle(), m, n, k, a, k, b, n, c, n, /*accumulate=*/0, &ms);
+  if (st != MMH_OK) die(st, "mmh_sgemm_host_timed");
+  return ms;
 }

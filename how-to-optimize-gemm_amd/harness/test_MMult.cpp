@@ -47,6 +47,10 @@
 //                              sweeps under profiles/ use 3, so that one transient (another process's
 //                              burst, a clock dip) does not own a point
 //   EXTENDED=1                 extra columns: pct_of_fp32_mfma_peak ref_gflops ref_cores
+//   PROBES=1                   before the sweep, measure the denominators on this device and print them on
+//                              STDERR (stdout keeps the reference's format): MFMA-only fp32 TFLOP/s, HBM
+//                              copy / read GB/s, LDS fragment-read GB/s -- the idea of
+//                              aarch64/gflops_benchmark/main.c:19-25 and vulkan/benchmark/*.cpp
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -69,7 +73,7 @@ struct Options {
   int m = sweep_defaults::kM, n = sweep_defaults::kN, k = sweep_defaults::kK;
   int nrepeats = sweep_defaults::kRepeats;
   int lda = sweep_defaults::kLda, ldb = sweep_defaults::kLdb, ldc = sweep_defaults::kLdc;
-  int warmup = 0, warmup_ms = 0, extended = 0, ngpus = 1, splitk = 0, trials = 1;
+  int warmup = 0, warmup_ms = 0, extended = 0, ngpus = 1, splitk = 0, trials = 1, probes = 0;
   std::string kernel = "auto", flavour = "device", input = "drand48", ref = "threads";
 };
 
@@ -129,6 +133,7 @@ int main(int argc, char **argv) {
   opt_int(argc, argv, "EXTENDED", o.extended);
   opt_int(argc, argv, "WARMUP_MS", o.warmup_ms);
   opt_int(argc, argv, "TRIALS", o.trials);
+  opt_int(argc, argv, "PROBES", o.probes);
   if (o.trials < 1) o.trials = 1;
   opt_int(argc, argv, "NGPUS", o.ngpus);
   opt_int(argc, argv, "SPLITK", o.splitk);
@@ -150,6 +155,16 @@ int main(int argc, char **argv) {
     MMH_CHECK(mmh_create(&handle, 0));
     MMH_CHECK(mmh_device_info(0, name, &cus, &mhz));
     std::printf("GPU Device %d: \"%s\" with %d CUs @ %d MHz\n\n", 0, name, cus, mhz);
+    if (o.probes) {
+      float mfma = 0, copy = 0, read = 0, lds = 0;
+      MMH_CHECK(mmh_probe_mfma_f32(handle, &mfma));
+      MMH_CHECK(mmh_probe_hbm_copy(handle, (size_t)1 << 30, &copy));
+      MMH_CHECK(mmh_probe_hbm_read(handle, (size_t)1 << 30, &read));
+      MMH_CHECK(mmh_probe_lds_read(handle, 16, &lds));
+      std::fprintf(stderr, "probes: mfma_f32 %.1f TFLOP/s, hbm copy %.0f GB/s, hbm read %.0f GB/s, lds read %.0f GB/s"
+                           " (%.1f B/clk/CU at %d MHz)\n",
+                   mfma, copy, read, lds, lds * 1e9 / ((double)mhz * 1e6 * cus), mhz);
+    }
     if (kid >= 0) MMH_CHECK(mmh_set_kernel(handle, kid));
     if (o.splitk) MMH_CHECK(mmh_set_option(handle, MMH_OPT_SPLITK, o.splitk));
     if (sharded) {

@@ -21,6 +21,10 @@
  *                     (armv7/MMult0.c:9-24, aarch64/MMult0.cpp:3-19).
  *   mmh_sgemm_host    host-pointer MY_MMult (armv7/test_MMult.c:8,76;
  *                     aarch64/test_MMult.cpp:17,113): does H2D, kernel, D2H.
+ *   mmh_sgemm_host_timed  the third flavour of the symbol, `float MY_MMult(m, n, k, a, b, c)`
+ *                     of the vulkan directory (vulkan/test_MMult.cpp:10,55): host pointers,
+ *                     C = A*B, RETURNS the device time of the GEMM in milliseconds
+ *                     (vulkan/MMult_vk_3.cpp:38-46 brackets the dispatch with timestamps).
  *   mmh_create/destroy the cublasHandle_t lifetime in the harness
  *                     (cuda/test_MMult.cpp:43-44,142).
  *   mmh_set_kernel    the makefile's `NEW := MMult_cuda_N` selection
@@ -186,6 +190,12 @@ int mmh_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, int lda
 int mmh_sgemm_host(mmh_handle_t handle, int m, int n, int k, const float *A, int lda,
                    const float *B, int ldb, float *C, int ldc, int accumulate);
 
+/* The same call in the plain staged form (copy in, ONE launch, copy out) with the launch bracketed by
+ * two events: *kernel_ms receives the device time of the GEMM alone, copies excluded -- what the
+ * reference's Vulkan flavour of MY_MMult returns (vulkan/test_MMult.cpp:55 sums it over NREPEATS). */
+int mmh_sgemm_host_timed(mmh_handle_t handle, int m, int n, int k, const float *A, int lda,
+                         const float *B, int ldb, float *C, int ldc, int accumulate, float *kernel_ms);
+
 /* int8 x int8 -> int32, C = A*B (+ C), row-major, inputs expected in
  * [-127,127]; bit-exact integer arithmetic on v_mfma_i32_16x16x64_i8.  4-byte aligned operands
  * (bases and leading dimensions) are read in place; others are first copied into dense aligned
@@ -270,6 +280,12 @@ int mmh_probe_mfma_i8(mmh_handle_t handle, float *tops);   /* v_mfma_i32_16x16x6
 int mmh_probe_mfma_i8_sustained(mmh_handle_t handle, int random_operands, float min_ms, float *tops);
 int mmh_probe_hbm_copy(mmh_handle_t handle, size_t bytes, float *gbps);
 int mmh_probe_hbm_read(mmh_handle_t handle, size_t bytes, float *gbps);
+/* LDS fragment reads and nothing else (the idea of vulkan/benchmark/smem_bandwidth.cpp:30-42), summed
+ * over the chip in GB/s: width = bytes per lane, 16 (ds_read_b128), 8 (ds_read_b64), 4 (ds_read_b32)
+ * or -8 (ds_read_b64_tr_b8, the transposing read of the in-place int8 kernel).  The roof for the 8- and
+ * 16-byte reads is 256 B/clk/CU (MI355X_MICROARCH.md, LDS) = 157 TB/s at 2.4 GHz x 256 CUs, half that
+ * for ds_read_b32. */
+int mmh_probe_lds_read(mmh_handle_t handle, int width, float *gbps);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ def test_null_handle_is_an_error_not_a_crash():
     L = H.lib()
     assert L.mmh_sgemm(None, 1, 1, 1, None, 1, None, 1, None, 1, 0, None) == H.ERR_INVALID_ARG
     assert L.mmh_sgemm_host(None, 1, 1, 1, None, 1, None, 1, None, 1, 0) == H.ERR_INVALID_ARG
+    assert L.mmh_sgemm_host_timed(None, 1, 1, 1, None, 1, None, 1, None, 1, 0, None) == H.ERR_INVALID_ARG
     assert L.mmh_destroy(None) == H.OK
     assert L.mmh_set_kernel(None, 2) == H.ERR_INVALID_ARG
 

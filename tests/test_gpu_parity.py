@@ -74,6 +74,19 @@ def test_golden_fixtures_host_flavour(mm, oracle, name):
     assert d <= tol(g["k"])
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 64), (512, 512, 512), (300, 200, 100), (2048, 1024, 512)])
+def test_vulkan_flavour_returns_the_chain_and_a_device_time(mm, oracle, shape):
+    """`float MY_MMult(m, n, k, a, b, c)` (vulkan/test_MMult.cpp:10,55): dense row-major host buffers,
+    C = A*B whatever C held, returns the GEMM's device milliseconds."""
+    m, n, k = shape
+    a, b = oracle.harness_inputs(m, n, k, seed=77 + m)
+    c = np.full((m, n), np.nan, dtype=np.float32)
+    mm.set_kernel("auto")
+    ms = mm.MY_MMult_ms(m, n, k, a, b, c)
+    assert np.array_equal(c, oracle.ref_mmult(a, b, fma=True))
+    assert 0.0 < ms < 50.0
+
+
 SHAPES = [(256, 256, 256), (384, 640, 1024), (128, 128, 32), (128, 256, 4096), (1000, 1000, 1000),
           (130, 129, 37), (3, 5, 7), (257, 255, 513), (512, 128, 2048), (1024, 1024, 1024)]
 
@@ -913,6 +926,20 @@ def test_host_flavour_pipeline_keeps_the_bits(oracle, panels):
             assert np.array_equal(got, oracle.ref_mmult(a[:, :k], b[:, :n], fma=True))
     finally:
         h.close()
+
+
+def test_lds_probe_reads_a_plausible_rate(mm):
+    """256 B/clk/CU x 256 CUs x 2.4 GHz = 157 TB/s is the LDS roof of the 8- and 16-byte reads
+    (MI355X_MICROARCH.md, LDS), half that for ds_read_b32: the 16-byte fragment read must land within
+    (50 %, 105 %) of it and the 4-byte read under 105 % of its own."""
+    import how_to_optimize_gemm_amd as H
+    wide = mm.probe_lds_read(16)
+    assert 0.5 * 157300 < wide < 1.05 * 157300, wide
+    assert 0 < mm.probe_lds_read(4) < 1.05 * 78600
+    for w in (8, -8):
+        assert 0 < mm.probe_lds_read(w) < 1.05 * 157300
+    with pytest.raises(H.MMultError):
+        mm.probe_lds_read(12)
 
 
 def test_entry_points_restore_the_callers_device(mm):

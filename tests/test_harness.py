@@ -15,6 +15,7 @@ HARNESS = os.path.join(REPO, "how-to-optimize-gemm_amd", "harness")
 EXE = os.path.join(HARNESS, "test_MMult.x")
 DROPIN_AARCH64 = os.path.join(REPO, "oracle", "_ref", "test_MMult_dropin_aarch64.x")
 DROPIN = os.path.join(REPO, "oracle", "_ref", "test_MMult_dropin.x")
+DROPIN_VULKAN = os.path.join(REPO, "oracle", "_ref", "test_MMult_dropin_vulkan.x")
 ROW = re.compile(r"^(\d+) (\d+\.\d+) (-?\d\.\d+e[+-]\d+) $")          # cuda flavour: %d %.2f %le
 ROW_LE = re.compile(r"^(\d+) (\d\.\d+e[+-]\d+) (-?\d\.\d+e[+-]\d+) $")  # armv7 flavour: %d %le %le
 
@@ -50,6 +51,7 @@ def test_builds_and_exports_reference_symbol():
     build()
     out = subprocess.check_output(["nm", os.path.join(HARNESS, "MMult_hip.o")], text=True)
     assert " T _Z8MY_MMultiiiPfiS_iS_i" in out            # 9-arg host flavour, C++ linkage
+    assert " T _Z8MY_MMultiiiPfS_S_" in out                # 6-arg vulkan-directory flavour (returns ms)
 
 
 def test_cpu_plumbing_config1():
@@ -181,3 +183,35 @@ def test_reference_aarch64_driver_linked_against_our_MY_MMult():
     rows = parse(out, ROW_LE)
     assert [r[0] for r in rows] == list(range(48, 961, 48))
     assert all(r[2] == 0.0 for r in rows)
+
+
+@pytest.mark.gpu
+def test_reference_vulkan_driver_linked_against_our_MY_MMult():
+    """The reference's vulkan/test_MMult.cpp + REF_MMult.cpp + compare_matrices.cpp + random_matrix.cpp
+    (plain C++: `float MY_MMult(m, n, k, a, b, c)` returns milliseconds, drand48 inputs in [-1, 1),
+    sweep 64..512 step 64) with ONLY MY_MMult replaced by ours.  oracle/Makefile compiles the
+    reference's files with -mfma -ffp-contract=fast -- the REF loop as FMA hardware runs it -- so the
+    diff column is EXACTLY 0 on random inputs, and the GFLOPS column comes from the milliseconds our
+    MY_MMult returned (the GEMM's device time)."""
+    if not os.path.exists(DROPIN_VULKAN):
+        pytest.skip("oracle/_ref/test_MMult_dropin_vulkan.x was not built (no /root/reference at build time)")
+    rc, out, err = run({}, exe=DROPIN_VULKAN)
+    assert rc == 0, err
+    rows = parse(out, ROW)        # vulkan/test_MMult.cpp:82-83 prints '%d %.2f %le '
+    assert [r[0] for r in rows] == list(range(64, 513, 64))
+    assert all(r[2] == 0.0 for r in rows)
+    assert all(r[1] > 0.0 for r in rows)      # a real device time came back from every call
+
+
+@pytest.mark.gpu
+def test_probes_go_to_stderr_and_leave_the_result_format_alone():
+    build()
+    rc, out, err = run({"PFIRST": 256, "PLAST": 256, "PROBES": 1, "REF": "serial"})
+    assert rc == 0, err
+    rows = parse(out)
+    assert [r[0] for r in rows] == [256]
+    mobj = re.search(r"probes: mfma_f32 (\d+\.\d) TFLOP/s, hbm copy (\d+) GB/s, hbm read (\d+) GB/s, "
+                     r"lds read (\d+) GB/s \((\d+\.\d) B/clk/CU", err)
+    assert mobj, err
+    assert 100 < float(mobj.group(1)) < 170 and 3000 < float(mobj.group(2)) < 8000
+    assert 100 < float(mobj.group(5)) <= 260      # the roof of ds_read_b128 is 256 B/clk/CU
