@@ -1590,6 +1590,17 @@ int mmh_probe_hbm_read(mmh_handle_t h, size_t bytes, float *gbps) {
   return mmh::probe_hbm_copy(bytes, gbps, &g_last_error, h->cu_count, 1);
 }
 
+#ifdef MMH_AB_BUILD
+// A/B library only: where the plain LDS-DMA kernels write their timeline stamps (4 x uint64 per workgroup;
+// NULL switches them off).  tools/dma_timeline.py.
+int mmh_ab_set_stamps(mmh_handle_t h, void *stamps) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mmh::g_dma_stamps), &stamps, sizeof(void *)));
+  return MMH_OK;
+}
+#endif
+
 int mmh_probe_lds_read(mmh_handle_t h, int width, float *gbps) {
   if (!h || !gbps || (width != 16 && width != 8 && width != 4 && width != -8)) return MMH_ERR_INVALID_ARG;
   ENTER(h);

@@ -43,13 +43,34 @@
 // What was tried and dropped (profiles/r02_ablation.md): four ring buffers (no faster); a run-time ring
 // index instead of the unrolled ring (-17 %: an address v_add per fragment read); 8-wave tiles, 256x128
 // with three buffers and 256x256 with two -- under the 256-register budget they need the run-time
-// ring and then trail the register-staged 256x256 kernel (143-147 vs 149-150 TFLOP/s at N >= 4096).
+// ring and then trail the register-staged 256x256 kernel (143-147 vs 149-150 TFLOP/s at N >= 4096);
+// the 64x64 tile as EIGHT waves of 16x32 (two waves per SIMD from one workgroup, for tile counts near one
+// per CU): 108.2 vs 108.2 TFLOP/s at N=1024 -- a short launch's K loop runs at 73-78 % of the matrix
+// pipe's rate either way (tools/dma_timeline.py), the LDS-DMA pieces cost what they cost whoever issues them.
 #pragma once
 #include <type_traits>
 
 #include "sgemm_tile.hpp"
 
 namespace mmh {
+
+// Timeline stamps for tools/dma_timeline.py (the A/B library only): workgroup b writes the wall clock at
+// kernel entry, after the prologue's barrier, after its K loop and after its C stores have completed.
+#ifdef MMH_AB_BUILD
+__device__ unsigned long long *g_dma_stamps = nullptr;
+__device__ __forceinline__ void dma_stamp(int i) {
+  if (g_dma_stamps && threadIdx.x == 0) g_dma_stamps[(size_t)blockIdx.x * 4 + i] = wall_clock64();
+}
+__device__ __forceinline__ void dma_stamp_after_stores(int i) {
+  if (g_dma_stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dma_stamp(i);
+  }
+}
+#else
+__device__ __forceinline__ void dma_stamp(int) {}
+__device__ __forceinline__ void dma_stamp_after_stores(int) {}
+#endif
 
 // One 1 KiB LDS-DMA piece: lane L's 16 bytes land at dst + 16 L.  (A static member of a class, like
 // LdsDma in igemm_s8.hpp: buffer descriptors in the signature of a function template trip hipcc's host pass.)
@@ -61,7 +82,7 @@ struct DmaPiece {
 
 template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
 struct DmaTile {
-  static_assert((WTM == 2 || WTM == 4) && (WTN == 2 || WTN == 4), "wave tile is 32|64 x 32|64");
+  static_assert((WTM == 1 || WTM == 2 || WTM == 4) && (WTN == 2 || WTN == 4), "wave tile is 16|32|64 x 32|64 (16: measured, not shipped)");
   static_assert(KB == 32 || KB == 64 || KB == 128, "a K-slice row of A is 128, 256 or 512 bytes");
   static_assert(BN == 64 || BN == 128 || BN == 256, "a k-row of B is 256, 512 or 1024 bytes");
   static_assert(NBUF == 3, "a ring of three K-slice buffers");
@@ -186,6 +207,7 @@ static __device__ __forceinline__ void run(float *lds, int m, int n, int k, cons
   });
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * ND) : "memory");
   __builtin_amdgcn_s_barrier();
+  dma_stamp(1);
   // Fragments are read D = 2 k-steps ahead of the MFMAs that use them, into a ring of four register
   // sets (slot = k-step mod 4; KS is a multiple of 4, so the slot numbering carries over from slice to
   // slice): with four MFMAs (128 matrix-pipe cycles) per k-step one step of distance does not cover an
@@ -260,8 +282,13 @@ static __device__ __forceinline__ void run(float *lds, int m, int n, int k, cons
   // reads that follow each slice's barrier into the NEXT slice's block (they are dead on the exit path)
   // and the first k-step of every slice waits for them
 #pragma unroll
-  for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]), "v"(fb[i]));
+  for (int i = 0; i < 4; ++i) {
+    asm volatile("" ::"v"(fb[i]));
+#pragma unroll
+    for (int t = 0; t < WTM; ++t) asm volatile("" ::"v"(fa[i][t]));   // (element-wise: a 1-vector has no register class)
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-length tail DMAs: nothing may still be landing in LDS
+  dma_stamp(2);
 
   // split-K finisher (see mfma_tile_segment): add the other parts' partial tiles in part order
   if (fix.count > 0) {
@@ -330,8 +357,10 @@ sgemm_mfma_dma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                       float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int tm, tn;
+  dma_stamp(0);
   block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
   DmaSegment<BM, BN, KB, WTM, WTN, NBUF>::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0, k / KB, accumulate != 0);
+  dma_stamp_after_stores(3);
 }
 
 // Segment policy of this tile for the chained stream-K control flow (streamk_body in sgemm_mfma.hpp,
