@@ -74,6 +74,16 @@ def use_ab_library() -> str:
     return AB_LIB_PATH
 
 
+def use_timeline_library() -> str:
+    """tools/dma_timeline.py only: the A/B library built with per-workgroup timeline stamps."""
+    global _lib_path
+    if _lib is not None:
+        raise MMultError(ERR_INVALID_ARG, "use_timeline_library", "a library is already loaded")
+    from . import build as _build
+    _lib_path = _build.build_timeline_library()
+    return _lib_path
+
+
 def _share_hip_runtime_with_torch() -> None:
     """One process must hold ONE HIP runtime.  PyTorch's ROCm wheels bundle their
     own libamdhip64.so.7; libmmult_hip.so needs the same SONAME.  If this
@@ -575,7 +585,7 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
 
 
 __all__ = ["MMult", "ShardedMMult", "MMultError", "lib", "use_ab_library", "device_count", "rccl_version", "shard_rows",
-           "kernel_name", "last_launch", "sgemm_sharded", "KERNELS", "CHAIN_KERNELS", "AB_LIB_PATH",
+           "kernel_name", "last_launch", "use_timeline_library", "sgemm_sharded", "KERNELS", "CHAIN_KERNELS", "AB_LIB_PATH",
            "OPT_SPLITK", "OPT_HOST_PANELS", "OPT_STREAMK_SPIN_LIMIT", "OPT_FAULT_INJECT", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
            "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OPT_IGEMM_MODE", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

@@ -53,6 +53,18 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_timeline_library(force: bool = False) -> str:
+    """-DMMH_AB_BUILD -DMMH_DMA_TIMELINE -> libmmult_hip_tl.so: the A/B library whose plain LDS-DMA kernels
+    also write per-workgroup wall-clock stamps (tools/dma_timeline.py only; the stamps perturb the
+    schedule of the big tiles, so no other tool measures with this build)."""
+    target = os.path.join(PKG_DIR, "libmmult_hip_tl.so")
+    if force or _stale(target, library_sources()):
+        subprocess.check_call([hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMMH_AB_BUILD",
+                               "-DMMH_DMA_TIMELINE", "-Wno-unused-result", os.path.join(CSRC, "mmult_hip.hip"), "-o",
+                               target, "-ldl"])
+    return target
+
+
 def build_ab_library(force: bool = False, verbose: bool = False) -> str:
     """The same sources with -DMMH_AB_BUILD -> libmmult_hip_ab.so: the product kernels PLUS the
     scheduling A/B variants and the timing-only ablation builds (wrong results).  Loaded by

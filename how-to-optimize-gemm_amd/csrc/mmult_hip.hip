@@ -507,6 +507,20 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       // runs as a stream-K launch when its tile count is ragged.
       const long tiles128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);
       const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
+      // The 64x64 LDS-DMA tile with three workgroups co-resident per CU has the most efficient loop of
+      // all (150 TFLOP/s at N = 3072, where 2304 tiles are exactly nine per CU; 151.6-152.9 at 5120 ..
+      // 8192 against 148.5-150.4 for the 256x256 tile) -- on a PLAIN launch: under the chained stream-K
+      // launch its workgroups run at different K phases and stop sharing operand slices in L2 (hit rate
+      // 81 % -> 22 %, 2.4 GB of fabric traffic per launch, profiles/r02_ablation.md section 9).  So it is
+      // chosen for whole-tile shapes with many tiles (>= 6 per CU) that fill their last round of CUs to
+      // >= 97.5 % (N = 2688, 3072, 3200, 4096 on the reference sweep; every large shape).
+      {
+        const long tiles64 = (long)((m + 63) / 64) * ((n + 63) / 64);
+        const long rounds64 = (tiles64 + cus - 1) / cus;
+        if (tiles64 >= 6 * cus && tiles64 * 1000 >= rounds64 * cus * 975 && window_ok(64, 64, k, lda, ldb) &&
+            fast_shape(64, 64, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
+          return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
+      }
       // At least one 256x256 tile per CU: the big tile (fewest staging ops per MFMA) -- unless its
       // edge tiles pad the shape noticeably more than 128x128 tiles would (an edge tile costs a whole
       // tile's time; ragged tile COUNTS are balanced by stream-K for either size).
@@ -673,6 +687,22 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return launch_mfma<64, 64, false, 4, 7, true, 2, 2, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
     case 44:
       return launch_mfma<64, 64, false, 4, 15, true, 2, 2, 128>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+    // A/B (valid results): the LDS-DMA tiles as EIGHT waves -- two waves per SIMD from one workgroup
+    case 45: {  // 64x64, waves of 16x32
+      const int sk = try_launch_streamk_dma<64, 64, 32, 1, 2, 3>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      return try_launch_dma<64, 64, 32, 1, 2, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    }
+    case 46: {  // 128x64, waves of 32x32
+      const int sk = try_launch_streamk_dma<128, 64, 32, 2, 2, 3>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      return try_launch_dma<128, 64, 32, 2, 2, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    }
+    case 47: {  // 128x128, waves of 64x32
+      const int sk = try_launch_streamk_dma<128, 128, 32, 4, 2, 3>(ctx, m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s);
+      if (sk <= 0) return sk;
+      return try_launch_dma<128, 128, 32, 4, 2, 3>(m, n, k, dA, lda, dB, ldb, dC, ldc, acc, s) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    }
 #endif
     default:
       g_last_error = "unknown kernel variant";
@@ -1064,6 +1094,9 @@ const char *mmh_kernel_name(int kernel) {
     case 42: return "ablate64x64_no_gload_no_ldswrite";
     case 43: return "ablate64x64_no_gload_no_ldswrite_no_barrier";
     case 44: return "ablate64x64_mfma_only";
+    case 45: return "exp_dma_64x64_8waves";
+    case 46: return "exp_dma_128x64_8waves";
+    case 47: return "exp_dma_128x128_8waves";
 #endif
     default: return nullptr;
   }
@@ -1590,8 +1623,8 @@ int mmh_probe_hbm_read(mmh_handle_t h, size_t bytes, float *gbps) {
   return mmh::probe_hbm_copy(bytes, gbps, &g_last_error, h->cu_count, 1);
 }
 
-#ifdef MMH_AB_BUILD
-// A/B library only: where the plain LDS-DMA kernels write their timeline stamps (4 x uint64 per workgroup;
+#ifdef MMH_DMA_TIMELINE
+// timeline build only: where the plain LDS-DMA kernels write their timeline stamps (4 x uint64 per workgroup;
 // NULL switches them off).  tools/dma_timeline.py.
 int mmh_ab_set_stamps(mmh_handle_t h, void *stamps) {
   if (!h) return MMH_ERR_INVALID_ARG;

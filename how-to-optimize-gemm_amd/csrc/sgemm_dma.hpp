@@ -54,9 +54,10 @@
 
 namespace mmh {
 
-// Timeline stamps for tools/dma_timeline.py (the A/B library only): workgroup b writes the wall clock at
-// kernel entry, after the prologue's barrier, after its K loop and after its C stores have completed.
-#ifdef MMH_AB_BUILD
+// Timeline stamps for tools/dma_timeline.py (its own build, -DMMH_DMA_TIMELINE, only): workgroup b writes
+// the wall clock at kernel entry, after the prologue's barrier, after its K loop and after its C stores
+// have completed.
+#ifdef MMH_DMA_TIMELINE
 __device__ unsigned long long *g_dma_stamps = nullptr;
 __device__ __forceinline__ void dma_stamp(int i) {
   if (g_dma_stamps && threadIdx.x == 0) g_dma_stamps[(size_t)blockIdx.x * 4 + i] = wall_clock64();

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Where does a short LDS-DMA launch spend its time?  Each workgroup of the plain K2L kernels (A/B library
-only) stamps the wall clock at entry, after its prologue, after its K loop and after its C stores; this
+"""Where does a short LDS-DMA launch spend its time?  Each workgroup of the plain K2L kernels (a build of its
+own, libmmult_hip_tl.so) stamps the wall clock at entry, after its prologue, after its K loop and after its C stores; this
 prints the distribution of each phase over the workgroups of ONE launch, next to the launch's
 back-to-back hipEvent time.
 usage: python tools/dma_timeline.py [--kernel mfma_64x64_dma] [--n 1024] [--launches 40]"""
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import how_to_optimize_gemm_amd as H  # noqa: E402
 
-H.use_ab_library()
+H.use_timeline_library()
 ap = argparse.ArgumentParser()
 ap.add_argument("--kernel", default="mfma_64x64_dma")
 ap.add_argument("--n", type=int, nargs="+", default=[1024])

@@ -19,6 +19,8 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--variants", default="auto,mfma_64x64_dma,mfma_128x64_dma,mfma_128x128_dma,mfma_64x64,mfma_128x64,mfma_tiles,"
                                        "mfma_splitk:0,auto:1,rocblas,hipblaslt,valu,valu_128x128,valu_64x64")
 args = ap.parse_args()
+if os.environ.get("MMH_AB") == "1":       # numeric variants = ids of the A/B library (e.g. 45/nosk)
+    H.use_ab_library()
 sizes = [int(x) for x in args.sizes.split(",")]
 variants = args.variants.split(",")
 mm = H.MMult(0)
@@ -61,7 +63,11 @@ for n in sizes:
             else:
                 name, _, s = v.partition(":")
                 nosk, sk2 = name.endswith("/nosk"), name.endswith("/sk2")   # without stream-K / stream-K whenever ragged
-                mm.set_kernel(name[:-5] if nosk else (name[:-4] if sk2 else name))
+                base = name[:-5] if nosk else (name[:-4] if sk2 else name)
+                if base.isdigit():
+                    assert H.lib().mmh_set_kernel(mm._h, int(base)) == 0, base
+                else:
+                    mm.set_kernel(base)
                 mm.set_streamk(0 if nosk else (2 if sk2 else 1))
                 mm.set_splitk(int(s) if s else 0)
                 ms = mm.time_sgemm(n, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, warmup=5,
