@@ -9,10 +9,9 @@ already resident in HBM (the reference excludes H2D/D2H from its timed region
 too: cuda/test_MMult.cpp:85-98,121).
 
   N = 1  workload = BASELINE.json configs[2]: fp32 N=4096 square SGEMM on the
-         MFMA kernel (MMH_KERNEL_AUTO picks the 64x64 LDS-DMA tile at this size:
-         4096 tiles, exactly 16 per CU, three workgroups co-resident per CU)
-         -- the configuration the headline metric ("% of MI355X fp32 MFMA peak
-         at N=4096") is quoted on.
+         MFMA kernel (MMH_KERNEL_AUTO picks the 256x256-tile configuration of it
+         at this size) -- the configuration the headline metric ("% of MI355X
+         fp32 MFMA peak at N=4096") is quoted on.
   N > 1  workload = configs[3]: fp32 N=16384, C row panels sharded over the N
          ranks (mmh_shard_rows), B replicated by one RCCL broadcast from rank 0
          BEFORE the timed region (it is data placement, the multi-GPU analogue

@@ -118,6 +118,7 @@ struct mmh_context {
   int *sticky_dev = nullptr;   // device view of the same word
   long long spin_limit = 1ll << 26;
   int fault = 0;               // MMH_OPT_FAULT_INJECT
+  int pin = 1;                 // persistent / sparse launches ask for 160 KiB / w of LDS so that exactly w workgroups fit a CU
   // the hand-off workspaces above are per handle: a launch on another stream first waits for the
   // stream that used them last
   hipStream_t ws_stream = nullptr;
@@ -312,8 +313,19 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int thr
   rc = ctx->parts.reserve((size_t)grid * BM * BN * sizeof(float));   // one partial-tile slot per range
   if (rc != MMH_OK) return rc;
   float *parts = static_cast<float *>(ctx->parts.p);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm, nbn,
-                     flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault);
+  // The ranges assume every workgroup owns 1/w of a CU.  When more than w would FIT (a 48 KiB ring three
+  // times), nothing obliges the dispatcher to spread grid = w x CUs workgroups evenly -- seen as a bimodal
+  // rate (N = 1536: 130 or 100 TFLOP/s from run to run) -- so the launch asks for 160 KiB / w of LDS:
+  // exactly w workgroups fit, every CU gets its share.
+  size_t lds_launch = lds;
+  if (ctx->pin) {
+    const size_t share = ((size_t)(160 * 1024) / (size_t)(grid / cus)) & ~(size_t)255;
+    if (share > lds_launch) lds_launch = share;
+    const int ok = allow_big_lds(kern, lds_launch);
+    if (ok != MMH_OK) return ok;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds_launch, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm,
+                     nbn, flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault);
   HIP_TRY(hipGetLastError());
   {
     char buf[200];
@@ -508,17 +520,24 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       const long tiles128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);
       const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
       // The 64x64 LDS-DMA tile with three workgroups co-resident per CU has the most efficient loop of
-      // all (150 TFLOP/s at N = 3072, where 2304 tiles are exactly nine per CU; 151.6-152.9 at 5120 ..
+      // all (148.5-150 TFLOP/s at N = 3072, where 2304 tiles are exactly nine per CU; 151.6-152.9 at 5120 ..
       // 8192 against 148.5-150.4 for the 256x256 tile) -- on a PLAIN launch: under the chained stream-K
       // launch its workgroups run at different K phases and stop sharing operand slices in L2 (hit rate
       // 81 % -> 22 %, 2.4 GB of fabric traffic per launch, profiles/r02_ablation.md section 9).  So it is
       // chosen for whole-tile shapes with many tiles (>= 6 per CU) that fill their last round of CUs to
-      // >= 97.5 % (N = 2688, 3072, 3200, 4096 on the reference sweep; every large shape).
+      // >= 97.5 % (N = 2688, 3072, 3200 on the reference sweep; every large shape).
+      // One exception: whole rounds of 256x256 tiles in a SHORT launch (N = 4096: one tile per CU, 0.93 ms).
+      // Sustained the two are level there (148.5-149.4 vs 148.7-150.5), but from an idle clock the big
+      // tile is within 1 % of its rate after 18 launches and the small one after 40 -- and 20 launches
+      // from idle is what the reference's timing convention measures (137 vs 129 TFLOP/s,
+      // profiles/r02_cold_start.txt).
       {
         const long tiles64 = (long)((m + 63) / 64) * ((n + 63) / 64);
         const long rounds64 = (tiles64 + cus - 1) / cus;
-        if (tiles64 >= 6 * cus && tiles64 * 1000 >= rounds64 * cus * 975 && window_ok(64, 64, k, lda, ldb) &&
-            fast_shape(64, 64, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
+        const double est_ms = 2.0 * (double)m * (double)n * (double)k / 150e9;
+        const bool whole_rounds_256 = tiles256 >= cus && tiles256 % cus == 0 && m % 256 == 0 && n % 256 == 0;
+        if (!(whole_rounds_256 && est_ms < 2.0) && tiles64 >= 6 * cus && tiles64 * 1000 >= rounds64 * cus * 975 &&
+            window_ok(64, 64, k, lda, ldb) && fast_shape(64, 64, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
           return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
       }
       // At least one 256x256 tile per CU: the big tile (fewest staging ops per MFMA) -- unless its
@@ -735,6 +754,7 @@ int create_context(mmh_context **out, int device) {
   ctx->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+  if (const char *e = std::getenv("MMH_NO_PIN")) ctx->pin = (*e && *e != '0') ? 0 : 1;   // diagnostic A/B switch
   // the sticky error word: pinned, mapped host memory (the device adds to it with a system-scope atomic)
   void *host = nullptr, *dev = nullptr;
   if (hipHostMalloc(&host, 64, hipHostMallocMapped) == hipSuccess) {
@@ -1017,6 +1037,11 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       h->fault = value ? 1 : 0;
       h->flags_dirty = true;
       return MMH_OK;
+#ifdef MMH_AB_BUILD
+    case 100:   // A/B: pin the residency of persistent launches by their LDS request (default on)
+      h->pin = value ? 1 : 0;
+      return MMH_OK;
+#endif
     default:
       return MMH_ERR_INVALID_ARG;
   }

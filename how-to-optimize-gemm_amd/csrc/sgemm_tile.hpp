@@ -55,20 +55,21 @@ __device__ __forceinline__ int swz_slot(int c) { return (c & 7) | ((c & 4) << 1)
 // hipGraph after one eager warm-up call).
 inline hipError_t opt_in_big_lds(const void *kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
+  struct Done { const void *kernel; int dev; size_t bytes; };
   static std::mutex mu;
-  static std::vector<std::pair<const void *, int>> done;
+  static std::vector<Done> done;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   {
     std::lock_guard<std::mutex> lock(mu);
     for (const auto &d : done)
-      if (d.first == kernel && d.second == dev) return hipSuccess;
+      if (d.kernel == kernel && d.dev == dev && d.bytes >= bytes) return hipSuccess;
   }
   e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
   std::lock_guard<std::mutex> lock(mu);
-  done.emplace_back(kernel, dev);
+  done.push_back(Done{kernel, dev, bytes});
   return hipSuccess;
 }
 

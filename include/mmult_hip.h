@@ -162,7 +162,9 @@ const char *mmh_kernel_name(int kernel);
 #define MMH_OPT_HOST_PANELS 5
 /* Test hooks.  MMH_OPT_STREAMK_SPIN_LIMIT: hand-off wait bound in units of 1024 polls (default
  * 65536, seconds).  MMH_OPT_FAULT_INJECT (default 0): 1 = stream-K producers do not publish their
- * partial tiles, so that every dependent wait times out and the sticky error path can be exercised. */
+ * partial tiles, so that every dependent wait times out and the sticky error path can be exercised.
+ * (Diagnostic environment switch, read at mmh_create: MMH_NO_PIN=1 -- persistent launches then do not
+ * ask for 160 KiB / w of LDS to pin w workgroups per CU.) */
 #define MMH_OPT_STREAMK_SPIN_LIMIT 6
 #define MMH_OPT_FAULT_INJECT 7
 int mmh_set_option(mmh_handle_t handle, int option, int value);

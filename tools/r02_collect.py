@@ -31,7 +31,7 @@ cp("hbm_patterns.txt", "r02_hbm_patterns.txt")
 cp("host_flavour.txt", "r02_host_flavour.txt")
 cp("prof4096_kernel_stats.csv", "r02_sgemm4096_kernel_stats.csv")
 cp("prof4096_summary.json", "r02_sgemm4096_auto_rocprofv3.json")
-cp("prof4096_256_summary.json", "r02_sgemm4096_256x256_rocprofv3.json")
+cp("prof3072_summary.json", "r02_sgemm3072_dma64x64_rocprofv3.json")
 cp("cold_start.txt", "r02_cold_start.txt")
 cp("prof2048_summary.json", "r02_sgemm2048_dma128x64_rocprofv3.json")
 cp("prof1024_summary.json", "r02_sgemm1024_dma64x64_rocprofv3.json")
@@ -40,7 +40,7 @@ cp(os.path.join("i8prof", "summary.json"), "r02_igemm_s8_rocprofv3.json")
 
 # roofline.traffic: FETCH_SIZE (KiB, x2 on gfx950 for 16 B/lane coalesced reads) + WRITE_SIZE (KiB)
 traffic = {}
-for n, name in ((4096, "prof4096_summary.json"), ("4096_mfma_256x256", "prof4096_256_summary.json"),
+for n, name in ((4096, "prof4096_summary.json"), (3072, "prof3072_summary.json"),
                 (2048, "prof2048_summary.json"), (1024, "prof1024_summary.json")):
     p = os.path.join(SRC, name)
     if not os.path.exists(p):
@@ -57,7 +57,7 @@ for n, name in ((4096, "prof4096_summary.json"), ("4096_mfma_256x256", "prof4096
         "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
         "correction": "FETCH_SIZE x2 on gfx950 for 16 B/lane coalesced reads (MI355X_MICROARCH.md, HBM)",
         "hbm_bytes_per_launch": int(round(fetch * 1024 * 2 + write * 1024)),
-        "algorithmic_bytes_per_launch": 3 * 4 * (n if isinstance(n, int) else 4096) ** 2,
+        "algorithmic_bytes_per_launch": 3 * 4 * n * n,
         "l2_hit_rate": round(hit / (hit + miss), 4),
         "avg_us": d["kernel_stats"][0]["avg_us"], "dispatches_in_trace": d["kernel_stats"][0]["calls"],
         "round": 2,

@@ -40,23 +40,23 @@ for _ in range(3):
 PY
 cat $OUT/probes.txt
 hipcc --offload-arch=gfx950 -O3 tools/probes/hbm_patterns.hip -o /tmp/hbm_patterns 2> /dev/null && /tmp/hbm_patterns > $OUT/hbm_patterns.txt 2>&1
-# cold start of the two N=4096 candidates, fresh process each, alternating (auto = the 64x64 LDS-DMA tile)
+# cold start of the two N=4096 candidates, fresh process each, alternating (auto = the 256x256 tile)
 for i in 1 2 3; do
-  for kk in auto mfma_256x256; do
+  for kk in auto mfma_64x64_dma; do
     timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --kernel $kk 2> /dev/null | \
       python -c "import json,sys; d=json.load(sys.stdin); c=d['cold']; print('$kk', 'sustained', d['value'], 'launch1_ms', c['launch_1_ms'], 'first20', c['reference_convention_20_launches_no_warmup_tflops'], 'launches2to21', c['launches_2_to_21_tflops'], 'within1pct_after', c['launches_until_within_1pct_of_sustained'])" >> $OUT/cold_start.txt
     sleep 2
   done
 done
 cat $OUT/cold_start.txt
-# rocprofv3: the default bench command (N=4096, auto -> 64x64 LDS-DMA tile), the 256x256 tile beside it,
-# then the other LDS-DMA tiles (N=1024 / 2048)
+# rocprofv3: the default bench command (N=4096, auto -> 256x256 tile), then the LDS-DMA tiles
+# (N=3072: 64x64 tile, nine per CU; N=2048: 128x64; N=1024: 64x64, one per CU)
 TAG=r02f/prof4096 KERNEL=auto bash tools/gpu_profile.sh > $OUT/prof4096.log 2>&1
-TAG=r02f/prof4096_256 KERNEL=mfma_256x256 bash tools/gpu_profile.sh > $OUT/prof4096_256.log 2>&1
+TAG=r02f/prof3072 KERNEL=auto BENCH_ARGS="--n 3072" bash tools/gpu_profile.sh > $OUT/prof3072.log 2>&1
 TAG=r02f/prof1024 KERNEL=auto BENCH_ARGS="--n 1024" bash tools/gpu_profile.sh > $OUT/prof1024.log 2>&1
 TAG=r02f/prof2048 KERNEL=auto BENCH_ARGS="--n 2048" bash tools/gpu_profile.sh > $OUT/prof2048.log 2>&1
-python tools/summarize_profile.py $OUT/prof4096 "sgemm_mfma_dma_kernel" > $OUT/prof4096_summary.json 2>> $OUT/prof4096.log
-python tools/summarize_profile.py $OUT/prof4096_256 "sgemm_mfma_kernel" > $OUT/prof4096_256_summary.json 2>> $OUT/prof4096_256.log
+python tools/summarize_profile.py $OUT/prof4096 "sgemm_mfma_kernel" > $OUT/prof4096_summary.json 2>> $OUT/prof4096.log
+python tools/summarize_profile.py $OUT/prof3072 "sgemm_mfma_dma_kernel" > $OUT/prof3072_summary.json 2>> $OUT/prof3072.log
 python tools/summarize_profile.py $OUT/prof1024 "sgemm_mfma_dma_kernel" > $OUT/prof1024_summary.json 2>> $OUT/prof1024.log
 python tools/summarize_profile.py $OUT/prof2048 "sgemm_mfma_dma_kernel" > $OUT/prof2048_summary.json 2>> $OUT/prof2048.log
 cp $OUT/prof4096/trace/*kernel_stats.csv $OUT/prof4096_kernel_stats.csv 2>/dev/null

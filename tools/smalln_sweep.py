@@ -2,7 +2,11 @@
 """Small-N half of the reference sweep (N = 1024 .. 2048): the chain kernels (AUTO and its tiles),
 the opt-in split-K launches, the VALU rung's two tiles, and the two vendor libraries, interleaved in
 one process (cdna guide rule 24), median of ROUNDS rounds.  Writes a markdown table to stdout.
-usage: python tools/smalln_sweep.py [--sizes 1024,1152,...] [--rounds 5]"""
+Every timed burst (REPS launches) follows WARM_MS milliseconds of untimed launches of the SAME variant
+(default 30): the sustained rate, as the harness's WARMUP_MS measures it -- a variant inherits whatever
+clock state the previous variant left, and the tiles differ in how many launches they need to settle
+(profiles/r02_cold_start.txt: 18 .. 40).  --warm-ms 0 gives the old 5-launch warm-up.
+usage: python tools/smalln_sweep.py [--sizes 1024,1152,...] [--rounds 5] [--warm-ms 30]"""
 import argparse
 import os
 import statistics
@@ -16,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sizes", default="1024,1152,1280,1408,1536,1664,1792,1920,2048")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--warm-ms", type=float, default=30.0)
 ap.add_argument("--variants", default="auto,mfma_64x64_dma,mfma_128x64_dma,mfma_128x128_dma,mfma_64x64,mfma_128x64,mfma_tiles,"
                                        "mfma_splitk:0,auto:1,rocblas,hipblaslt,valu,valu_128x128,valu_64x64")
 args = ap.parse_args()
@@ -34,10 +39,23 @@ for _ in range(200):                      # clock ramp
 torch.cuda.synchronize()
 
 
-def timed(fn, reps):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+def warm(fn):
+    """args.warm_ms of untimed launches (at least 5)."""
+    import time
     for _ in range(5):
         fn()
+    if args.warm_ms > 0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < args.warm_ms:
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+
+
+def timed(fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    warm(fn)
     e0.record()
     for _ in range(reps):
         fn()
@@ -70,7 +88,8 @@ for n in sizes:
                     mm.set_kernel(base)
                 mm.set_streamk(0 if nosk else (2 if sk2 else 1))
                 mm.set_splitk(int(s) if s else 0)
-                ms = mm.time_sgemm(n, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, warmup=5,
+                warm(lambda: mm.matmul(a, b, out=c))
+                ms = mm.time_sgemm(n, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, warmup=2,
                                    reps=args.reps, stream=stream)
                 launch[v] = H.last_launch()
             res[v].append(2.0 * n ** 3 / (ms * 1e-3) / 1e12)
