@@ -119,6 +119,11 @@ struct mmh_context {
   long long spin_limit = 1ll << 26;
   int fault = 0;               // MMH_OPT_FAULT_INJECT
   int pin = 1;                 // persistent / sparse launches ask for 160 KiB / w of LDS so that exactly w workgroups fit a CU
+  int sk_order = 1;            // stream-K launches get the phase-ordered range / tile tables (sk_tables below)
+  // stream-K tables per launch shape (tiles, K-slices, grid): [order: grid ints][place: tiles ints]
+  struct SkTable { long tiles = 0; int nk = 0, grid = 0; DevBuf buf; unsigned long stamp = 0; };
+  std::vector<SkTable> sk_tables;
+  unsigned long sk_stamp = 0;
   // the hand-off workspaces above are per handle: a launch on another stream first waits for the
   // stream that used them last
   hipStream_t ws_stream = nullptr;
@@ -271,12 +276,81 @@ int prepare_flags(mmh_context *ctx, long tiles, hipStream_t s, int **flags) {
   return MMH_OK;
 }
 
+// The two tables of a stream-K launch (streamk_body's `order` and `place`), per shape, cached in the handle.
+// Range r of the G ranges covers units [U r / G, U (r + 1) / G) of the U = tiles x nk (tile slot, K-slice)
+// units; its PHASE is the length of its head (the slices of its last slot it computes first): its whole
+// tiles start that many slice-times into the launch.
+//   order[rho]: the range taken by the workgroup at chip position rho (XCD-contiguous) -- ranges sorted by
+//               phase, so that neighbours on the chip are a slice or two apart in K, not half a tile;
+//   place[j]  : the tile computed in slot j -- dealt out level by level (the o-th slot each range owns),
+//               within a level in phase order: what neighbouring workgroups compute at the same time are
+//               neighbouring tiles of the grouped raster.
+// Any pair of bijections is CORRECT (the chain only needs every workgroup to agree on them); these restore
+// the L2 reuse a plain launch has.  Built on the host at a shape's first eager launch (one synchronising
+// copy); a launch that is being captured before its shape was seen runs with the identity tables.
+int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place) {
+  *order = *place = nullptr;
+  // Worth it from ~1.8 tiles per workgroup (measured): phase order puts the two workgroups that share a
+  // tile on different XCDs, so the partial tile crosses the fabric instead of being an L2 hit -- with one
+  // tile per workgroup that hand-over is a tenth of the launch (N = 2176 on 128x64 tiles: 139.5 -> 125.0),
+  // with two or more the restored L2 reuse wins (N = 3584 on 64x64 tiles: 138.5 -> 146.0).
+  if (!ctx->sk_order || tiles > (1L << 20) || tiles * 10 < (long)grid * 18) return MMH_OK;
+  for (auto &t : ctx->sk_tables)
+    if (t.tiles == tiles && t.nk == nk && t.grid == grid) {
+      t.stamp = ++ctx->sk_stamp;
+      *order = static_cast<const int *>(t.buf.p);
+      *place = *order + grid;
+      return MMH_OK;
+    }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  if (cap != hipStreamCaptureStatusNone) return MMH_OK;
+  const long long U = (long long)tiles * nk;
+  auto S = [&](long long r) { return U * r / grid; };
+  std::vector<int> first(grid + 1), rank_of(grid), host((size_t)grid + (size_t)tiles);
+  std::vector<std::pair<int, int>> by_phase(grid);
+  for (int r = 0; r <= grid; ++r) first[r] = r == grid ? (int)tiles : (int)((S(r) + nk - 1) / nk);
+  for (int r = 0; r < grid; ++r) by_phase[r] = {(int)(S(r + 1) % nk), r};
+  std::sort(by_phase.begin(), by_phase.end());
+  int levels = 0;
+  for (int i = 0; i < grid; ++i) {
+    host[i] = by_phase[i].second;               // order[rho]
+    levels = std::max(levels, first[by_phase[i].second + 1] - first[by_phase[i].second]);
+  }
+  int next = 0;
+  for (int o = 0; o < levels; ++o)
+    for (int i = 0; i < grid; ++i) {
+      const int r = by_phase[i].second;
+      if (first[r + 1] - first[r] > o) host[(size_t)grid + first[r] + o] = next++;   // place[slot]
+    }
+  if (next != (int)tiles) return MMH_OK;         // (cannot happen; identity tables are always right)
+  // a new shape: evict the least recently used entry beyond eight
+  mmh_context::SkTable *slot = nullptr;
+  if (ctx->sk_tables.size() < 8) {
+    ctx->sk_tables.emplace_back();
+    slot = &ctx->sk_tables.back();
+  } else {
+    slot = &ctx->sk_tables[0];
+    for (auto &t : ctx->sk_tables)
+      if (t.stamp < slot->stamp) slot = &t;
+  }
+  HIP_TRY(hipStreamSynchronize(s));              // the evicted tables may still be read by a launch on s
+  if (ctx->ws_used && ctx->ws_stream != s) HIP_TRY(hipStreamSynchronize(ctx->ws_stream));
+  const int rc = slot->buf.reserve(host.size() * sizeof(int));
+  if (rc != MMH_OK) { slot->tiles = 0; return rc; }
+  HIP_TRY(hipMemcpy(slot->buf.p, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
+  slot->tiles = tiles; slot->nk = nk; slot->grid = grid; slot->stamp = ++ctx->sk_stamp;
+  *order = static_cast<const int *>(slot->buf.p);
+  *place = *order + grid;
+  return MMH_OK;
+}
+
 // Persistent chained stream-K launch (sgemm_mfma.hpp, K2p): what is common to every tile code.  `kern`
 // is the instantiation to launch (`occ_kern` the one whose residency bounds the grid).  Returns MMH_OK
 // if it launched, 1 if the shape does not qualify (caller then uses the plain one-tile-per-workgroup
 // launch).
 template <typename K>
-int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int threads, size_t lds, const char *what,
+int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB, int threads, size_t lds, const char *what,
                    int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int acc,
                    hipStream_t s) {
   const int nbm = (m + BM - 1) / BM, nbn = (n + BN - 1) / BN;
@@ -302,7 +376,10 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int thr
   // 128x128 tiles up a hand-over is small beside a tile's work and stream-K wins whenever the count is
   // ragged (N = 2816 / 3456 / 3968: 143 / 145 / 146.5 against 138 / 139 / 138 plain).
   // (Balance is a matter of CUs, not of workgroup slots: co-resident workgroups share their CU's matrix pipe.)
-  if (ctx->streamk != 2 && BM * BN < 128 * 128) {   // MMH_OPT_STREAMK = 2: whenever ragged (A/B switch)
+  // (The 128x64 tile counts as a big one once the launch is phase-ordered -- >= 1.8 tiles per workgroup,
+  // sk_tables_for -- N = 3968: 147.7 under stream-K, 141.9 plain.)
+  const bool ordered = ctx->sk_order && tiles * 10 >= (long)grid * 18;
+  if (ctx->streamk != 2 && BM * BN < 128 * 128 && !(ordered && BM * BN >= 128 * 64)) {   // MMH_OPT_STREAMK = 2: whenever ragged
     const long rounds = (tiles + cus - 1) / cus;
     if (tiles * 100 >= rounds * cus * 93) return 1;
   }
@@ -324,8 +401,10 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int thr
     const int ok = allow_big_lds(kern, lds_launch);
     if (ok != MMH_OK) return ok;
   }
+  const int *order = nullptr, *place = nullptr;
+  if ((rc = sk_tables_for(ctx, tiles, (k + KB - 1) / KB, grid, s, &order, &place)) != MMH_OK) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds_launch, s, m, n, k, A, lda, B, ldb, C, ldc, acc, nbm,
-                     nbn, flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault);
+                     nbn, flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault, order, place);
   HIP_TRY(hipGetLastError());
   {
     char buf[200];
@@ -351,7 +430,7 @@ int try_launch_streamk(mmh_context *ctx, int m, int n, int k, const float *A, in
   char what[160];
   snprintf(what, sizeof what, "sgemm_mfma_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d%s", BM, BN, 16 * WTM,
            16 * WTN, KB, fast ? "" : ", guarded");
-  return launch_streamk(ctx, fast ? kern_fast : kern_edge, kern_edge, BM, BN, threads, lds, what, m, n, k, A, lda, B, ldb,
+  return launch_streamk(ctx, fast ? kern_fast : kern_edge, kern_edge, BM, BN, KB, threads, lds, what, m, n, k, A, lda, B, ldb,
                         C, ldc, acc, s);
 }
 
@@ -366,7 +445,7 @@ int try_launch_streamk_dma(mmh_context *ctx, int m, int n, int k, const float *A
   char what[160];
   snprintf(what, sizeof what, "sgemm_dma_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by LDS-DMA", BM,
            BN, 16 * WTM, 16 * WTN, KB, NBUF);
-  return launch_streamk(ctx, kern, kern, BM, BN, T::THREADS, T::LDS_BYTES, what, m, n, k, A, lda, B, ldb, C, ldc, acc, s);
+  return launch_streamk(ctx, kern, kern, BM, BN, KB, T::THREADS, T::LDS_BYTES, what, m, n, k, A, lda, B, ldb, C, ldc, acc, s);
 }
 
 // Opt-in split-K launch (sgemm_mfma.hpp, K2s) of tile config <BM, BN, WTN> with S concurrent K parts.
@@ -543,6 +622,12 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       // At least one 256x256 tile per CU: the big tile (fewest staging ops per MFMA) -- unless its
       // edge tiles pad the shape noticeably more than 128x128 tiles would (an edge tile costs a whole
       // tile's time; ragged tile COUNTS are balanced by stream-K for either size).
+      // a ragged count of 256x256 tiles would run as stream-K with ~1.1-1.2 tiles per workgroup; the 128x64
+      // tile covers the same shape with >= 9 tiles per workgroup pair, phase-ordered (N = 4352 / 4608:
+      // 148.6 / 148.9 against 147.2 / 147.4)
+      if (tiles256 >= cus && tiles256 % cus != 0 && tiles128x64 * 10 >= 2 * cus * 18 && window_ok(128, 128, k, lda, ldb) &&
+          fast_shape(128, 64, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
+        return sgemm_on(ctx, MMH_KERNEL_MFMA_128X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
       if (tiles256 >= cus) {
         const double fill256 = (double)m * (double)n / ((double)tiles256 * 65536.0);
         const double fill128 = (double)m * (double)n / ((double)tiles128 * 16384.0);
@@ -569,6 +654,10 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       // (profiles/r02_ablation.md): 128x128 from 1.15 tiles per CU (N >= 2304), 128x64 from 1.25 of
       // those per CU (N >= 1664), 64x64 below -- each as a chained stream-K launch when worthwhile.
       if (window_ok(128, 128, k, lda, ldb)) {
+        // two co-resident 128x64 workgroups per CU beat one 128x128 workgroup by 1-1.5 % once the launch
+        // is a phase-ordered stream-K (>= 1.8 tiles per workgroup of a 2-per-CU grid: N >= 2816)
+        if (tiles128x64 * 10 >= 2 * cus * 18 && fast_shape(128, 64, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
+          return sgemm_on(ctx, MMH_KERNEL_MFMA_128X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
         if (tiles128 * 100 >= cus * 115 && fast_shape(128, 128, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
           return sgemm_on(ctx, MMH_KERNEL_MFMA_128X128_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
         if (tiles128x64 * 100 >= cus * 125 && fast_shape(128, 64, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
@@ -754,7 +843,8 @@ int create_context(mmh_context **out, int device) {
   ctx->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
-  if (const char *e = std::getenv("MMH_NO_PIN")) ctx->pin = (*e && *e != '0') ? 0 : 1;   // diagnostic A/B switch
+  if (const char *e = std::getenv("MMH_NO_PIN")) ctx->pin = (*e && *e != '0') ? 0 : 1;   // diagnostic A/B switches
+  if (const char *e = std::getenv("MMH_NO_SK_ORDER")) ctx->sk_order = (*e && *e != '0') ? 0 : 1;
   // the sticky error word: pinned, mapped host memory (the device adds to it with a system-scope atomic)
   void *host = nullptr, *dev = nullptr;
   if (hipHostMalloc(&host, 64, hipHostMallocMapped) == hipSuccess) {
@@ -785,6 +875,7 @@ void destroy_context(mmh_context *h) {
   h->qb.release();
   h->qc.release();
   h->qs.release();
+  for (auto &t : h->sk_tables) t.buf.release();
   if (h->pipeline_ready) {
     for (int i = 0; i < kMaxHostPanels; ++i) {
       if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]);
@@ -1037,6 +1128,9 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       h->fault = value ? 1 : 0;
       h->flags_dirty = true;
       return MMH_OK;
+    case MMH_OPT_STREAMK_ORDER:
+      h->sk_order = value ? 1 : 0;
+      return MMH_OK;
 #ifdef MMH_AB_BUILD
     case 100:   // A/B: pin the residency of persistent launches by their LDS request (default on)
       h->pin = value ? 1 : 0;
@@ -1056,6 +1150,7 @@ int mmh_get_option(mmh_handle_t h, int option, int *value) {
     case MMH_OPT_HOST_PANELS: *value = h->host_panels; return MMH_OK;
     case MMH_OPT_STREAMK_SPIN_LIMIT: *value = (int)(h->spin_limit >> 10); return MMH_OK;
     case MMH_OPT_FAULT_INJECT: *value = h->fault; return MMH_OK;
+    case MMH_OPT_STREAMK_ORDER: *value = h->sk_order; return MMH_OK;
     case MMH_OPT_STREAMK_TIMEOUTS: {
       // synchronises, then reads the sticky word: how many hand-off waits have timed out on this
       // handle since it was last cleared

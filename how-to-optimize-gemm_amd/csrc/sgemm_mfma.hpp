@@ -568,7 +568,8 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
                                              const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                              int accumulate, int nbm, int nbn, int *__restrict__ flags,
                                              int *__restrict__ err, float *__restrict__ parts, long long spin_limit,
-                                             int fault) {
+                                             int fault, const int *__restrict__ order = nullptr,
+                                             const int *__restrict__ place = nullptr) {
   // err: the handle's STICKY error word (host-mapped): a hand-off wait that runs into `spin_limit`
   // adds to it and the workgroup stops -- it never continues a chain from a slot that was not
   // published -- and every later mmh_* call on the handle fails until the word is cleared.
@@ -579,7 +580,14 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
   // XCD-contiguous ranges: workgroup p (on XCD p % 8) takes range index q
   const int xcd = blockIdx.x % NXCD, local = blockIdx.x / NXCD;
   const int gq = G / NXCD, gr = G % NXCD;
-  const int q = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + local;
+  // `order` / `place` (launch_streamk builds them per shape; NULL = identity): workgroups that are
+  // neighbours on the chip take ranges with neighbouring K PHASES (a range's whole tiles start after its
+  // head, whose length is the phase), and the tiles they work on at the same time are neighbours in the
+  // matrix -- so that, as on a plain launch, the tiles of a row / column walk K together and share their
+  // operand slices in L2.  Without them the phases of adjacent workgroups are unrelated and the L2 hit
+  // rate of a stream-K launch is 22-35 % instead of 80 % (profiles/r02_streamk_l2.md).
+  const int rho = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + local;
+  const int q = order ? order[rho] : rho;
   const long long total = (long long)T * nk;
   auto range_start = [&](int r) { return total * r / G; };
   const long long u0 = range_start(q), u1 = range_start(q + 1);
@@ -619,7 +627,7 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
       if (!bad && ke == nk) __hip_atomic_store(&flags[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     int tm, tn;
-    tile_of(t, tm, tn);
+    tile_of(place ? place[t] : t, tm, tn);
     __syncthreads();   // LDS is reused from segment to segment; orders the loads after the acquire
     if (kb > 0) {      // (uniform) tell every wave whether the wait succeeded
       if (threadIdx.x == 0) reinterpret_cast<volatile int *>(lds)[0] = bad;
@@ -662,10 +670,11 @@ __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)
 sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                           const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                           int accumulate, int nbm, int nbn, int *__restrict__ flags,
-                          int *__restrict__ err, float *__restrict__ parts, long long spin_limit, int fault) {
+                          int *__restrict__ err, float *__restrict__ parts, long long spin_limit, int fault,
+                          const int *__restrict__ order, const int *__restrict__ place) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   streamk_body<RegSeg<BM, BN, EDGE, WTN, WTM, KB>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn, flags, err,
-                                                   parts, spin_limit, fault);
+                                                   parts, spin_limit, fault, order, place);
 }
 
 template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
@@ -673,10 +682,11 @@ __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64)
 sgemm_dma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B,
                          int ldb, float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn,
                          int *__restrict__ flags, int *__restrict__ err, float *__restrict__ parts,
-                         long long spin_limit, int fault) {
+                         long long spin_limit, int fault, const int *__restrict__ order,
+                         const int *__restrict__ place) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   streamk_body<DmaSeg<BM, BN, KB, WTM, WTN, NBUF>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn, flags,
-                                                   err, parts, spin_limit, fault);
+                                                   err, parts, spin_limit, fault, order, place);
 }
 
 // ---------------------------------------------------------------------------

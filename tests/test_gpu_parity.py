@@ -214,13 +214,20 @@ def test_big_tile_full_matrix_vs_oracle(mm, oracle, shape, expect):
     import how_to_optimize_gemm_amd as H
     m, n, k = shape
     a, b = oracle.harness_inputs(m, n, k, seed=3 * m + 5 * n + 7 * k)
-    mm.set_kernel("auto")
+    mm.set_kernel("mfma_256x256")
     got = mm.matmul(dev(a), dev(b)).cpu().numpy()
     assert expect in H.last_launch(), H.last_launch()
     assert mm.streamk_timeouts() == 0
     assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
     d, _ = oracle.compare_matrices(got, oracle.ref_mmult(a, b, fma=False))
     assert d <= tol(k)
+    # whatever AUTO picks for the shape (4352^3: the 128x64 LDS-DMA tile as a phase-ordered stream-K
+    # launch; the ragged ones: the guarded 256x256 tile) -- the same bits
+    mm.set_kernel("auto")
+    assert np.array_equal(mm.matmul(dev(a), dev(b)).cpu().numpy(), got), H.last_launch()
+    assert mm.streamk_timeouts() == 0
+    if shape == (4352, 4352, 4352):
+        assert "sgemm_dma_streamk_kernel<128,64>" in H.last_launch(), H.last_launch()
 
 
 def test_sweep_sizes_integer_pattern_exact(mm, oracle):
@@ -263,6 +270,55 @@ def test_size_independent_properties_at_full_size(mm):
     # views with leading dimensions larger than the row length
     sub2 = mm.matmul(a[512:640, :], b[:, 128:384])        # ldb = 4096 > n = 256
     assert torch.equal(sub2, c[512:640, 128:384])
+
+
+@pytest.mark.parametrize("kernel,sk,shape", [
+    ("mfma_128x64_dma", 1, (2944, 2944, 2944)),     # 1058 tiles on 512 workgroups
+    ("mfma_128x64_dma", 1, (4352, 4352, 256)),      # 2312 tiles on 512
+    ("mfma_64x64_dma", 2, (2560, 2560, 512)),       # 1600 tiles on 768 (forced: the policy prefers the plain launch)
+    ("mfma_128x128_dma", 1, (2944, 3072, 384)),     # 552 tiles on 256
+    ("mfma", 1, (3968, 3968, 200)),                 # register-staged 128x128 tile (961 tiles on 512), ragged K
+    ("mfma", 1, (4097, 4095, 70)),                  # guarded: ragged edges and K
+    ("mfma_256x256", 1, (7000, 7000, 96)),          # 784 guarded 256x256 tiles on 256
+])
+def test_phase_ordered_stream_k_keeps_the_bits(mm, oracle, kernel, sk, shape):
+    """MMH_OPT_STREAMK_ORDER (default on): from 1.8 tiles per workgroup a stream-K launch takes its ranges
+    in K-phase order and its tiles in a matching placement (two per-shape tables) -- a different
+    assignment of the same (tile, K-range) parts to workgroups, so C is the same chain: bit-equal to the
+    launch with ranges in plain order, to one workgroup per tile, and to the oracle; overwrite and
+    accumulate; repeated launches (the cached tables) as well."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    m, n, k = shape
+    a, b = oracle.harness_inputs(m, n, k, seed=m + 3 * n + 11 * k)
+    da, db = dev(a), dev(b)
+    mm.set_kernel(kernel)
+    mm.set_streamk(sk)
+    try:
+        assert mm.get_option(H.OPT_STREAMK_ORDER) == 1
+        got = mm.matmul(da, db)
+        assert "streamk" in H.last_launch(), H.last_launch()
+        again = mm.matmul(da, db)                       # second launch: tables from the cache
+        mm.set_option(H.OPT_STREAMK_ORDER, 0)
+        plain_order = mm.matmul(da, db)
+        mm.set_option(H.OPT_STREAMK_ORDER, 1)
+        assert mm.streamk_timeouts() == 0
+        assert torch.equal(got, again) and torch.equal(got, plain_order)
+        mm.set_kernel("mfma_tiles")
+        assert torch.equal(got, mm.matmul(da, db))
+        if m * n * k <= 3000 * 3000 * 3000:
+            assert np.array_equal(got.cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
+        c0 = torch.rand((m, n), device="cuda")
+        want = c0.clone()
+        mm.matmul(da, db, out=want, accumulate=True)    # one workgroup per tile
+        mm.set_kernel(kernel)
+        out = c0.clone()
+        mm.matmul(da, db, out=out, accumulate=True)
+        assert "streamk" in H.last_launch()
+        assert torch.equal(out, want)
+    finally:
+        mm.set_option(H.OPT_STREAMK_ORDER, 1)
+        mm.set_streamk(True)
 
 
 @pytest.mark.parametrize("shape", [(2176, 2176, 2176), (3072, 3072, 1024), (2560, 3200, 512),
