@@ -287,7 +287,7 @@ int prepare_flags(mmh_context *ctx, long tiles, hipStream_t s, int **flags) {
 //               neighbouring tiles of the grouped raster.
 // Any pair of bijections is CORRECT (the chain only needs every workgroup to agree on them); these restore
 // the L2 reuse a plain launch has.  Built on the host at a shape's first eager launch (one synchronising
-// copy); a launch that is being captured before its shape was seen runs with the identity tables.
+// copy); a launch that is being captured into a hipGraph runs with the identity tables.
 int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place) {
   *order = *place = nullptr;
   // Worth it from ~1.8 tiles per workgroup (measured): phase order puts the two workgroups that share a
@@ -295,6 +295,11 @@ int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s,
   // tile per workgroup that hand-over is a tenth of the launch (N = 2176 on 128x64 tiles: 139.5 -> 125.0),
   // with two or more the restored L2 reuse wins (N = 3584 on 64x64 tiles: 138.5 -> 146.0).
   if (!ctx->sk_order || tiles > (1L << 20) || tiles * 10 < (long)grid * 18) return MMH_OK;
+  // a launch that is being captured must not point into this cache (an entry can be evicted and rewritten
+  // long before the graph is replayed): it is recorded with the identity tables
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  if (cap != hipStreamCaptureStatusNone) return MMH_OK;
   for (auto &t : ctx->sk_tables)
     if (t.tiles == tiles && t.nk == nk && t.grid == grid) {
       t.stamp = ++ctx->sk_stamp;
@@ -302,9 +307,6 @@ int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s,
       *place = *order + grid;
       return MMH_OK;
     }
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(s, &cap);
-  if (cap != hipStreamCaptureStatusNone) return MMH_OK;
   const long long U = (long long)tiles * nk;
   auto S = [&](long long r) { return U * r / grid; };
   std::vector<int> first(grid + 1), rank_of(grid), host((size_t)grid + (size_t)tiles);

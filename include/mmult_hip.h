@@ -125,9 +125,11 @@ int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
  * cublasSetStream); a stream-K / split-K launch on ANOTHER stream than the previous one first waits
  * for that stream (so the hand-off workspaces are never in use twice), which costs the overlap --
  * use one handle per stream that should run concurrently.  A launch captured into a hipGraph is
- * recorded without that wait (nothing may synchronise during capture): a graph that contains
- * stream-K launches owns the handle's workspaces while it runs, like any buffer it was captured with.  Every entry point runs on the handle's
- * device and restores the caller's current device before it returns. */
+ * recorded without that wait (nothing may synchronise during capture; a captured stream-K launch is
+ * recorded with plain-order ranges -- it must not point into the handle's per-shape table cache,
+ * MMH_OPT_STREAMK_ORDER): a graph that contains stream-K launches owns the handle's workspaces while it
+ * runs, like any buffer it was captured with.  Every entry point runs on the handle's device and restores
+ * the caller's current device before it returns. */
 int mmh_create(mmh_handle_t *handle, int device);
 int mmh_destroy(mmh_handle_t handle);
 int mmh_set_kernel(mmh_handle_t handle, int kernel);
@@ -169,7 +171,8 @@ const char *mmh_kernel_name(int kernel);
 #define MMH_OPT_FAULT_INJECT 7
 /* MMH_OPT_STREAMK_ORDER (default 1): stream-K launches with >= 1.8 tiles per workgroup take their ranges
  * in K-PHASE order and their tiles in a matching placement (two small per-shape tables, built on the host
- * at the shape's first eager launch -- one synchronising copy -- and cached in the handle), so that
+ * at the shape's first eager launch -- one synchronising copy -- and cached in the handle; launches captured
+ * into a hipGraph run with ranges in plain order), so that
  * workgroups that are neighbours on the chip walk K in step on neighbouring tiles and share operand slices
  * in L2 as a plain launch does (hit rate 22-35 % -> 75 %).  Same chain, same bits; 0 = ranges in plain
  * order (the A/B baseline; environment MMH_NO_SK_ORDER=1 does the same at mmh_create). */
