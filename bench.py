@@ -466,11 +466,12 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    # fd 1 stays parked on stderr until the process exits (RCCL prints its version banner as late as
+    # library teardown): the ONE line goes straight to the saved descriptor
     sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    os.close(saved_stdout)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(saved_stdout, (json.dumps(out) + "\n").encode())
+    os.close(saved_stdout)
 
 
 if __name__ == "__main__":

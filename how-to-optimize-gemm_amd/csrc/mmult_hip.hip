@@ -606,7 +606,7 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       // launch its workgroups run at different K phases and stop sharing operand slices in L2 (hit rate
       // 81 % -> 22 %, 2.4 GB of fabric traffic per launch, profiles/r02_ablation.md section 9).  So it is
       // chosen for whole-tile shapes with many tiles (>= 6 per CU) that fill their last round of CUs to
-      // >= 97.5 % (N = 2688, 3072, 3200 on the reference sweep; every large shape).
+      // >= 97.5 % (N = 2688, 3072, 3200 on the reference sweep; 5120, 6144, 8192).
       // One exception: whole rounds of 256x256 tiles in a SHORT launch (N = 4096: one tile per CU, 0.93 ms).
       // Sustained the two are level there (148.5-149.4 vs 148.7-150.5), but from an idle clock the big
       // tile is within 1 % of its rate after 18 launches and the small one after 40 -- and 20 launches
@@ -617,7 +617,11 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
         const long rounds64 = (tiles64 + cus - 1) / cus;
         const double est_ms = 2.0 * (double)m * (double)n * (double)k / 150e9;
         const bool whole_rounds_256 = tiles256 >= cus && tiles256 % cus == 0 && m % 256 == 0 && n % 256 == 0;
-        if (!(whole_rounds_256 && est_ms < 2.0) && tiles64 >= 6 * cus && tiles64 * 1000 >= rounds64 * cus * 975 &&
+        // ... and only up to N = 8192-sized problems: with K = 16384 and B beyond the Infinity Cache the
+        // small tile's two slices of look-ahead no longer cover its misses (2048 .. 16384 x 16384 x 16384:
+        // 147.8 .. 140.0 against 150.9-151.1 for the 256x256 tile, which those shapes keep)
+        if (!(whole_rounds_256 && est_ms < 2.0) && k <= 8192 && tiles64 <= 64 * cus && tiles64 >= 6 * cus &&
+            tiles64 * 1000 >= rounds64 * cus * 975 &&
             window_ok(64, 64, k, lda, ldb) && fast_shape(64, 64, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
           return sgemm_on(ctx, MMH_KERNEL_MFMA_64X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
       }
@@ -627,7 +631,8 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       // a ragged count of 256x256 tiles would run as stream-K with ~1.1-1.2 tiles per workgroup; the 128x64
       // tile covers the same shape with >= 9 tiles per workgroup pair, phase-ordered (N = 4352 / 4608:
       // 148.6 / 148.9 against 147.2 / 147.4)
-      if (tiles256 >= cus && tiles256 % cus != 0 && tiles128x64 * 10 >= 2 * cus * 18 && window_ok(128, 128, k, lda, ldb) &&
+      if (tiles256 >= cus && tiles256 % cus != 0 && k <= 8192 && tiles128x64 <= 32 * cus &&
+          tiles128x64 * 10 >= 2 * cus * 18 && window_ok(128, 128, k, lda, ldb) &&
           fast_shape(128, 64, 32, m, n, k, dA, lda, dB, ldb, dC, ldc))
         return sgemm_on(ctx, MMH_KERNEL_MFMA_128X64_DMA, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate, s);
       if (tiles256 >= cus) {
