@@ -42,3 +42,22 @@ def test_no_gpu_means_no_number():
     r = _run("--gpus", "1", "--steps", "2", "--warmup", "1")
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
     assert "value" not in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [(), ("--force-shard", "--n", "2048")])
+def test_exactly_one_json_line_on_stdout(extra):
+    """The contract: rank 0 prints ONE JSON line.  RCCL writes its version banner to the process's
+    stdout as late as library teardown; bench.py keeps fd 1 parked on stderr so that nothing but the
+    line arrives -- with the process group (and the RCCL communicator) of the sharded code path too."""
+    import json
+    r = _run("--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", *extra, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["warmup"] == 1 and d["steps"] == 2 and d["n_gpus"] == 1
+    assert d["roofline"]["bound"] == "mfma" and 0.2 < d["roofline"]["frac"] < 1.0
