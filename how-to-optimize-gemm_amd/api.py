@@ -47,7 +47,7 @@ EXPORTS = [
     "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm",
     "mmh_rccl_version",
     "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
-    "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy", "mmh_probe_hbm_read", "mmh_probe_lds_read",
+    "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy", "mmh_probe_hbm_read", "mmh_probe_lds_read", "mmh_streamk_plan",
 ]
 
 
@@ -72,6 +72,15 @@ def use_ab_library() -> str:
     _build.build_ab_library()
     _lib_path = AB_LIB_PATH
     return AB_LIB_PATH
+
+
+def streamk_plan(tiles: int, nk: int, grid: int):
+    """(order, place) of a phase-ordered stream-K launch as numpy int32 arrays (host arithmetic only)."""
+    order = np.zeros(grid, dtype=np.int32)
+    place = np.zeros(tiles, dtype=np.int32)
+    _check(lib().mmh_streamk_plan(tiles, nk, grid, order.ctypes.data_as(C.POINTER(C.c_int)),
+                                  place.ctypes.data_as(C.POINTER(C.c_int))), "mmh_streamk_plan")
+    return order, place
 
 
 def use_timeline_library() -> str:
@@ -158,6 +167,7 @@ def lib() -> C.CDLL:
     L.mmh_trace_sgemm.argtypes = gemm + [C.c_int, vp, fp]
     L.mmh_probe_hbm_read.argtypes = [vp, C.c_size_t, fp]
     L.mmh_probe_lds_read.argtypes = [vp, C.c_int, fp]
+    L.mmh_streamk_plan.argtypes = [C.c_long, C.c_int, C.c_int, ip, ip]
     L.mmh_probe_mfma_f32.argtypes = [vp, fp]
     L.mmh_probe_mfma_i8.argtypes = [vp, fp]
     L.mmh_probe_mfma_i8_sustained.argtypes = [vp, C.c_int, C.c_float, fp]
@@ -585,7 +595,7 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
 
 
 __all__ = ["MMult", "ShardedMMult", "MMultError", "lib", "use_ab_library", "device_count", "rccl_version", "shard_rows",
-           "kernel_name", "last_launch", "use_timeline_library", "sgemm_sharded", "KERNELS", "CHAIN_KERNELS", "AB_LIB_PATH",
+           "kernel_name", "last_launch", "use_timeline_library", "streamk_plan", "sgemm_sharded", "KERNELS", "CHAIN_KERNELS", "AB_LIB_PATH",
            "OPT_SPLITK", "OPT_HOST_PANELS", "OPT_STREAMK_SPIN_LIMIT", "OPT_FAULT_INJECT", "OPT_STREAMK_ORDER", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
            "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OPT_IGEMM_MODE", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

@@ -288,6 +288,30 @@ int prepare_flags(mmh_context *ctx, long tiles, hipStream_t s, int **flags) {
 // Any pair of bijections is CORRECT (the chain only needs every workgroup to agree on them); these restore
 // the L2 reuse a plain launch has.  Built on the host at a shape's first eager launch (one synchronising
 // copy); a launch that is being captured into a hipGraph runs with the identity tables.
+// (pure host arithmetic: mmh_streamk_plan exposes it to the CPU tests)
+bool build_sk_tables(long tiles, int nk, int grid, int *order, int *place) {
+  if (tiles <= 0 || nk <= 0 || grid <= 0 || tiles < grid) return false;
+  const long long U = (long long)tiles * nk;
+  auto S = [&](long long r) { return U * r / grid; };
+  std::vector<int> first(grid + 1);
+  std::vector<std::pair<int, int>> by_phase(grid);
+  for (int r = 0; r <= grid; ++r) first[r] = r == grid ? (int)tiles : (int)((S(r) + nk - 1) / nk);
+  for (int r = 0; r < grid; ++r) by_phase[r] = {(int)(S(r + 1) % nk), r};
+  std::sort(by_phase.begin(), by_phase.end());
+  int levels = 0;
+  for (int i = 0; i < grid; ++i) {
+    order[i] = by_phase[i].second;
+    levels = std::max(levels, first[by_phase[i].second + 1] - first[by_phase[i].second]);
+  }
+  int next = 0;
+  for (int o = 0; o < levels; ++o)
+    for (int i = 0; i < grid; ++i) {
+      const int r = by_phase[i].second;
+      if (first[r + 1] - first[r] > o) place[first[r] + o] = next++;
+    }
+  return next == (int)tiles;
+}
+
 int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place) {
   *order = *place = nullptr;
   // Worth it from ~1.8 tiles per workgroup (measured): phase order puts the two workgroups that share a
@@ -307,25 +331,8 @@ int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s,
       *place = *order + grid;
       return MMH_OK;
     }
-  const long long U = (long long)tiles * nk;
-  auto S = [&](long long r) { return U * r / grid; };
-  std::vector<int> first(grid + 1), rank_of(grid), host((size_t)grid + (size_t)tiles);
-  std::vector<std::pair<int, int>> by_phase(grid);
-  for (int r = 0; r <= grid; ++r) first[r] = r == grid ? (int)tiles : (int)((S(r) + nk - 1) / nk);
-  for (int r = 0; r < grid; ++r) by_phase[r] = {(int)(S(r + 1) % nk), r};
-  std::sort(by_phase.begin(), by_phase.end());
-  int levels = 0;
-  for (int i = 0; i < grid; ++i) {
-    host[i] = by_phase[i].second;               // order[rho]
-    levels = std::max(levels, first[by_phase[i].second + 1] - first[by_phase[i].second]);
-  }
-  int next = 0;
-  for (int o = 0; o < levels; ++o)
-    for (int i = 0; i < grid; ++i) {
-      const int r = by_phase[i].second;
-      if (first[r + 1] - first[r] > o) host[(size_t)grid + first[r] + o] = next++;   // place[slot]
-    }
-  if (next != (int)tiles) return MMH_OK;         // (cannot happen; identity tables are always right)
+  std::vector<int> host((size_t)grid + (size_t)tiles);
+  if (!build_sk_tables(tiles, nk, grid, host.data(), host.data() + grid)) return MMH_OK;   // identity is always right
   // a new shape: evict the least recently used entry beyond eight
   mmh_context::SkTable *slot = nullptr;
   if (ctx->sk_tables.size() < 8) {
@@ -1760,6 +1767,11 @@ int mmh_ab_set_stamps(mmh_handle_t h, void *stamps) {
   return MMH_OK;
 }
 #endif
+
+int mmh_streamk_plan(long tiles, int nk, int grid, int *order, int *place) {
+  if (!order || !place) return MMH_ERR_INVALID_ARG;
+  return build_sk_tables(tiles, nk, grid, order, place) ? MMH_OK : MMH_ERR_INVALID_ARG;
+}
 
 int mmh_probe_lds_read(mmh_handle_t h, int width, float *gbps) {
   if (!h || !gbps || (width != 16 && width != 8 && width != 4 && width != -8)) return MMH_ERR_INVALID_ARG;

@@ -178,6 +178,10 @@ const char *mmh_kernel_name(int kernel);
  * order (the A/B baseline; environment MMH_NO_SK_ORDER=1 does the same at mmh_create). */
 #define MMH_OPT_STREAMK_ORDER 8
 int mmh_set_option(mmh_handle_t handle, int option, int value);
+/* The two tables of a phase-ordered stream-K launch (MMH_OPT_STREAMK_ORDER) for `tiles` tile slots of `nk`
+ * K-slices on `grid` persistent workgroups, computed on the host (no device needed): order[grid] = the range
+ * each chip position takes, place[tiles] = the tile computed in each slot.  For tests and tools. */
+int mmh_streamk_plan(long tiles, int nk, int grid, int *order, int *place);
 int mmh_get_option(mmh_handle_t handle, int option, int *value);
 
 /* The hot path ------------------------------------------------------------ */
