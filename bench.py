@@ -22,6 +22,10 @@ too: cuda/test_MMult.cpp:85-98,121).
          (re-executes under torch.distributed.run on 127.0.0.1) and FAILS when
          fewer than N devices are visible -- it never falls back to fewer ranks.
 
+roofline.traffic is measured by the run itself (N=1, unless --no-extras / --no-live-traffic): two rocprofv3
+passes, FETCH_SIZE and WRITE_SIZE each in its own run, over a child process that launches the timed kernel
+on the same shape; the committed pass of profiles/pmc_traffic.json rides along as traffic_committed_pass.
+
 value = GFLOPS = 2*m*n*k*1e-9 / t  (cuda/test_MMult.cpp:116-118), whole job.
 Rank 0 prints ONE JSON line.
 
@@ -66,6 +70,8 @@ def parse_args():
     ap.add_argument("--n", type=int, default=0, help="override the square size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sweep / probes extras")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC pass instead of two rocprofv3 runs now")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the multi-GPU code path (process group, broadcast, all_reduce) even with one rank")
     ap.add_argument("--ramp-csv", default="", help="write the per-launch clock-ramp trace to this CSV")
@@ -147,6 +153,49 @@ def pmc_traffic(n: int):
         return d.get(str(n), {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def live_traffic(n: int, kernel: str):
+    """HBM-side bytes per launch measured NOW: two rocprofv3 passes (FETCH_SIZE and WRITE_SIZE each in
+    its own run, kernel trace only beside them -- MI355X_MICROARCH.md, HBM) over a child process that
+    launches the same kernel on the same shape eight times.  Returns (bytes, description) or
+    (None, why not); never raises."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    child = (f"import sys; sys.path.insert(0, {REPO!r}); import torch, how_to_optimize_gemm_amd as H; "
+             f"mm = H.MMult(0, {kernel!r}); a = torch.rand(({n}, {n}), device='cuda') * 2 - 1; "
+             f"b = torch.rand(({n}, {n}), device='cuda') * 2 - 1; c = torch.empty(({n}, {n}), device='cuda'); "
+             f"[mm.matmul(a, b, out=c) for _ in range(8)]; torch.cuda.synchronize()")
+    kib = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="mmh_pmc_", dir="/tmp")
+            try:
+                subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                                sys.executable, "-c", child], cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
+                               capture_output=True, text=True, timeout=240)
+                per_dispatch = {}
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if "sgemm_" in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
+                            per_dispatch[r["Dispatch_Id"]] = per_dispatch.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+                vals = [v for _, v in sorted(per_dispatch.items(), key=lambda kv: int(kv[0]))][2:]   # skip the cold ones
+                if not vals:
+                    return None, f"no {ctr} rows for the kernel in rocprofv3's output"
+                kib[ctr] = sum(vals) / len(vals)
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+    except Exception as e:   # a profiler that is missing, refused or slow must not cost the run its line
+        return None, f"{type(e).__name__}: {e}"[:200]
+    total = int(round(kib["FETCH_SIZE"] * 1024 * 2 + kib["WRITE_SIZE"] * 1024))
+    return total, (f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes run by this invocation (each its own run, "
+                   f"mean of 6 launches of the timed kernel): FETCH_SIZE {kib['FETCH_SIZE']:.0f} KiB x 2 (gfx950, 16 B/lane "
+                   f"reads) + WRITE_SIZE {kib['WRITE_SIZE']:.0f} KiB")
 
 
 def main():
@@ -456,6 +505,14 @@ def main():
             except Exception as e:   # extras are optional: never let them cost the run its JSON line
                 extras["error"] = f"{type(e).__name__}: {e}"[:300]
             out["extras"] = extras
+        if not sharded and not args.no_live_traffic and not args.no_extras and "ROCPROFILER_" not in " ".join(os.environ):
+            # (not under a profiler already: gpu_profile.sh runs this script under rocprofv3)
+            live, how = live_traffic(n, args.kernel)
+            if live is not None:
+                out["roofline"]["traffic_committed_pass"] = out["roofline"]["traffic"]
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = live, how
+            else:
+                out["roofline"]["traffic_live_failed"] = how
         if not sharded and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n)
