@@ -176,9 +176,17 @@ def live_traffic(n: int, kernel: str):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="mmh_pmc_", dir="/tmp")
             try:
-                subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-                                sys.executable, "-c", child], cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
-                               capture_output=True, text=True, timeout=240)
+                # its own process group, so that a profiler that stops responding is killed WITH the child it started
+                p = subprocess.Popen([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc",
+                                      "--", sys.executable, "-c", child], cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
+                                     stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    p.wait(timeout=90)
+                except subprocess.TimeoutExpired:
+                    import signal
+                    os.killpg(p.pid, signal.SIGKILL)
+                    p.wait()
+                    return None, f"rocprofv3 --pmc {ctr} did not finish within 90 s"
                 per_dispatch = {}
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     for r in csv.DictReader(open(f)):
