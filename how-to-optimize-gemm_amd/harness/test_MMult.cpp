@@ -47,6 +47,10 @@
 //                              sweeps under profiles/ use 3, so that one transient (another process's
 //                              burst, a clock dip) does not own a point
 //   EXTENDED=1                 extra columns: pct_of_fp32_mfma_peak ref_gflops ref_cores
+//   JSON=<path>                besides the reference-format rows on stdout, one JSON object per size in
+//                              <path> (a JSON array): p, m, n, k, gflops, diff, pct_of_fp32_mfma_peak,
+//                              seconds, flavour, kernel and what the library actually launched
+//                              (mmh_last_launch) -- the machine-readable side of the result file
 //   PROBES=1                   before the sweep, measure the denominators on this device and print them on
 //                              STDERR (stdout keeps the reference's format): MFMA-only fp32 TFLOP/s, HBM
 //                              copy / read GB/s, LDS fragment-read GB/s -- the idea of
@@ -74,6 +78,7 @@ struct Options {
   int nrepeats = sweep_defaults::kRepeats;
   int lda = sweep_defaults::kLda, ldb = sweep_defaults::kLdb, ldc = sweep_defaults::kLdc;
   int warmup = 0, warmup_ms = 0, extended = 0, ngpus = 1, splitk = 0, trials = 1, probes = 0;
+  std::string json;
   std::string kernel = "auto", flavour = "device", input = "drand48", ref = "threads";
 };
 
@@ -134,6 +139,7 @@ int main(int argc, char **argv) {
   opt_int(argc, argv, "WARMUP_MS", o.warmup_ms);
   opt_int(argc, argv, "TRIALS", o.trials);
   opt_int(argc, argv, "PROBES", o.probes);
+  opt_str(argc, argv, "JSON", o.json);
   if (o.trials < 1) o.trials = 1;
   opt_int(argc, argv, "NGPUS", o.ngpus);
   opt_int(argc, argv, "SPLITK", o.splitk);
@@ -180,6 +186,16 @@ int main(int argc, char **argv) {
   }
   std::printf("MY_MMult = [\n");
 
+  std::FILE *json_out = nullptr;
+  int json_rows = 0;
+  if (!o.json.empty()) {
+    json_out = std::fopen(o.json.c_str(), "w");
+    if (!json_out) {
+      std::fprintf(stderr, "JSON=%s: cannot open for writing\n", o.json.c_str());
+      return EXIT_FAILURE;
+    }
+    std::fprintf(json_out, "[");
+  }
   for (int p = o.pfirst; p <= o.plast; p += o.pinc) {
     const int m = o.m == -1 ? p : o.m, n = o.n == -1 ? p : o.n, k = o.k == -1 ? p : o.k;
     const int lda = o.lda == -1 ? k : o.lda, ldb = o.ldb == -1 ? n : o.ldb,
@@ -309,6 +325,22 @@ int main(int argc, char **argv) {
     else
       std::printf("%d %.2f %le \n", p, gflops, diff);
     std::fflush(stdout);
+    if (json_out) {
+      std::string launched = cpu_only ? "serial triple loop (no GPU)" : mmh_last_launch();
+      for (auto &ch : launched)
+        if (ch == '"' || ch == '\\') ch = '\'';
+      std::fprintf(json_out,
+                   "%s\n {\"p\": %d, \"m\": %d, \"n\": %d, \"k\": %d, \"gflops\": %.2f, \"diff\": %.6e, "
+                   "\"pct_of_fp32_mfma_peak\": %.2f, \"seconds\": %.6e, \"flavour\": \"%s\", \"kernel\": \"%s\", "
+                   "\"launched\": \"%s\"}",
+                   json_rows++ ? "," : "", p, m, n, k, gflops, diff, 100.0 * gflops / (kPeakTflops * 1e3), seconds,
+                   o.flavour.c_str(), o.kernel.c_str(), launched.c_str());
+      std::fflush(json_out);
+    }
+  }
+  if (json_out) {
+    std::fprintf(json_out, "\n]\n");
+    std::fclose(json_out);
   }
 
   if (shard) MMH_CHECK(mmh_shard_destroy(shard));

@@ -63,6 +63,22 @@ def test_cpu_plumbing_config1():
     assert [r[0] for r in rows] == [256] and rows[0][2] == 0.0 and rows[0][1] > 0.05
 
 
+def test_json_sidecar_beside_the_reference_format(tmp_path):
+    """JSON=<path>: stdout keeps the reference's format; the same rows land in a JSON array with the
+    shape, the rate as % of the fp32 MFMA peak and what was launched."""
+    import json
+    build()
+    path = tmp_path / "sweep.json"
+    rc, out, err = run({"FLAVOUR": "cpu", "PFIRST": 64, "PLAST": 192, "PINC": 64, "NREPEATS": 1, "JSON": str(path)})
+    assert rc == 0, err
+    rows = parse(out)
+    side = json.load(open(path))
+    assert [r["p"] for r in side] == [r[0] for r in rows] == [64, 128, 192]
+    for r, s_ in zip(rows, side):
+        assert abs(s_["gflops"] - r[1]) < 0.011 and s_["diff"] == r[2] == 0.0
+        assert s_["m"] == s_["n"] == s_["k"] == s_["p"] and s_["flavour"] == "cpu" and "serial" in s_["launched"]
+
+
 def test_cpu_sweep_format_and_threaded_ref_identical():
     build()
     rc, out, _ = run({"FLAVOUR": "cpu", "PFIRST": 40, "PLAST": 200, "PINC": 40, "NREPEATS": 1,
