@@ -27,7 +27,7 @@ AB_LIB_PATH = os.path.join(PKG_DIR, "libmmult_hip_ab.so")   # tools-only build (
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_ALLOC, ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_256, KERNEL_NAIVE, KERNEL_MFMA_SIMPLE, KERNEL_MFMA_PIPE = 0, 1, 2, 3, 4, 5, 6
 OPT_STREAMK, OPT_STREAMK_TIMEOUTS, OPT_IGEMM_MODE = 1, 2, 3
-OPT_SPLITK, OPT_HOST_PANELS, OPT_STREAMK_SPIN_LIMIT, OPT_FAULT_INJECT, OPT_STREAMK_ORDER = 4, 5, 6, 7, 8
+OPT_SPLITK, OPT_HOST_PANELS, OPT_STREAMK_SPIN_LIMIT, OPT_FAULT_INJECT, OPT_STREAMK_ORDER, OPT_DMA_EDGE = 4, 5, 6, 7, 8, 9
 KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
            "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11, "mfma_256x256": 12,
@@ -40,10 +40,10 @@ CHAIN_KERNELS = [k for k in KERNELS if "splitk" not in k]
 EXPORTS = [
     "mmh_strerror", "mmh_last_error", "mmh_last_launch", "mmh_version", "mmh_is_ab_build", "mmh_device_count",
     "mmh_device_info",
-    "mmh_create", "mmh_destroy", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name",
+    "mmh_create", "mmh_destroy", "mmh_warm", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name", "mmh_kernel_id",
     "mmh_set_option", "mmh_get_option",
     "mmh_sgemm", "mmh_sgemm_host", "mmh_sgemm_host_timed", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
-    "mmh_sgemm_rocblas", "mmh_shard_rows",
+    "mmh_sgemm_rocblas", "mmh_sgemm_hipblaslt", "mmh_shard_rows",
     "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm",
     "mmh_rccl_version",
     "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
@@ -140,6 +140,8 @@ def lib() -> C.CDLL:
     L.mmh_device_info.argtypes = [C.c_int, C.c_char_p, ip, ip]
     L.mmh_create.argtypes = [C.POINTER(vp), C.c_int]
     L.mmh_destroy.argtypes = [vp]
+    L.mmh_warm.argtypes = [vp]
+    L.mmh_kernel_id.argtypes = [C.c_char_p]
     L.mmh_set_kernel.argtypes = [vp, C.c_int]
     L.mmh_get_kernel.argtypes = [vp, ip]
     L.mmh_set_option.argtypes = [vp, C.c_int, C.c_int]
@@ -152,6 +154,7 @@ def lib() -> C.CDLL:
     L.mmh_sgemm_host_timed.argtypes = gemm + [C.c_int, C.POINTER(C.c_float)]
     L.mmh_igemm_s8.argtypes = gemm + [C.c_int, vp]
     L.mmh_sgemm_rocblas.argtypes = gemm + [vp]
+    L.mmh_sgemm_hipblaslt.argtypes = gemm + [vp]
     L.mmh_qgemm_f32.argtypes = gemm + [vp]
     L.mmh_quantize_sym_s8.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp]
     L.mmh_shard_rows.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
@@ -217,7 +220,12 @@ def kernel_name(kernel: int) -> Optional[str]:
 
 def _kernel_id(kernel) -> int:
     if isinstance(kernel, str):
-        return KERNELS[kernel]
+        if kernel in KERNELS:
+            return KERNELS[kernel]
+        kid = lib().mmh_kernel_id(kernel.encode())      # the library's own table (A/B ids of the tools build too)
+        if kid < 0:
+            raise KeyError(kernel)
+        return kid
     return int(kernel)
 
 
@@ -251,6 +259,11 @@ class MMult:
 
     def __exit__(self, *exc):
         self.close()
+
+    def warm(self) -> None:
+        """Everything a first launch would pay for (code objects, LDS opt-ins, residency queries, stream-K
+        workspaces) -- mmh_create does it already unless MMH_LAZY=1; idempotent."""
+        _check(lib().mmh_warm(self._h), "mmh_warm")
 
     # -- configuration ------------------------------------------------------
     def set_kernel(self, kernel) -> None:
@@ -472,6 +485,23 @@ class MMult:
                "mmh_sgemm_rocblas")
         return out
 
+    def matmul_hipblaslt(self, a, b, out=None):
+        """The second vendor comparator (cuda/MMult_cuBLAS_2.cpp:11-26): hipBLASLt, fp32 compute."""
+        import torch
+        m, k = a.shape
+        k2, n = b.shape
+        if k != k2:
+            raise MMultError(ERR_INVALID_ARG, "matmul_hipblaslt", "inner dimensions differ")
+        if out is None:
+            out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        pa, lda = self._tensor_args(a, m, k, "hipblaslt(A)", torch.float32)
+        pb, ldb = self._tensor_args(b, k, n, "hipblaslt(B)", torch.float32)
+        pc, ldc = self._tensor_args(out, m, n, "hipblaslt(C)", torch.float32)
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        _check(lib().mmh_sgemm_hipblaslt(self._h, m, n, k, pa, lda, pb, ldb, pc, ldc, stream),
+               "mmh_sgemm_hipblaslt")
+        return out
+
     # -- measurement -------------------------------------------------------------
     def time_sgemm(self, m, n, k, dA, lda, dB, ldb, dC, ldc, warmup=1, reps=20, stream: int = 0) -> float:
         """Mean ms per call: one hipEvent pair around `reps` back-to-back launches on
@@ -596,6 +626,6 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
 
 __all__ = ["MMult", "ShardedMMult", "MMultError", "lib", "use_ab_library", "device_count", "rccl_version", "shard_rows",
            "kernel_name", "last_launch", "use_timeline_library", "streamk_plan", "sgemm_sharded", "KERNELS", "CHAIN_KERNELS", "AB_LIB_PATH",
-           "OPT_SPLITK", "OPT_HOST_PANELS", "OPT_STREAMK_SPIN_LIMIT", "OPT_FAULT_INJECT", "OPT_STREAMK_ORDER", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
+           "OPT_SPLITK", "OPT_HOST_PANELS", "OPT_STREAMK_SPIN_LIMIT", "OPT_FAULT_INJECT", "OPT_STREAMK_ORDER", "OPT_DMA_EDGE", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
            "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OPT_IGEMM_MODE", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

@@ -36,33 +36,54 @@ def _stale(target: str, srcs: list[str]) -> bool:
 def library_sources() -> list[str]:
     out = [os.path.join(REPO, "include", "mmult_hip.h")]
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".hpp")):
+        if f.endswith((".hip", ".hpp", ".map")):
             out.append(os.path.join(CSRC, f))
     return out
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> how-to-optimize-gemm_amd/libmmult_hip.so"""
-    srcs = library_sources()
-    if force or _stale(LIB, srcs):
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-Wno-unused-result", os.path.join(CSRC, "mmult_hip.hip"), "-o", LIB, "-ldl"]
+def translation_units() -> list[str]:
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _build_shared(target: str, defines: list[str], objdir: str, force: bool, verbose: bool) -> str:
+    """hipcc -c every translation unit of csrc/ (in parallel: the kernel-heavy ones take a minute each),
+    then link them into `target`.  Objects live under build/<objdir>/ (git-ignored) and are reused while
+    neither their .hip nor any header has changed."""
+    from concurrent.futures import ThreadPoolExecutor
+    headers = [s for s in library_sources() if s.endswith((".hpp", ".h"))]
+    odir = os.path.join(PKG_DIR, "build", objdir)
+    os.makedirs(odir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + defines
+    jobs = []
+    for tu in translation_units():
+        obj = os.path.join(odir, os.path.basename(tu)[:-4] + ".o")
+        if force or _stale(obj, [tu] + headers):
+            jobs.append([hipcc()] + flags + ["-c", tu, "-o", obj])
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+            list(pool.map(run, jobs))
+    objs = [os.path.join(odir, os.path.basename(tu)[:-4] + ".o") for tu in translation_units()]
+    if force or jobs or _stale(target, objs + [os.path.join(CSRC, "exports.map")]):
+        run([hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs +
+            ["-o", target, "-ldl", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")])
+    return target
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> how-to-optimize-gemm_amd/libmmult_hip.so"""
+    return _build_shared(LIB, [], "product", force, verbose)
 
 
 def build_timeline_library(force: bool = False) -> str:
     """-DMMH_AB_BUILD -DMMH_DMA_TIMELINE -> libmmult_hip_tl.so: the A/B library whose plain LDS-DMA kernels
     also write per-workgroup wall-clock stamps (tools/dma_timeline.py only; the stamps perturb the
     schedule of the big tiles, so no other tool measures with this build)."""
-    target = os.path.join(PKG_DIR, "libmmult_hip_tl.so")
-    if force or _stale(target, library_sources()):
-        subprocess.check_call([hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMMH_AB_BUILD",
-                               "-DMMH_DMA_TIMELINE", "-Wno-unused-result", os.path.join(CSRC, "mmult_hip.hip"), "-o",
-                               target, "-ldl"])
-    return target
+    return _build_shared(os.path.join(PKG_DIR, "libmmult_hip_tl.so"), ["-DMMH_AB_BUILD", "-DMMH_DMA_TIMELINE"], "timeline",
+                         force, False)
 
 
 def build_ab_library(force: bool = False, verbose: bool = False) -> str:
@@ -70,14 +91,7 @@ def build_ab_library(force: bool = False, verbose: bool = False) -> str:
     scheduling A/B variants and the timing-only ablation builds (wrong results).  Loaded by
     tools/ab_bench.py and tools/misc_bench.py only; never by the package, the harness or the tests
     of the product path."""
-    srcs = library_sources()
-    if force or _stale(AB_LIB, srcs):
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMMH_AB_BUILD",
-               "-Wno-unused-result", os.path.join(CSRC, "mmult_hip.hip"), "-o", AB_LIB, "-ldl"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-    return AB_LIB
+    return _build_shared(AB_LIB, ["-DMMH_AB_BUILD"], "ab", force, verbose)
 
 
 def build_harness(force: bool = False) -> str:

@@ -1,0 +1,297 @@
+// abi.hip -- the extern "C" entry points of include/mmult_hip.h that are not tied to one kernel family: library
+// and handle queries, options, the device-pointer MY_MMult (mmh_sgemm), the measurement helpers.
+// Part of libmmult_hip.so (see internal.hpp).
+#include <algorithm>
+
+#include "internal.hpp"
+
+using namespace mmh;
+
+extern "C" {
+
+const char *mmh_strerror(int status) {
+  switch (status) {
+    case MMH_OK: return "success";
+    case MMH_ERR_INVALID_ARG: return "invalid argument";
+    case MMH_ERR_HIP: return "HIP runtime error";
+    case MMH_ERR_NO_DEVICE: return "no gfx950 device";
+    case MMH_ERR_UNSUPPORTED: return "unsupported in this build";
+    case MMH_ERR_ALLOC: return "allocation failed";
+    case MMH_ERR_COMM: return "RCCL error";
+    default: return "unknown status";
+  }
+}
+
+const char *mmh_last_error(void) { return last_error_ref().c_str(); }
+
+const char *mmh_last_launch(void) { return last_launch_ref().c_str(); }
+
+int mmh_version(void) { return 300; }
+
+int mmh_is_ab_build(void) {
+#ifdef MMH_AB_BUILD
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+int mmh_device_count(int *count) {
+  if (!count) return MMH_ERR_INVALID_ARG;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    (void)hipGetLastError();
+    return MMH_OK;  // "no devices" is an answer, not a failure
+  }
+  *count = c;
+  return MMH_OK;
+}
+
+int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (name) snprintf(name, 256, "%s (%s)", prop.name, prop.gcnArchName);
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+  return MMH_OK;
+}
+
+int mmh_create(mmh_handle_t *handle, int device) {
+  if (!handle) return MMH_ERR_INVALID_ARG;
+  return create_context(handle, device);
+}
+
+int mmh_destroy(mmh_handle_t h) {
+  destroy_context(h);
+  return MMH_OK;
+}
+
+int mmh_set_kernel(mmh_handle_t h, int kernel) {
+  if (!h || !known_kernel(kernel)) return MMH_ERR_INVALID_ARG;
+  h->kernel = kernel;
+  return MMH_OK;
+}
+
+int mmh_set_option(mmh_handle_t h, int option, int value) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  switch (option) {
+    case MMH_OPT_STREAMK:
+      if (value < 0 || value > 2) return MMH_ERR_INVALID_ARG;
+      h->streamk = value;
+      return MMH_OK;
+    case MMH_OPT_STREAMK_TIMEOUTS:   // writing 0 clears the sticky error
+      if (value != 0) return MMH_ERR_INVALID_ARG;
+      {
+        DeviceGuard guard;
+        HIP_TRY(guard.enter(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+      }
+      if (h->sticky) *reinterpret_cast<volatile int *>(h->sticky) = 0;
+      h->flags_dirty = true;   // a launch that timed out may have left hand-off counters behind
+      return MMH_OK;
+    case MMH_OPT_IGEMM_MODE:
+      if ((value >= 0 && value <= 6)
+#ifdef MMH_AB_BUILD
+          || (value >= 10 && value <= 13)
+#endif
+      ) {
+        h->igemm_mode = value;
+        return MMH_OK;
+      }
+      return MMH_ERR_INVALID_ARG;
+    case MMH_OPT_SPLITK:
+      if (value < 0 || value > 16) return MMH_ERR_INVALID_ARG;
+      h->splitk = value;
+      return MMH_OK;
+    case MMH_OPT_HOST_PANELS:
+      if (value < -1 || value > kMaxHostPanels) return MMH_ERR_INVALID_ARG;
+      h->host_panels = value;
+      return MMH_OK;
+    case MMH_OPT_STREAMK_SPIN_LIMIT:   // in units of 1024 polls
+      if (value < 1) return MMH_ERR_INVALID_ARG;
+      h->spin_limit = (long long)value << 10;
+      return MMH_OK;
+    case MMH_OPT_FAULT_INJECT:
+      h->fault = value ? 1 : 0;
+      h->flags_dirty = true;
+      return MMH_OK;
+    case MMH_OPT_STREAMK_ORDER:
+      h->sk_order = value ? 1 : 0;
+      return MMH_OK;
+    case MMH_OPT_DMA_EDGE:   // 0: ragged / unaligned shapes on the register-staged tiles only; 1: guarded LDS-DMA tiles
+      h->dma_edge = value ? 1 : 0;     //    for rows that are 16-byte aligned; 2 (default): for any 4-byte aligned rows
+      h->dma_dword_rows = value >= 2 ? 1 : 0;
+      return MMH_OK;
+#ifdef MMH_AB_BUILD
+    case 100:   // A/B: pin the residency of persistent launches by their LDS request (default on)
+      h->pin = value ? 1 : 0;
+      return MMH_OK;
+#endif
+    default:
+      return MMH_ERR_INVALID_ARG;
+  }
+}
+
+int mmh_get_option(mmh_handle_t h, int option, int *value) {
+  if (!h || !value) return MMH_ERR_INVALID_ARG;
+  switch (option) {
+    case MMH_OPT_STREAMK: *value = h->streamk; return MMH_OK;
+    case MMH_OPT_IGEMM_MODE: *value = h->igemm_mode; return MMH_OK;
+    case MMH_OPT_SPLITK: *value = h->splitk; return MMH_OK;
+    case MMH_OPT_HOST_PANELS: *value = h->host_panels; return MMH_OK;
+    case MMH_OPT_STREAMK_SPIN_LIMIT: *value = (int)(h->spin_limit >> 10); return MMH_OK;
+    case MMH_OPT_FAULT_INJECT: *value = h->fault; return MMH_OK;
+    case MMH_OPT_STREAMK_ORDER: *value = h->sk_order; return MMH_OK;
+    case MMH_OPT_DMA_EDGE: *value = h->dma_edge ? (h->dma_dword_rows ? 2 : 1) : 0; return MMH_OK;
+    case MMH_OPT_STREAMK_TIMEOUTS: {
+      // synchronises, then reads the sticky word: how many hand-off waits have timed out on this
+      // handle since it was last cleared
+      *value = 0;
+      DeviceGuard guard;
+      HIP_TRY(guard.enter(h->device));
+      HIP_TRY(hipDeviceSynchronize());
+      if (h->sticky) *value = *reinterpret_cast<volatile int *>(h->sticky);
+      return MMH_OK;
+    }
+    default:
+      return MMH_ERR_INVALID_ARG;
+  }
+}
+
+int mmh_get_kernel(mmh_handle_t h, int *kernel) {
+  if (!h || !kernel) return MMH_ERR_INVALID_ARG;
+  *kernel = h->kernel;
+  return MMH_OK;
+}
+
+const char *mmh_kernel_name(int kernel) {
+  switch (kernel) {
+    case MMH_KERNEL_AUTO: return "MMult_hip_auto";
+    case MMH_KERNEL_VALU: return "MMult_hip_valu";
+    case MMH_KERNEL_VALU_128X128: return "MMult_hip_valu_128x128";
+    case MMH_KERNEL_VALU_64X64: return "MMult_hip_valu_64x64";
+    case MMH_KERNEL_MFMA: return "MMult_hip_mfma";
+    case MMH_KERNEL_MFMA_256: return "MMult_hip_mfma256";
+    case MMH_KERNEL_NAIVE: return "MMult_hip_naive";
+    case MMH_KERNEL_MFMA_SIMPLE: return "MMult_hip_mfma_simple";
+    case MMH_KERNEL_MFMA_PIPE: return "MMult_hip_mfma_pipe";
+    case MMH_KERNEL_MFMA_TILES: return "MMult_hip_mfma_tiles";
+    case MMH_KERNEL_MFMA_128X64: return "MMult_hip_mfma_128x64";
+    case MMH_KERNEL_MFMA_64X64: return "MMult_hip_mfma_64x64";
+    case MMH_KERNEL_MFMA_256X256: return "MMult_hip_mfma_256x256";
+    case MMH_KERNEL_MFMA_64X64_DMA: return "MMult_hip_mfma_64x64_dma";
+    case MMH_KERNEL_MFMA_128X64_DMA: return "MMult_hip_mfma_128x64_dma";
+    case MMH_KERNEL_MFMA_128X128_DMA: return "MMult_hip_mfma_128x128_dma";
+    case MMH_KERNEL_MFMA_SPLITK: return "MMult_hip_mfma_splitk";
+    case MMH_KERNEL_MFMA_SPLITK_128X64: return "MMult_hip_mfma_splitk_128x64";
+#ifdef MMH_AB_BUILD
+    case 19: return "exp_dma_b";
+    case 16: return "cadence_3";
+    case 17: return "cadence_4";
+    case 18: return "cadence_1";
+    case 32: return "ablate_no_gload";
+    case 33: return "ablate_no_gload_no_ldswrite";
+    case 34: return "ablate_no_gload_no_ldswrite_no_barrier";
+    case 35: return "ablate_mfma_only";
+    case 21: return "ablate256_no_gload";
+    case 22: return "ablate256_no_gload_no_ldswrite";
+    case 23: return "ablate256_no_gload_no_ldswrite_no_barrier";
+    case 24: return "ablate256_mfma_only";
+    case 36: return "ablate128x64_hot_loads";
+    case 37: return "ablate128x64_no_gload";
+    case 38: return "ablate128x64_no_gload_no_ldswrite";
+    case 39: return "ablate128x64_no_gload_no_ldswrite_no_barrier";
+    case 40: return "ablate128x64_mfma_only";
+    case 41: return "ablate64x64_no_gload";
+    case 42: return "ablate64x64_no_gload_no_ldswrite";
+    case 43: return "ablate64x64_no_gload_no_ldswrite_no_barrier";
+    case 44: return "ablate64x64_mfma_only";
+    case 45: return "exp_dma_64x64_8waves";
+    case 46: return "exp_dma_128x64_8waves";
+    case 47: return "exp_dma_128x128_8waves";
+#endif
+    default: return nullptr;
+  }
+}
+
+// the inverse of mmh_kernel_name, on the short names the harness, MMULT_KERNEL and the Python API use
+int mmh_kernel_id(const char *name) {
+  if (!name) return -1;
+  const std::string want = std::string("MMult_hip_") + name;
+  for (int id = 0; id < 64; ++id) {
+    const char *s = mmh_kernel_name(id);
+    if (s && want == s) return id;
+  }
+  return -1;
+}
+
+int mmh_warm(mmh_handle_t h) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return warm_context(h);
+}
+
+int mmh_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, const float *dB,
+              int ldb, float *dC, int ldc, int accumulate, void *stream) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate,
+                  static_cast<hipStream_t>(stream));
+}
+int mmh_time_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, const float *dB,
+                   int ldb, float *dC, int ldc, int warmup, int reps, void *stream,
+                   float *ms_per_call) {
+  if (!h || reps <= 0 || warmup < 0 || !ms_per_call) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc;
+  for (int i = 0; i < warmup; ++i)
+    if ((rc = sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s)) != MMH_OK) return rc;
+  hipEvent_t t0, t1;
+  HIP_TRY(hipEventCreate(&t0));
+  HIP_TRY(hipEventCreate(&t1));
+  HIP_TRY(hipEventRecord(t0, s));
+  for (int i = 0; i < reps; ++i)
+    if ((rc = sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s)) != MMH_OK) return rc;
+  HIP_TRY(hipEventRecord(t1, s));
+  HIP_TRY(hipEventSynchronize(t1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  *ms_per_call = ms / reps;
+  return check_sticky(h);
+}
+
+// per-launch durations of `count` back-to-back calls (one event pair each): the clock-ramp trace
+int mmh_trace_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
+                    float *dC, int ldc, int count, void *stream, float *ms_each) {
+  if (!h || count <= 0 || count > 4096 || !ms_each) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::vector<hipEvent_t> ev(count + 1, nullptr);
+  int rc = MMH_OK;
+  hipError_t e = hipSuccess;
+  for (auto &x : ev)
+    if (e == hipSuccess) e = hipEventCreate(&x);
+  if (e == hipSuccess) e = hipEventRecord(ev[0], s);
+  for (int i = 0; i < count && rc == MMH_OK && e == hipSuccess; ++i) {
+    rc = sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s);
+    if (rc == MMH_OK) e = hipEventRecord(ev[i + 1], s);
+  }
+  if (rc == MMH_OK && e == hipSuccess) e = hipEventSynchronize(ev[count]);
+  for (int i = 0; i < count && rc == MMH_OK && e == hipSuccess; ++i) e = hipEventElapsedTime(&ms_each[i], ev[i], ev[i + 1]);
+  for (auto &x : ev)   // every event that was created, whatever failed in between
+    if (x) (void)hipEventDestroy(x);
+  if (rc == MMH_OK && e != hipSuccess) rc = hip_fail(e, "mmh_trace_sgemm");
+  return rc;
+}
+
+int mmh_streamk_plan(long tiles, int nk, int grid, int *order, int *place) {
+  if (!order || !place) return MMH_ERR_INVALID_ARG;
+  return build_sk_tables(tiles, nk, grid, order, place) ? MMH_OK : MMH_ERR_INVALID_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+// internal.hpp -- what the translation units of libmmult_hip.so share on the HOST side: the handle,
+// error plumbing, workspace ownership and the launcher entry points each TU exports to the others.
+//
+// The library is the "thin C-ABI shim" of BASELINE.json's north star around the hand-written gfx950
+// kernels of this directory.  Translation units (build.py compiles them in parallel):
+//   state.hip        handle life cycle, sticky error, stream-K workspaces and phase tables, mmh_warm
+//   policy.hip       sgemm_on(): MMH_KERNEL_AUTO's tile choice -- the reference's `NEW := MMult_xxx`
+//                    makefile switch (cuda/makefile:1-3) made a run-time choice.  Pure host code.
+//   launch_reg.hip   register-staged MFMA tiles (sgemm_mfma.hpp): plain, stream-K, split-K
+//   launch_dma.hip   LDS-DMA tiles (sgemm_dma.hpp): plain, stream-K; whole and guarded shapes
+//   launch_valu.hip  K1 / K0 (sgemm_valu.hpp)
+//   host_flavour.hip mmh_sgemm_host(_timed): the host-pointer MY_MMult, row-panel pipeline
+//   shard.hip        mmh_shard_*: single-process row-panel shard over RCCL
+//   igemm.hip        int8 GEMM, quantisation passes
+//   vendor.hip       rocBLAS / hipBLASLt comparators, RCCL loader
+//   probes.hip       peak probes
+//   abi.hip          the remaining extern "C" entry points
+// No torch, no CPU fallback: without a gfx950 device every compute entry point returns
+// MMH_ERR_NO_DEVICE / MMH_ERR_HIP.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mmult_hip.h"
+
+namespace mmh {
+
+// ---- error text (thread-local, state.hip) ----
+void set_last_error(const std::string &s);
+void set_last_launch(const std::string &s);
+const std::string &last_error_ref();
+const std::string &last_launch_ref();
+int hip_fail(hipError_t e, const char *what);
+
+#define HIP_TRY(expr)                                        \
+  do {                                                       \
+    hipError_t e_ = (expr);                                  \
+    if (e_ != hipSuccess) return ::mmh::hip_fail(e_, #expr); \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  // keep_old: a launch captured into a hipGraph may point at the current allocation -- then a buffer
+  // that has to grow is RETIRED (freed with the handle), never freed under the graph
+  int reserve(size_t need, std::vector<void *> *retire_to = nullptr);
+  void release();
+};
+
+// Entry points run on the HANDLE's device and leave the caller's current device as they found it
+// (a torch process whose current device differs from the handle's must not find it changed).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t enter(int device);
+  ~DeviceGuard();
+};
+
+constexpr int kMaxHostPanels = 16;
+
+struct GemmArgs {
+  int m, n, k;
+  const float *A;
+  int lda;
+  const float *B;
+  int ldb;
+  float *C;
+  int ldc;
+  int acc;          // 0: C = A*B, 1: C = A*B + C
+  hipStream_t s;
+};
+
+}  // namespace mmh
+
+struct mmh_context {
+  int device = 0;
+  int kernel = MMH_KERNEL_AUTO;
+  int cu_count = 0;
+  mmh::DevBuf a, b, c;     // staging for the host-pointer flavour
+  mmh::DevBuf bt;          // int8 GEMM: packed (transposed, padded) B
+  int igemm_mode = 0;      // 0 auto, see MMH_OPT_IGEMM_MODE
+  mmh::DevBuf qa, qb, qc, qs;   // quantised GEMM workspace: int8 A, int8 B, int32 C, {amax bits, scales}
+  mmh::DevBuf flags;       // stream-K / split-K per-tile hand-off words; every launch leaves them ZERO (the
+                           // last reader of a word resets it), so only a fresh or suspect buffer is memset
+  bool flags_dirty = true;
+  mmh::DevBuf parts;       // stream-K / split-K partial tiles
+  bool ws_captured = false;          // a captured launch points at flags / parts: retire, never free
+  std::vector<void *> retired;       // allocations a captured graph may still point at
+  int streamk = 1;         // allow the persistent stream-K launch for ragged tile counts
+  int splitk = 0;          // opt-in split-K: 0 off (default), 1 auto, >= 2 that many parts
+  int host_panels = -1;    // host flavour: -1 auto, 0/1 the plain staged form, n pipelined row panels
+  void *rocblas = nullptr; // rocblas_handle, created on first use
+  void *blaslt = nullptr;  // hipBLASLt bridge state (vendor.hip)
+  // the sticky error word: host memory the device can write (an opt-in split-K wait that times out adds
+  // to it); every entry point looks at it before doing anything else
+  int *sticky = nullptr;       // host view
+  int *sticky_dev = nullptr;   // device view of the same word
+  long long spin_limit = 1ll << 26;
+  int fault = 0;               // MMH_OPT_FAULT_INJECT
+  int pin = 1;                 // persistent launches ask for 160 KiB / w of LDS so that exactly w workgroups fit a CU
+  int sk_order = 1;            // stream-K launches get the phase-ordered range / tile tables
+  int dma_edge = 1;            // ragged / 4-byte-aligned shapes may run the guarded LDS-DMA tiles (MMH_OPT_DMA_EDGE)
+  int dma_dword_rows = 1;      // ... including operands whose rows are only 4-byte aligned (odd lda / ldb / base)
+  // stream-K tables per launch shape (tiles, K-slices, grid): [order: grid ints][place: tiles ints]
+  struct SkTable {
+    long tiles = 0;
+    int nk = 0, grid = 0;
+    mmh::DevBuf buf;
+    int *host = nullptr;       // pinned staging the asynchronous upload reads from
+    size_t host_ints = 0;
+    unsigned long stamp = 0;
+    bool pinned = false;       // a captured graph points at buf: never evicted
+    bool uploaded = false;
+  };
+  std::vector<SkTable *> sk_tables;
+  unsigned long sk_stamp = 0;
+  // the hand-off workspaces above are per handle: an eager launch on another stream than the previous
+  // one is ordered behind it with an event (no host block)
+  hipStream_t ws_stream = nullptr;
+  hipEvent_t ws_event = nullptr;
+  bool ws_used = false;
+  // resident workgroups per CU of each persistent kernel, per handle (= per device)
+  std::vector<std::pair<const void *, int>> per_cu;
+  bool warmed = false;
+  // host flavour pipeline: copy-in / compute / copy-out streams, per-panel events
+  hipStream_t hs_in = nullptr, hs_run = nullptr, hs_out = nullptr;
+  hipEvent_t ev_in[mmh::kMaxHostPanels] = {}, ev_run[mmh::kMaxHostPanels] = {}, ev_b = nullptr;
+  bool pipeline_ready = false;
+  hipEvent_t t0 = nullptr, t1 = nullptr;   // mmh_sgemm_host_timed
+};
+
+namespace mmh {
+
+// every compute entry point: refuse a handle whose sticky error word is set
+int check_sticky(mmh_context *h);
+#define ENTER(h)                                       \
+  ::mmh::DeviceGuard guard_;                           \
+  HIP_TRY(guard_.enter((h)->device));                  \
+  if (int st_ = ::mmh::check_sticky(h); st_ != MMH_OK) return st_
+
+int create_context(mmh_context **out, int device);
+void destroy_context(mmh_context *h);
+int warm_context(mmh_context *h);
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  return cap != hipStreamCaptureStatusNone;
+}
+
+// whole tiles, 16-byte aligned operands: the unguarded instantiations
+inline bool fast_shape(int BM, int BN, int KB, const GemmArgs &g) {
+  return (g.m % BM == 0) && (g.n % BN == 0) && (g.k % KB == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) &&
+         (g.ldc % 4 == 0) && aligned16(g.A) && aligned16(g.B) && aligned16(g.C);
+}
+// the buffer-descriptor path needs every byte offset inside a 2 GiB window
+inline bool window_ok(int BM, int BN, int k, int lda, int ldb) {
+  const size_t lim = (1ull << 31) - 4096;
+  return ((size_t)BM * lda + k) * 4 < lim && ((size_t)k * ldb + BN) * 4 < lim;
+}
+
+int check_gemm_args(int m, int n, int k, const void *A, int lda, const void *B, int ldb, const void *C, int ldc);
+bool known_kernel(int kernel);
+
+// ---- stream-K workspaces (state.hip) ----
+int claim_workspaces(mmh_context *ctx, hipStream_t s);
+void workspaces_launched(mmh_context *ctx, hipStream_t s);
+int prepare_flags(mmh_context *ctx, long tiles, hipStream_t s, int **flags);
+int reserve_parts(mmh_context *ctx, size_t bytes, hipStream_t s, float **parts);
+bool build_sk_tables(long tiles, int nk, int grid, int *order, int *place);
+int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place);
+
+// ---- the kernel families (each returns MMH_OK, an error, or 1 = "this shape does not qualify") ----
+int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
+             float *dC, int ldc, int accumulate, hipStream_t s);
+// launch_reg.hip: `kernel` is one of the register-staged ids (MFMA, MFMA_TILES, MFMA_256, MFMA_256X256, MFMA_128X64,
+// MFMA_64X64, MFMA_SIMPLE, MFMA_PIPE, the split-K ids and, in the A/B build, the ablation ids)
+int launch_reg(mmh_context *ctx, int kernel, const GemmArgs &g);
+int launch_reg_splitk(mmh_context *ctx, int tile /* 128 or 64 = BN */, int S, const GemmArgs &g);
+int warm_reg(mmh_context *ctx, float *scratch, hipStream_t s);
+// launch_dma.hip: tile = MMH_KERNEL_MFMA_{64X64,128X64,128X128}_DMA; returns 1 when the shape does not qualify
+int launch_dma(mmh_context *ctx, int kernel, const GemmArgs &g);
+bool dma_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g);
+int warm_dma(mmh_context *ctx, float *scratch, hipStream_t s);
+// launch_valu.hip
+int launch_valu(mmh_context *ctx, int kernel, const GemmArgs &g);
+int warm_valu(mmh_context *ctx, float *scratch, hipStream_t s);
+
+// ---- vendor bridges (vendor.hip) ----
+int rocblas_sgemm_rowmajor(void **handle, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
+                           float *dC, int ldc, void *stream);
+void rocblas_release(void *&handle);
+int hipblaslt_sgemm_rowmajor(void **state, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
+                             float *dC, int ldc, void *stream);
+void hipblaslt_release(void *&state);
+
+struct RcclApi {
+  void *lib = nullptr;
+  int (*get_version)(int *) = nullptr;
+  int (*comm_init_all)(void **, int, const int *) = nullptr;
+  int (*comm_destroy)(void *) = nullptr;
+  int (*comm_count)(void *, int *) = nullptr;
+  int (*group_start)() = nullptr;
+  int (*group_end)() = nullptr;
+  int (*broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  bool ok = false;
+};
+RcclApi &rccl_api();
+
+}  // namespace mmh

@@ -1,0 +1,162 @@
+// policy.hip -- sgemm_on(): argument checks, the empty contraction, and MMH_KERNEL_AUTO's tile choice (the
+// reference's `NEW := MMult_xxx` makefile switch, cuda/makefile:1-3, as a run-time decision).  Pure host code;
+// the kernels are launched by launch_reg.hip / launch_dma.hip / launch_valu.hip.
+#include <algorithm>
+
+#include "internal.hpp"
+
+namespace mmh {
+
+namespace {
+constexpr int kSliceK = 32;   // K-slice depth of the MFMA tiles (sgemm_tile.hpp BK)
+
+// MMH_KERNEL_AUTO: tile choice by how well the shape fills 256 CUs (measured: profiles/r01_sweep.md,
+// r02_ablation.md section 4, r03_offgrid_vs_vendor.md).  Tile counts are counted with the edge tiles a ragged
+// shape needs; since round 3 the LDS-DMA tiles take ragged and 4-byte-aligned shapes too (guarded
+// instantiations), so the same rules serve shapes on and off the 128-grid.
+int auto_kernel(mmh_context *ctx, const GemmArgs &g) {
+  const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
+  const int m = g.m, n = g.n, k = g.k;
+  const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
+  const long tiles128x64 = (long)((m + 127) / 128) * ((n + 63) / 64);
+  const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
+  const long tiles64 = (long)((m + 63) / 64) * ((n + 63) / 64);
+  const bool dma64 = dma_shape_ok(ctx, MMH_KERNEL_MFMA_64X64_DMA, g);
+  const bool dma128x64 = dma_shape_ok(ctx, MMH_KERNEL_MFMA_128X64_DMA, g);
+  const bool dma128 = dma_shape_ok(ctx, MMH_KERNEL_MFMA_128X128_DMA, g);
+  // how much of the tiles' area is matrix (an edge tile costs a whole tile's time)
+  auto fill = [&](long tiles, double area) { return (double)m * (double)n / ((double)tiles * area); };
+  // The 64x64 LDS-DMA tile with three workgroups co-resident per CU has the most efficient loop of
+  // all (148.5-150 TFLOP/s at N = 3072, where 2304 tiles are exactly nine per CU; 151.6-152.9 at 5120 ..
+  // 8192 against 148.5-150.4 for the 256x256 tile) -- on a PLAIN launch: under the chained stream-K
+  // launch its workgroups run at different K phases and stop sharing operand slices in L2 (hit rate
+  // 81 % -> 22 %, 2.4 GB of fabric traffic per launch, profiles/r02_ablation.md section 9).  So it is
+  // chosen for shapes with many tiles (>= 6 per CU) that fill their last round of CUs to
+  // >= 97.5 % (N = 2688, 3072, 3200 on the reference sweep; 5120, 6144, 8192).
+  // One exception: whole rounds of 256x256 tiles in a SHORT launch (N = 4096: one tile per CU, 0.93 ms).
+  // Sustained the two are level there (148.5-149.4 vs 148.7-150.5), but from an idle clock the big
+  // tile is within 1 % of its rate after 18 launches and the small one after 40 -- and 20 launches
+  // from idle is what the reference's timing convention measures (137 vs 129 TFLOP/s,
+  // profiles/r02_cold_start.txt).
+  {
+    const long rounds64 = (tiles64 + cus - 1) / cus;
+    const double est_ms = 2.0 * (double)m * (double)n * (double)k / 150e9;
+    const bool whole_rounds_256 = tiles256 >= cus && tiles256 % cus == 0 && m % 256 == 0 && n % 256 == 0;
+    // ... and only up to N = 8192-sized problems: with K = 16384 and B beyond the Infinity Cache the
+    // small tile's two slices of look-ahead no longer cover its misses (2048 .. 16384 x 16384 x 16384:
+    // 147.8 .. 140.0 against 150.9-151.1 for the 256x256 tile, which those shapes keep)
+    if (dma64 && !(whole_rounds_256 && est_ms < 2.0) && k <= 8192 && tiles64 <= 64 * cus && tiles64 >= 6 * cus &&
+        tiles64 * 1000 >= rounds64 * cus * 975 && fill(tiles64, 4096.0) >= 0.97)
+      return MMH_KERNEL_MFMA_64X64_DMA;
+  }
+  // a ragged count of 256x256 tiles would run as stream-K with ~1.1-1.2 tiles per workgroup; the 128x64
+  // tile covers the same shape with >= 9 tiles per workgroup pair, phase-ordered (N = 4352 / 4608:
+  // 148.6 / 148.9 against 147.2 / 147.4)
+  if (dma128x64 && tiles256 >= cus && tiles256 % cus != 0 && k <= 8192 && tiles128x64 <= 32 * cus &&
+      tiles128x64 * 10 >= 2 * cus * 18)
+    return MMH_KERNEL_MFMA_128X64_DMA;
+  // At least one 256x256 tile per CU: the big tile (fewest staging ops per MFMA) -- unless its
+  // edge tiles pad the shape noticeably more than 128x128 tiles would (ragged tile COUNTS are balanced
+  // by stream-K for either size).
+  if (tiles256 >= cus && fill(tiles256, 65536.0) >= fill(tiles128, 16384.0) - 0.015) return MMH_KERNEL_MFMA_256X256;
+  // Below one 256x256 tile per CU (N < 4096 on the reference sweep) the LDS-DMA tiles (sgemm_dma.hpp), the
+  // choice measured on the sweep (profiles/r02_ablation.md): 128x128 from 1.15 tiles per CU (N >= 2304),
+  // 128x64 from 1.25 of those per CU (N >= 1664), 64x64 below -- each as a chained stream-K launch when
+  // worthwhile.
+  // two co-resident 128x64 workgroups per CU beat one 128x128 workgroup by 1-1.5 % once the launch
+  // is a phase-ordered stream-K (>= 1.8 tiles per workgroup of a 2-per-CU grid: N >= 2816)
+  if (dma128x64 && tiles128x64 * 10 >= 2 * cus * 18) return MMH_KERNEL_MFMA_128X64_DMA;
+  if (dma128 && tiles128 * 100 >= cus * 115) return MMH_KERNEL_MFMA_128X128_DMA;
+  if (dma128x64 && tiles128x64 * 100 >= cus * 125) return MMH_KERNEL_MFMA_128X64_DMA;
+  if (dma64) return MMH_KERNEL_MFMA_64X64_DMA;
+  // operands the descriptors cannot window (beyond 2 GiB), or the guarded LDS-DMA form switched off:
+  // the register-staged tiles
+  if (tiles128x64 * 2 <= cus) return MMH_KERNEL_MFMA_64X64;
+  if (tiles128 * 10 < cus * 8) return MMH_KERNEL_MFMA_128X64;
+  return MMH_KERNEL_MFMA;
+}
+}  // namespace
+
+int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
+             float *dC, int ldc, int accumulate, hipStream_t s) {
+  int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
+  if (rc != MMH_OK) {
+    set_last_error("invalid argument");
+    return rc;
+  }
+  if (m == 0 || n == 0) return MMH_OK;
+  if (k == 0) {
+    // empty contraction: C = 0 (overwrite) or C unchanged (accumulate)
+    if (!accumulate)
+      HIP_TRY(hipMemset2DAsync(dC, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), (size_t)m, s));
+    return MMH_OK;
+  }
+  const GemmArgs g{m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s};
+  const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
+  const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
+  if (kernel == MMH_KERNEL_AUTO) {
+    // OPT-IN split-K (default off: it gives up the one-chain-per-element bits, see sgemm_mfma.hpp K2s):
+    // shapes with fewer 128x128 tiles than workgroup slots run their K ranges concurrently
+    const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
+    if (ctx && ctx->splitk > 0 && tiles128 < cus && tiles256 < cus) {
+      int S = ctx->splitk;
+      if (S == 1) {   // auto: fill two workgroups per CU, keep >= 8 K-slices per part
+        S = (int)((2 * cus) / (tiles128 > 0 ? tiles128 : 1));
+        S = std::min(std::min(S, k / (8 * kSliceK)), 8);
+      }
+      if (S >= 2) {
+        const int sk = launch_reg_splitk(ctx, 128, S, g);
+        if (sk <= 0) return sk;
+      }
+    }
+    kernel = auto_kernel(ctx, g);
+  }
+  switch (kernel) {
+    case MMH_KERNEL_VALU:
+    case MMH_KERNEL_VALU_128X128:
+    case MMH_KERNEL_VALU_64X64:
+    case MMH_KERNEL_NAIVE:
+      return launch_valu(ctx, kernel, g);
+    case MMH_KERNEL_MFMA_64X64_DMA: {   // K2L; shapes it does not take run the register-staged tile of the same size
+      const int d = launch_dma(ctx, kernel, g);
+      return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA_64X64, g);
+    }
+    case MMH_KERNEL_MFMA_128X64_DMA: {
+      const int d = launch_dma(ctx, kernel, g);
+      return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA_128X64, g);
+    }
+    case MMH_KERNEL_MFMA_128X128_DMA: {
+      const int d = launch_dma(ctx, kernel, g);
+      return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA, g);
+    }
+    case MMH_KERNEL_MFMA_SPLITK: {   // K2s forced: 128x128 tiles, ctx->splitk parts (auto when <= 1)
+      int S = ctx ? ctx->splitk : 0;
+      if (S <= 1) {
+        S = (int)((2 * cus) / (tiles128 > 0 ? tiles128 : 1));
+        S = std::min(std::min(S, k / (8 * kSliceK)), 8);
+      }
+      const int sk = launch_reg_splitk(ctx, 128, S, g);
+      return sk <= 0 ? sk : launch_reg(ctx, MMH_KERNEL_MFMA, g);
+    }
+    case MMH_KERNEL_MFMA_SPLITK_128X64: {   // K2s on 128x64 tiles
+      int S = ctx ? ctx->splitk : 0;
+      const long tiles = (long)((m + 127) / 128) * ((n + 63) / 64);
+      if (S <= 1) {
+        S = (int)((2 * cus) / (tiles > 0 ? tiles : 1));
+        S = std::min(std::min(S, k / (8 * kSliceK)), 8);
+      }
+      const int sk = launch_reg_splitk(ctx, 64, S, g);
+      return sk <= 0 ? sk : launch_reg(ctx, MMH_KERNEL_MFMA_128X64, g);
+    }
+#ifdef MMH_AB_BUILD
+    case 45:
+    case 46:
+    case 47:
+      return launch_dma(ctx, kernel, g);
+#endif
+    default:
+      return launch_reg(ctx, kernel, g);
+  }
+}
+
+}  // namespace mmh

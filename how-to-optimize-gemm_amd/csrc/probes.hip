@@ -1,33 +1,17 @@
-// probes.hpp -- peak probes and the two vendor-library bridges (rocBLAS
-// comparator; the RCCL entry points the single-process row-panel shard uses).
-//
-// Probes: the reference measures its ceilings before quoting percentages
-// (aarch64/gflops_benchmark/main.c:19-25 -- an FMLA-only loop;
-// vulkan/benchmark/gmem_bandwidth.cpp:8-48 -- a copy kernel).  Same idea on
-// gfx950: an MFMA-only loop (v_mfma_f32_16x16x4_f32, 8 independent
-// accumulators per wave, no memory traffic) and a float4 stream copy.
-//
-// rocBLAS and RCCL are loaded with dlopen on first use so that the core
-// library has no link-time dependency on either.
-#pragma once
-#include <dlfcn.h>
-#include <hip/hip_runtime.h>
-
-#include <string>
-#include <vector>
-
-#include "../../include/mmult_hip.h"
+// probes.hip -- peak probes.  The reference measures its ceilings before quoting percentages
+// (aarch64/gflops_benchmark/main.c:19-25 -- an FMLA-only loop; vulkan/benchmark/gmem_bandwidth.cpp:8-48 -- a copy
+// kernel; vulkan/benchmark/smem_bandwidth.cpp:30-42).  Same idea on gfx950: MFMA-only loops (fp32 and int8, no memory
+// traffic), a float4 stream copy / read, LDS fragment reads.  Part of libmmult_hip.so (see internal.hpp).
+#include "internal.hpp"
 #include "sgemm_tile.hpp"
 
 namespace mmh {
+namespace {
 
-#define MMH_HIP_TRY(expr, err)                                         \
+#define MMH_HIP_TRY(expr)                                              \
   do {                                                                 \
     hipError_t e_ = (expr);                                            \
-    if (e_ != hipSuccess) {                                            \
-      if (err) *(err) = std::string(#expr) + ": " + hipGetErrorString(e_); \
-      return MMH_ERR_HIP;                                              \
-    }                                                                  \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);                  \
   } while (0)
 
 // ------------------------------------------------------------- MFMA probe --
@@ -47,21 +31,21 @@ __global__ void __launch_bounds__(256) probe_mfma_kernel(float *out, int iters, 
   if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];  // keep the chain live
 }
 
-inline int probe_mfma_f32(int cu_count, float *tflops, std::string *err) {
+int probe_mfma_f32(int cu_count, float *tflops) {
   if (cu_count <= 0) cu_count = 256;
   float *d = nullptr;
-  MMH_HIP_TRY(hipMalloc(&d, 64), err);
+  MMH_HIP_TRY(hipMalloc(&d, 64));
   const int iters = 20000, blocks = cu_count * 2;
   hipEvent_t t0, t1;
-  MMH_HIP_TRY(hipEventCreate(&t0), err);
-  MMH_HIP_TRY(hipEventCreate(&t1), err);
+  MMH_HIP_TRY(hipEventCreate(&t0));
+  MMH_HIP_TRY(hipEventCreate(&t1));
   hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, 0, d, 2000, 0.001f);
-  MMH_HIP_TRY(hipEventRecord(t0, 0), err);
+  MMH_HIP_TRY(hipEventRecord(t0, 0));
   hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, 0, d, iters, 0.001f);
-  MMH_HIP_TRY(hipEventRecord(t1, 0), err);
-  MMH_HIP_TRY(hipEventSynchronize(t1), err);
+  MMH_HIP_TRY(hipEventRecord(t1, 0));
+  MMH_HIP_TRY(hipEventSynchronize(t1));
   float ms = 0.f;
-  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
+  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
   const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
   *tflops = (float)(flops / (ms * 1e-3) / 1e12);
   (void)hipEventDestroy(t0);
@@ -135,15 +119,15 @@ __global__ void __launch_bounds__(256) probe_mfma_i8_random_kernel(int *out, int
 
 // random_operands: 0 = the constant-operand loop, 1 = the random-operand loop; the timed launch is
 // repeated until `min_ms` have passed and the LAST launch's rate is returned (sustained clock).
-inline int probe_mfma_i8(int cu_count, float *tops, std::string *err, int random_operands = 0,
+int probe_mfma_i8(int cu_count, float *tops, int random_operands = 0,
                          float min_ms = 0.f) {
   if (cu_count <= 0) cu_count = 256;
   int *d = nullptr;
-  MMH_HIP_TRY(hipMalloc(&d, 64), err);
+  MMH_HIP_TRY(hipMalloc(&d, 64));
   const int iters = 40000, blocks = cu_count * 2;
   hipEvent_t t0, t1;
-  MMH_HIP_TRY(hipEventCreate(&t0), err);
-  MMH_HIP_TRY(hipEventCreate(&t1), err);
+  MMH_HIP_TRY(hipEventCreate(&t0));
+  MMH_HIP_TRY(hipEventCreate(&t1));
   auto launch = [&](int n) {
     if (random_operands) hipLaunchKernelGGL(probe_mfma_i8_random_kernel, dim3(blocks), dim3(256), 0, 0, d, n, 1);
     else hipLaunchKernelGGL(probe_mfma_i8_kernel, dim3(blocks), dim3(256), 0, 0, d, n, 1);
@@ -151,11 +135,11 @@ inline int probe_mfma_i8(int cu_count, float *tops, std::string *err, int random
   launch(4000);
   float ms = 0.f, total = 0.f;
   do {
-    MMH_HIP_TRY(hipEventRecord(t0, 0), err);
+    MMH_HIP_TRY(hipEventRecord(t0, 0));
     launch(iters);
-    MMH_HIP_TRY(hipEventRecord(t1, 0), err);
-    MMH_HIP_TRY(hipEventSynchronize(t1), err);
-    MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
+    MMH_HIP_TRY(hipEventRecord(t1, 0));
+    MMH_HIP_TRY(hipEventSynchronize(t1));
+    MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
     total += ms;
   } while (total < min_ms);
   const double ops = (double)blocks * 4 * iters * 8.0 * (2.0 * 16 * 16 * 64);
@@ -199,19 +183,19 @@ __global__ void __launch_bounds__(256) probe_read_kernel(const f32x4 *__restrict
 }
 
 // mode 0: copy (read + write bytes counted); mode 1: read only.
-inline int probe_hbm_copy(size_t bytes, float *gbps, std::string *err, int cu_count = 256, int mode = 0) {
+int probe_hbm_copy(size_t bytes, float *gbps, int cu_count = 256, int mode = 0) {
   const size_t n = bytes / sizeof(f32x4);
   f32x4 *src = nullptr, *dst = nullptr;
-  MMH_HIP_TRY(hipMalloc(&src, n * sizeof(f32x4)), err);
+  MMH_HIP_TRY(hipMalloc(&src, n * sizeof(f32x4)));
   if (hipMalloc(&dst, mode == 0 ? n * sizeof(f32x4) : 64) != hipSuccess) {
     (void)hipFree(src);
-    if (err) *err = "hipMalloc(dst) failed";
+    set_last_error("hipMalloc(dst) failed");
     return MMH_ERR_ALLOC;
   }
-  MMH_HIP_TRY(hipMemset(src, 1, n * sizeof(f32x4)), err);
+  MMH_HIP_TRY(hipMemset(src, 1, n * sizeof(f32x4)));
   hipEvent_t t0, t1;
-  MMH_HIP_TRY(hipEventCreate(&t0), err);
-  MMH_HIP_TRY(hipEventCreate(&t1), err);
+  MMH_HIP_TRY(hipEventCreate(&t0));
+  MMH_HIP_TRY(hipEventCreate(&t1));
   (void)cu_count;
   const unsigned blocks = (unsigned)((n + 256 * PROBE_U - 1) / (256 * PROBE_U));
   const int reps = 10;
@@ -221,12 +205,12 @@ inline int probe_hbm_copy(size_t bytes, float *gbps, std::string *err, int cu_co
   };
   launch();
   launch();
-  MMH_HIP_TRY(hipEventRecord(t0, 0), err);
+  MMH_HIP_TRY(hipEventRecord(t0, 0));
   for (int r = 0; r < reps; ++r) launch();
-  MMH_HIP_TRY(hipEventRecord(t1, 0), err);
-  MMH_HIP_TRY(hipEventSynchronize(t1), err);
+  MMH_HIP_TRY(hipEventRecord(t1, 0));
+  MMH_HIP_TRY(hipEventSynchronize(t1));
   float ms = 0.f;
-  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
+  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
   *gbps = (float)((mode == 0 ? 2.0 : 1.0) * n * sizeof(f32x4) * reps / (ms * 1e-3) / 1e9);
   (void)hipEventDestroy(t0);
   (void)hipEventDestroy(t1);
@@ -280,12 +264,12 @@ __global__ void __launch_bounds__(512) probe_lds_read_kernel(float *__restrict__
 }
 
 // bytes per clock per CU are derived by the caller from the device clock; this returns aggregate GB/s
-inline int probe_lds_read(int width, float *gbps, std::string *err, int cu_count) {
+int probe_lds_read(int width, float *gbps, int cu_count) {
   float *out = nullptr;
-  MMH_HIP_TRY(hipMalloc(&out, 64), err);
+  MMH_HIP_TRY(hipMalloc(&out, 64));
   hipEvent_t t0, t1;
-  MMH_HIP_TRY(hipEventCreate(&t0), err);
-  MMH_HIP_TRY(hipEventCreate(&t1), err);
+  MMH_HIP_TRY(hipEventCreate(&t0));
+  MMH_HIP_TRY(hipEventCreate(&t1));
   const int iters = 4096, blocks = 2 * cu_count;
   auto launch = [&] {
     switch (width) {
@@ -297,12 +281,12 @@ inline int probe_lds_read(int width, float *gbps, std::string *err, int cu_count
   };
   launch();
   const int reps = 10;
-  MMH_HIP_TRY(hipEventRecord(t0, 0), err);
+  MMH_HIP_TRY(hipEventRecord(t0, 0));
   for (int r = 0; r < reps; ++r) launch();
-  MMH_HIP_TRY(hipEventRecord(t1, 0), err);
-  MMH_HIP_TRY(hipEventSynchronize(t1), err);
+  MMH_HIP_TRY(hipEventRecord(t1, 0));
+  MMH_HIP_TRY(hipEventSynchronize(t1));
   float ms = 0.f;
-  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1), err);
+  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
   const int w = width < 0 ? -width : width;
   *gbps = (float)((double)blocks * 512 * 8 * w * iters * reps / (ms * 1e-3) / 1e9);
   (void)hipEventDestroy(t0);
@@ -311,96 +295,47 @@ inline int probe_lds_read(int width, float *gbps, std::string *err, int cu_count
   return MMH_OK;
 }
 
-// ---------------------------------------------------------------- rocBLAS --
-// Comparator only (the reference's OLD := MMult_cuBLAS_1 line,
-// cuda/makefile:1; cuda/MMult_cuBLAS_1.cpp:17-18): a column-major library
-// computes C^T = B^T * A^T, which is row-major C = A * B.
-struct RocblasApi {
-  void *lib = nullptr;
-  int (*create)(void **) = nullptr;
-  int (*destroy)(void *) = nullptr;
-  int (*set_stream)(void *, hipStream_t) = nullptr;
-  int (*sgemm)(void *, int, int, int, int, int, const float *, const float *, int, const float *,
-               int, const float *, float *, int) = nullptr;
-  bool ok = false;
-};
-
-inline RocblasApi &rocblas_api() {
-  static RocblasApi api = [] {
-    RocblasApi a;
-    a.lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!a.lib) a.lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!a.lib) return a;
-    a.create = reinterpret_cast<decltype(a.create)>(dlsym(a.lib, "rocblas_create_handle"));
-    a.destroy = reinterpret_cast<decltype(a.destroy)>(dlsym(a.lib, "rocblas_destroy_handle"));
-    a.set_stream = reinterpret_cast<decltype(a.set_stream)>(dlsym(a.lib, "rocblas_set_stream"));
-    a.sgemm = reinterpret_cast<decltype(a.sgemm)>(dlsym(a.lib, "rocblas_sgemm"));
-    a.ok = a.create && a.destroy && a.set_stream && a.sgemm;
-    return a;
-  }();
-  return api;
-}
-
-inline void rocblas_release(void *&handle) {
-  if (handle && rocblas_api().ok) rocblas_api().destroy(handle);
-  handle = nullptr;
-}
-
-inline int rocblas_sgemm_rowmajor(void **handle, int m, int n, int k, const float *dA, int lda,
-                                  const float *dB, int ldb, float *dC, int ldc, void *stream,
-                                  std::string *err) {
-  RocblasApi &api = rocblas_api();
-  if (!api.ok) {
-    if (err) *err = "librocblas.so could not be loaded";
-    return MMH_ERR_UNSUPPORTED;
-  }
-  if (!*handle && api.create(handle) != 0) {
-    if (err) *err = "rocblas_create_handle failed";
-    return MMH_ERR_UNSUPPORTED;
-  }
-  api.set_stream(*handle, static_cast<hipStream_t>(stream));
-  const float one = 1.0f, zero = 0.0f;
-  constexpr int op_none = 111;  // rocblas_operation_none
-  const int st = api.sgemm(*handle, op_none, op_none, n, m, k, &one, dB, ldb, dA, lda, &zero, dC, ldc);
-  if (st != 0) {
-    if (err) *err = "rocblas_sgemm returned status " + std::to_string(st);
-    return MMH_ERR_HIP;
-  }
-  return MMH_OK;
-}
-
-// ------------------------------------------------------------------- RCCL --
-struct RcclApi {
-  void *lib = nullptr;
-  int (*get_version)(int *) = nullptr;
-  int (*comm_init_all)(void **, int, const int *) = nullptr;
-  int (*comm_destroy)(void *) = nullptr;
-  int (*comm_count)(void *, int *) = nullptr;
-  int (*group_start)() = nullptr;
-  int (*group_end)() = nullptr;
-  int (*broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-  bool ok = false;
-};
-
-inline RcclApi &rccl_api() {
-  static RcclApi api = [] {
-    RcclApi a;
-    a.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!a.lib) a.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!a.lib) a.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!a.lib) return a;
-    a.get_version = reinterpret_cast<decltype(a.get_version)>(dlsym(a.lib, "ncclGetVersion"));
-    a.comm_init_all = reinterpret_cast<decltype(a.comm_init_all)>(dlsym(a.lib, "ncclCommInitAll"));
-    a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(a.lib, "ncclCommDestroy"));
-    a.comm_count = reinterpret_cast<decltype(a.comm_count)>(dlsym(a.lib, "ncclCommCount"));
-    a.group_start = reinterpret_cast<decltype(a.group_start)>(dlsym(a.lib, "ncclGroupStart"));
-    a.group_end = reinterpret_cast<decltype(a.group_end)>(dlsym(a.lib, "ncclGroupEnd"));
-    a.broadcast = reinterpret_cast<decltype(a.broadcast)>(dlsym(a.lib, "ncclBroadcast"));
-    a.ok = a.get_version && a.comm_init_all && a.comm_destroy && a.comm_count && a.group_start && a.group_end &&
-           a.broadcast;
-    return a;
-  }();
-  return api;
-}
-
+}  // namespace
 }  // namespace mmh
+
+using namespace mmh;
+
+extern "C" {
+
+int mmh_probe_mfma_f32(mmh_handle_t h, float *tflops) {
+  if (!h || !tflops) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return probe_mfma_f32(h->cu_count, tflops);
+}
+
+int mmh_probe_mfma_i8(mmh_handle_t h, float *tops) {
+  if (!h || !tops) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return probe_mfma_i8(h->cu_count, tops);
+}
+
+int mmh_probe_mfma_i8_sustained(mmh_handle_t h, int random_operands, float min_ms, float *tops) {
+  if (!h || !tops || min_ms < 0.f || min_ms > 2000.f) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return probe_mfma_i8(h->cu_count, tops, random_operands ? 1 : 0, min_ms);
+}
+
+int mmh_probe_hbm_copy(mmh_handle_t h, size_t bytes, float *gbps) {
+  if (!h || !gbps || bytes < (1u << 20)) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return probe_hbm_copy(bytes, gbps, h->cu_count, 0);
+}
+
+int mmh_probe_hbm_read(mmh_handle_t h, size_t bytes, float *gbps) {
+  if (!h || !gbps || bytes < (1u << 20)) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return probe_hbm_copy(bytes, gbps, h->cu_count, 1);
+}
+
+int mmh_probe_lds_read(mmh_handle_t h, int width, float *gbps) {
+  if (!h || !gbps || (width != 16 && width != 8 && width != 4 && width != -8)) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return probe_lds_read(width, gbps, h->cu_count);
+}
+
+}  // extern "C"

@@ -36,9 +36,21 @@
 // slower at N <= 1664, profiles/r02_ablation.md section 2).
 //
 // Arithmetic: the same MFMA (v_mfma_f32_16x16x4_f32) fed the same k's in ascending order as every
-// other kernel here -- one fp32 fmaf chain per C element, bit-identical results.  Whole-tile,
-// 16-byte-aligned shapes only (a ragged K tail of A cannot be masked on its way into LDS); the
-// launcher sends everything else to the register-staged kernels.
+// other kernel here -- one fp32 fmaf chain per C element, bit-identical results.
+//
+// Any shape (EDGE instantiations, round 3).  Nothing can be masked on its way into LDS, so the edges are
+// handled where the hardware and the fragment reads allow it:
+//   * M / N edges: the descriptors' extents end at the block's last valid A row / B column (the trick of
+//     the guarded register-staged kernel, sgemm_mfma.hpp): the per-dword range check turns rows >= m of A
+//     and rows >= k of B into zeros IN LDS; columns >= n of B are neighbouring memory and only feed C
+//     columns that are never stored;
+//   * K tail: A's columns >= k of the last, partial slice are the next row (or the caller's padding) and
+//     may be anything, NaN included.  That slice is peeled out of the unrolled ring and run by a copy of
+//     the slice body that zeroes the A fragments whose k index is past the end (one v_cndmask per fragment
+//     element; B's rows there are zeros already) -- one slice per tile pays the run-time ring index;
+//   * 4-byte aligned operands / odd leading dimensions: `buffer_load_dwordx4 ... lds` takes any dword-
+//     aligned source (tools/probes/lds_dma_align_probe.hip); C goes out through `aligned(4)` vectors.
+// The whole-tile 16-byte-aligned instantiations (EDGE = false) are the round-2 kernels, unchanged.
 //
 // What was tried and dropped (profiles/r02_ablation.md): four ring buffers (no faster); a run-time ring
 // index instead of the unrolled ring (-17 %: an address v_add per fragment read); 8-wave tiles, 256x128
@@ -105,7 +117,7 @@ struct DmaTile {
 // (A static member of a class template, not a function template: hipcc's host pass mishandles function
 // templates whose bodies hold buffer descriptors in generic lambdas -- igemm_s8.hpp has the same note --
 // and the 8-wave instantiations then fail to resolve from a second __global__ template.)
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool PART_WT = false>
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool PART_WT = false, bool EDGE = false>
 struct DmaSegment {
 static __device__ __forceinline__ void run(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
                                            const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
@@ -125,6 +137,13 @@ static __device__ __forceinline__ void run(float *lds, int m, int n, int k, cons
   const int crow = row0 + wm * 16 * WTM + 4 * kq;
   const int ccol = col0 + wn * 16 * WTN + WTN * li;
 
+  // EDGE: the block may hang over the matrix; C may be only 4-byte aligned (the type must say so)
+  const int rows_valid = EDGE ? min(BM, m - row0) : BM;
+  const int cols_valid = EDGE ? min(BN, n - col0) : BN;
+  const bool whole_c = !EDGE || (rows_valid == BM && cols_valid == BN);
+  typedef float c_vec_u __attribute__((ext_vector_type(WTN), aligned(4)));
+  using c_vec = std::conditional_t<EDGE, c_vec_u, bfrag_t>;
+
   f32x4 acc[WTM][WTN];
   if (part_in) {
 #pragma unroll
@@ -140,7 +159,15 @@ static __device__ __forceinline__ void run(float *lds, int m, int n, int k, cons
     for (int t = 0; t < WTM; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bfrag_t v = *reinterpret_cast<const bfrag_t *>(C + (size_t)(crow + 16 * t + r) * ldc + ccol);
+        const int row = crow + 16 * t + r;
+        bfrag_t v = {};
+        if (whole_c) {
+          v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
+        } else if (row < m) {
+#pragma unroll
+          for (int u = 0; u < WTN; ++u)
+            if (ccol + u < n) v[u] = C[(size_t)row * ldc + ccol + u];
+        }
 #pragma unroll
         for (int u = 0; u < WTN; ++u) acc[t][u][r] = v[u];
       }
@@ -152,10 +179,14 @@ static __device__ __forceinline__ void run(float *lds, int m, int n, int k, cons
   }
 
   // descriptors: A from (row0, 0), B from (0, col0); a zero-length twin of each for slices past the end
+  // (EDGE: extents end at the last valid element of this block's A rows / B columns -- rows >= m of A and
+  // rows >= k of B arrive in LDS as zeros)
+  const uint32_t ext_a = EDGE ? (uint32_t)(((rows_valid - 1) * lda + k) * 4) : 0x7fffffffu;
+  const uint32_t ext_b = EDGE ? (uint32_t)(((k - 1) * ldb + cols_valid) * 4) : 0x7fffffffu;
   const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + (size_t)row0 * lda), 0, 0x7fffffffu, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A + (size_t)row0 * lda), 0, ext_a, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + col0), 0, 0x7fffffffu, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B + col0), 0, ext_b, 0x00020000);
   const __amdgpu_buffer_rsrc_t null_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t null_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, 0, 0x00020000);
   // wave w moves pieces CA w .. CA w + CA - 1 of the A image and likewise of the B image; the 16-byte
@@ -269,15 +300,46 @@ static __device__ __forceinline__ void run(float *lds, int m, int n, int k, cons
       __builtin_amdgcn_sched_barrier(0);
     });
   };
+  // EDGE: the problem's last slice when k is not a multiple of KB -- A's fragments past column k are zeroed
+  // as they are used (they hold the next row's floats or the caller's padding, NaN included; B's rows there
+  // are zeros by descriptor).  Peeled: its ring position is a run-time value, which the steady-state slices
+  // must not pay for (see `slice`).  Its fragments for k-steps 0 .. D-1 were read by whatever ran before it.
+  const bool ragged_k = EDGE && ke * KB > k;
+  const int ke_main = ragged_k ? ke - 1 : ke;
   int kt = kb;
-  for (;;) {
-    static_assert(NBUF == 3, "the slice loop is unrolled over a ring of three (four was measured: no faster)");
-    slice(kt, std::integral_constant<int, 0>{});
-    if (++kt >= ke) break;
-    slice(kt, std::integral_constant<int, 1>{});
-    if (++kt >= ke) break;
-    slice(kt, std::integral_constant<int, 2>{});
-    if (++kt >= ke) break;
+  if (kt < ke_main)
+    for (;;) {
+      static_assert(NBUF == 3, "the slice loop is unrolled over a ring of three (four was measured: no faster)");
+      slice(kt, std::integral_constant<int, 0>{});
+      if (++kt >= ke_main) break;
+      slice(kt, std::integral_constant<int, 1>{});
+      if (++kt >= ke_main) break;
+      slice(kt, std::integral_constant<int, 2>{});
+      if (++kt >= ke_main) break;
+    }
+  if constexpr (EDGE) {
+    if (ragged_k) {
+      const int krem = k - kt * KB;                       // valid k's of this slice, 1 .. KB-1
+      const float *buf = lds + ((kt - kb) % NBUF) * STAGE;
+      static_for<KS>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        if constexpr (ks + D < KS) {
+          fa[(ks + D) & 3] = frag_a(buf, std::integral_constant<int, ks + D>{});
+          fb[(ks + D) & 3] = frag_b(buf, std::integral_constant<int, ks + D>{});
+        }
+        afrag_t a = fa[ks & 3];
+        bfrag_t b = fb[ks & 3];
+        const bool live = 4 * ks + kq < krem;   // this lane's k of the k-step (the same k for its A and its B operand)
+#pragma unroll
+        for (int t = 0; t < WTM; ++t) a[t] = live ? a[t] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < WTN; ++u) b[u] = live ? b[u] : 0.0f;   // (zeros by descriptor already; belt and braces)
+#pragma unroll
+        for (int t = 0; t < WTM; ++t)
+#pragma unroll
+          for (int u = 0; u < WTN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
+      });
+    }
   }
   // keep the fragments prefetched past the last slice formally alive: otherwise the compiler sinks the
   // reads that follow each slice's barrier into the NEXT slice's block (they are dead on the exit path)
@@ -344,15 +406,19 @@ static __device__ __forceinline__ void run(float *lds, int m, int n, int k, cons
         } else {
           *reinterpret_cast<bfrag_t *>(part_out + (size_t)(row - row0) * BN + (ccol - col0)) = v;
         }
-      } else {
-        *reinterpret_cast<bfrag_t *>(C + (size_t)row * ldc + ccol) = v;
+      } else if (whole_c) {
+        *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + ccol) = v;
+      } else if (row < m) {
+#pragma unroll
+        for (int u = 0; u < WTN; ++u)
+          if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
       }
     }
 }
 };
 
 // One workgroup per C tile (XCD-aware block -> tile map), whole K range.
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false>
 __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64)
 sgemm_mfma_dma_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
                       float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn) {
@@ -360,14 +426,15 @@ sgemm_mfma_dma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   int tm, tn;
   dma_stamp(0);
   block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
-  DmaSegment<BM, BN, KB, WTM, WTN, NBUF>::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0, k / KB, accumulate != 0);
+  DmaSegment<BM, BN, KB, WTM, WTN, NBUF, false, EDGE>::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0,
+                                                           (k + KB - 1) / KB, accumulate != 0);
   dma_stamp_after_stores(3);
 }
 
 // Segment policy of this tile for the chained stream-K control flow (streamk_body in sgemm_mfma.hpp,
 // K2p) -- tile counts that do not divide the chip run as one persistent workgroup per CU over ranges
 // of (tile, K-slice) units, partial tiles handed over through the workspace: sgemm_dma_streamk_kernel.
-template <int BM_, int BN_, int KB_, int WTM, int WTN, int NBUF>
+template <int BM_, int BN_, int KB_, int WTM, int WTN, int NBUF, bool EDGE = false>
 struct DmaSeg {
   static constexpr int BM = BM_, BN = BN_, KB = KB_;
   static constexpr int THREADS = DmaTile<BM_, BN_, KB_, WTM, WTN, NBUF>::THREADS;
@@ -375,8 +442,8 @@ struct DmaSeg {
                                              const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                              int tm, int tn, int kb, int ke, bool init_from_c, const float *part_in,
                                              float *part_out) {
-    DmaSegment<BM, BN, KB, WTM, WTN, NBUF, true>::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke, init_from_c,
-                                                      part_in, part_out);   // partial tiles write-through
+    DmaSegment<BM, BN, KB, WTM, WTN, NBUF, true, EDGE>::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke,
+                                                            init_from_c, part_in, part_out);   // partial tiles write-through
   }
 };
 

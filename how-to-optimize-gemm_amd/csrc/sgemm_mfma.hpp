@@ -524,27 +524,34 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 // ---------------------------------------------------------------------------
 // K2p: persistent, chained stream-K.  For tile counts that do not divide the
 // chip (e.g. N=3072: 576 tiles for 512 workgroup slots) the plain kernel runs
-// a nearly empty last round.  Here gridDim.x resident workgroups split the
-// T * nk (tile, K-slice) units evenly into consecutive ranges.  A range is
-//     [a later part of tile a] [whole tiles ...] [the head of tile b]
-// and is worked through with the head of b FIRST (slices 0..h-1; the partial
-// accumulators are stored to this workgroup's slot of a partials workspace and the
-// tile's part counter is published), then the whole tiles, the part of a LAST.  A later
-// part CONTINUES the chain its predecessor left in the workspace (the slot of the range
-// before it -- consecutive parts of a tile are consecutive ranges): it waits for the
-// tile's counter to reach its part index, starts its accumulators from that slot, runs
-// its slices and either finishes the tile (only then is C written) or stores to its own
-// slot and publishes the counter for the next part -- so every C(i,j) is still
-// one fp32 fmaf chain over ascending k and the result is bit-identical to the
-// plain kernel.  A workgroup publishes its head before doing anything else, so
-// with ranges of at least one tile the wait is over before it starts; with
-// shorter ranges (>= half a tile, two workgroups per CU) a waiting workgroup
-// leaves its CU to its partner, which is still better than an idle CU.
-// Dependencies only ever point to lower range indices.
+// a nearly empty last round.  Here gridDim.x workgroups split the T * nk
+// (tile, K-slice) units evenly into consecutive ranges of AT LEAST ONE TILE
+// (the launcher guarantees T >= gridDim.x), so a range is
+//     [the tail of tile a] [whole tiles ...] [the head of tile b]
+// and a tile has at most two parts.  A range is worked through with the head of
+// b FIRST (slices 0..h-1; the partial accumulators go to this range's slot of a
+// workspace, write-through), then the whole tiles, the tail of a LAST: it
+// CONTINUES the chain the head's owner left in the workspace, so every C(i,j) is
+// still one fp32 fmaf chain over ascending k and the result is bit-identical to
+// the plain kernel.
+//
+// The hand-over is WAIT-FREE (round 3; rounds 1-2 had the tail's owner spin on a flag, which is only
+// live while every workgroup of the grid is resident -- something HIP never promises and a second
+// stream, a second handle or an RCCL kernel takes away).  A shared tile has one word:
+//     0  nothing yet        1  head published        2  the tail's owner came first
+// The head's owner stores its partial tile, drains, and EXCHANGES 1 into the word; the tail's owner,
+// when it gets there, COMPARE-AND-SWAPs 0 -> 2.  Exactly one of them sees the other's mark:
+//   * the tail's owner reads 1 (always, when the grid is co-resident: the head is the first thing its
+//     owner does, a whole tile earlier): it acquires, continues the chain from the slot, stores C;
+//   * the head's owner reads 2: the tail's owner has LEFT (it never waits); the head's owner runs the
+//     tail itself, from its own slot, after its other work.
+// Whoever finishes the tile puts the 0 back, so the next launch needs no memset.  No workgroup ever
+// waits for another: a launch makes progress with ANY number of resident workgroups, in any dispatch
+// order -- co-residency is a matter of speed (the ranges are sized for it), not of correctness, and
+// there is no time-out left to take.
 // Visibility across CUs/XCDs (cdna guide G16, recipe R1): producer = write-through (sc1)
-// stores of the partial tile, every wave drains vmcnt, barrier, one lane relaxed
-// agent-scope counter store; consumer = one lane relaxed poll (bounded), agent-scope
-// acquire fence, barrier, plain loads.
+// stores of the partial tile, every wave drains vmcnt, barrier, one lane's relaxed agent-scope
+// atomic on the word; consumer = one lane's atomic, agent-scope acquire fence, barrier, plain loads.
 // ---------------------------------------------------------------------------
 // The stream-K control flow is written once, over a SEGMENT policy -- how one (tile, K-slice range) is
 // computed: Seg::BM, BN, KB, THREADS and Seg::run(lds, ..., tm, tn, kb, ke, init_from_c, part_in,
@@ -563,17 +570,14 @@ struct RegSeg {
   }
 };
 
+constexpr int SK_EMPTY = 0, SK_HEAD_DONE = 1, SK_TAIL_LEFT = 2;
+
 template <class Seg>
 __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
                                              const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                              int accumulate, int nbm, int nbn, int *__restrict__ flags,
-                                             int *__restrict__ err, float *__restrict__ parts, long long spin_limit,
-                                             int fault, const int *__restrict__ order = nullptr,
+                                             float *__restrict__ parts, const int *__restrict__ order = nullptr,
                                              const int *__restrict__ place = nullptr) {
-  // err: the handle's STICKY error word (host-mapped): a hand-off wait that runs into `spin_limit`
-  // adds to it and the workgroup stops -- it never continues a chain from a slot that was not
-  // published -- and every later mmh_* call on the handle fails until the word is cleared.
-  // fault != 0 (MMH_OPT_FAULT_INJECT, tests): producers do not publish, so every consumer times out.
   constexpr int BM = Seg::BM, BN = Seg::BN, KB = Seg::KB;
   const int nk = (k + KB - 1) / KB;
   const int T = nbm * nbn, G = gridDim.x;
@@ -602,67 +606,69 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
     tm = first_m + in_group % gsize;
     tn = in_group / gsize;
   };
-  // slices [kb, ke) of tile t.  kb > 0: a later part -- wait for the parts before it.
-  // ke < nk: not the last part -- publish.  Returns false when the wait timed out.
-  auto run = [&](int t, int kb, int ke) -> bool {
-    int part = 0;                                  // how many ranges begin inside tile t before ours
-    if (kb > 0)
-      for (int r = q; r > 0 && range_start(r) > (long long)t * nk; --r) ++part;
-    int bad = 0;
-    if (kb > 0 && threadIdx.x == 0) {
-      long long spins = 0;
-      while (__hip_atomic_load(&flags[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < part) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > spin_limit) {                // default ~ seconds: give up loudly rather than hang
-          bad = 1;
-          break;
-        }
-      }
-      if (bad) __hip_atomic_fetch_add(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      // The part that finishes a tile is the last reader of its counter: it puts the 0 back, so that
-      // the NEXT launch finds every counter zero without a memset dispatch in front of it (3-4 us of
-      // fill kernel and launch boundaries -- 10 % of a 34 us N = 1152 launch).  A launch that timed
-      // out may leave counters behind; the host zeroes the buffer again before the handle is reused.
-      if (!bad && ke == nk) __hip_atomic_store(&flags[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  // one lane's atomic on a tile's word, its result made workgroup-uniform through LDS (which is free
+  // between two segments: every wave is past its last fragment read)
+  auto uniform = [&](int v) {
+    __syncthreads();
+    if (threadIdx.x == 0) reinterpret_cast<volatile int *>(lds)[0] = v;
+    __syncthreads();
+    const int r = reinterpret_cast<volatile int *>(lds)[0];
+    __syncthreads();
+    return r;
+  };
+  // slices [kb, ke) of tile slot t; partial tiles live in the workspace, one dense BM x BN slot per range:
+  // never in C, so C needs no alignment and tiles that share cache lines at ragged edges never exchange
+  // data through them
+  auto segment = [&](int t, int kb, int ke, const float *part_in, float *part_out) {
     int tm, tn;
     tile_of(place ? place[t] : t, tm, tn);
-    __syncthreads();   // LDS is reused from segment to segment; orders the loads after the acquire
-    if (kb > 0) {      // (uniform) tell every wave whether the wait succeeded
-      if (threadIdx.x == 0) reinterpret_cast<volatile int *>(lds)[0] = bad;
-      __syncthreads();
-      const int b = reinterpret_cast<volatile int *>(lds)[0];
-      __syncthreads();
-      if (b) return false;
-    }
-    // partial tiles live in the workspace, one dense BM x BN slot per range: never in C, so C needs
-    // no alignment and tiles that share cache lines at ragged edges never exchange data through them
-    const float *part_in = kb > 0 ? parts + (size_t)(q - 1) * BM * BN : nullptr;
-    float *part_out = ke < nk ? parts + (size_t)q * BM * BN : nullptr;
+    __syncthreads();   // LDS is reused from segment to segment; orders the loads after an acquire
     Seg::run(lds, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke, kb == 0 && accumulate != 0, part_in, part_out);
-    if (ke < nk) {
-      // Publish (cdna guide G16, recipe R1): the partial tile was stored write-through (sc1), so there is
-      // nothing for a release fence to write back -- every storing wave drains its stores, the
-      // workgroup meets, ONE lane stores the counter.  (Round 1 used plain stores + an agent release
-      // fence: `buffer_wbl2` on 64 KiB of freshly dirtied lines stalls the publisher ~6 us, which every
-      // wave then waits out at the next segment's barrier.)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0 && !fault)
-        __hip_atomic_store(&flags[t], part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return true;
   };
-  if (t_first == t_last) {                         // the whole range lies in one tile
-    run(t_first, k_first, k_last_end);
+  float *my_slot = parts + (size_t)q * BM * BN;
+  if (t_first == t_last && k_first == 0 && k_last_end == nk) {   // exactly one whole tile
+    segment(t_first, 0, nk, nullptr, nullptr);
     return;
   }
   const bool first_partial = k_first != 0, last_partial = k_last_end != nk;
-  if (last_partial && !run(t_last, 0, k_last_end)) return;                // 1. head of the last tile
+  bool tail_of_last_is_mine = false;
+  if (last_partial) {                                                      // 1. head of the last tile
+    segment(t_last, 0, k_last_end, nullptr, my_slot);
+    // Publish (cdna guide G16, recipe R1): the partial tile was stored write-through (sc1), so there is
+    // nothing for a release fence to write back -- every storing wave drains its stores, the
+    // workgroup meets, ONE lane exchanges the word.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int old = 0;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      old = __hip_atomic_exchange(&flags[t_last], SK_HEAD_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tail_of_last_is_mine = uniform(old) == SK_TAIL_LEFT;
+  }
   for (int t = t_first + (first_partial ? 1 : 0); t <= t_last - (last_partial ? 1 : 0); ++t)
-    if (!run(t, 0, nk)) return;                                          // 2. whole tiles
-  if (first_partial) run(t_first, k_first, nk);                           // 3. rest of the first tile
+    segment(t, 0, nk, nullptr, nullptr);                                   // 2. whole tiles
+  if (first_partial) {                                                     // 3. rest of the first tile
+    int seen = SK_EMPTY;
+    if (threadIdx.x == 0) {
+      __hip_atomic_compare_exchange_strong(&flags[t_first], &seen, SK_TAIL_LEFT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+      if (seen == SK_HEAD_DONE) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // the part that finishes a tile is the last reader of its word: it puts the 0 back, so that the
+        // NEXT launch finds every word zero without a memset dispatch in front of it
+        __hip_atomic_store(&flags[t_first], SK_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (uniform(seen) == SK_HEAD_DONE)
+      segment(t_first, k_first, nk, parts + (size_t)(q - 1) * BM * BN, nullptr);
+    // else: the head is not there yet -- its owner will find our mark and finish the tile itself
+  }
+  if (tail_of_last_is_mine) {                                              // 4. a tail somebody left to us
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // our own write-through stores, read back through L2
+      __hip_atomic_store(&flags[t_last], SK_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    segment(t_last, k_last_end, nk, my_slot, nullptr);
+  }
 }
 
 template <int BM, int BN, bool EDGE, int WTN = 4, int WTM = 4, int KB = BK>
@@ -670,23 +676,21 @@ __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)
 sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                           const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                           int accumulate, int nbm, int nbn, int *__restrict__ flags,
-                          int *__restrict__ err, float *__restrict__ parts, long long spin_limit, int fault,
-                          const int *__restrict__ order, const int *__restrict__ place) {
+                          float *__restrict__ parts, const int *__restrict__ order, const int *__restrict__ place) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  streamk_body<RegSeg<BM, BN, EDGE, WTN, WTM, KB>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn, flags, err,
-                                                   parts, spin_limit, fault, order, place);
+  streamk_body<RegSeg<BM, BN, EDGE, WTN, WTM, KB>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn, flags,
+                                                   parts, order, place);
 }
 
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false>
 __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64)
 sgemm_dma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B,
                          int ldb, float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn,
-                         int *__restrict__ flags, int *__restrict__ err, float *__restrict__ parts,
-                         long long spin_limit, int fault, const int *__restrict__ order,
+                         int *__restrict__ flags, float *__restrict__ parts, const int *__restrict__ order,
                          const int *__restrict__ place) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  streamk_body<DmaSeg<BM, BN, KB, WTM, WTN, NBUF>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn, flags,
-                                                   err, parts, spin_limit, fault, order, place);
+  streamk_body<DmaSeg<BM, BN, KB, WTM, WTN, NBUF, EDGE>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn,
+                                                         flags, parts, order, place);
 }
 
 // ---------------------------------------------------------------------------
@@ -710,7 +714,10 @@ __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)
 sgemm_mfma_splitk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                          const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                          int accumulate, int nbm, int nbn, int S, int *__restrict__ flags,
-                         int *__restrict__ err, float *__restrict__ parts, long long spin_limit) {
+                         int *__restrict__ err, float *__restrict__ parts, long long spin_limit, int fault) {
+  // err: the handle's STICKY error word (host-mapped): a finisher whose wait runs into `spin_limit` adds to it
+  // and stops without storing -- every later mmh_* call on the handle then fails until the word is cleared.
+  // fault != 0 (MMH_OPT_FAULT_INJECT, tests): producers do not announce themselves, so every finisher times out.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int nk = (k + KB - 1) / KB;
   const int T = nbm * nbn;
@@ -726,7 +733,7 @@ sgemm_mfma_splitk_kernel(int m, int n, int k, const float *__restrict__ A, int l
                                                                             tm, tn, kb, ke, false, nullptr, part_out);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave drains (G16 R1)
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0 && !fault)
       __hip_atomic_fetch_add(&flags[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }

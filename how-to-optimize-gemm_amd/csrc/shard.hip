@@ -1,0 +1,262 @@
+// shard.hip -- BASELINE.json config 4, single-process form: C row panels over the devices of this process,
+// B replicated by ONE ncclBroadcast over xGMI, no other collective (mmh_shard_*).  The reference has no analogue
+// (cuda/test_MMult.cpp:24-25: cudaSetDevice(0) only).  Part of libmmult_hip.so (see internal.hpp).
+#include <algorithm>
+#include <chrono>
+#include <new>
+#include <thread>
+
+#include "internal.hpp"
+
+using namespace mmh;
+
+struct mmh_shard {
+  int ngpus = 0;
+  int kernel = MMH_KERNEL_AUTO;
+  int rccl_ranks = 0;                 // ranks of the communicator (0 when ngpus == 1: no RCCL)
+  std::vector<int> devices;
+  std::vector<mmh_context *> ctx;     // one product handle per device (stream-K workspaces etc.)
+  std::vector<hipStream_t> streams;
+  std::vector<DevBuf> a, b, c;        // per device: A panel, B, C panel
+  std::vector<void *> comms;
+};
+
+extern "C" {
+
+int mmh_shard_rows(int m, int nranks, int rank, int *row0, int *rows) {
+  if (m < 0 || nranks <= 0 || rank < 0 || rank >= nranks || !row0 || !rows)
+    return MMH_ERR_INVALID_ARG;
+  // Whole 128-row tiles first, dealt as evenly as possible from rank 0 up;
+  // the ragged tail (m % 128 rows) rides with the last rank that has tiles
+  // (or rank 0 if there are none), so every boundary is tile-aligned.
+  const int tiles = m / 128, tail = m % 128;
+  const int base = tiles / nranks, extra = tiles % nranks;
+  const int my_tiles = base + (rank < extra ? 1 : 0);
+  const int first_tile = rank * base + (rank < extra ? rank : extra);
+  int r0 = first_tile * 128, nr = my_tiles * 128;
+  int last_with_tiles = tiles == 0 ? 0 : (tiles >= nranks ? nranks - 1 : tiles - 1);
+  if (rank == last_with_tiles) nr += tail;
+  if (rank > last_with_tiles) r0 = m;  // empty panels sit at the end
+  *row0 = r0;
+  *rows = nr;
+  return MMH_OK;
+}
+
+// ---- single-process row-panel shard: a handle (BASELINE.json config 4) ----------------------------
+int mmh_shard_destroy(mmh_shard_t sh) {
+  if (!sh) return MMH_OK;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  for (int d = 0; d < (int)sh->devices.size(); ++d) {
+    (void)hipSetDevice(sh->devices[d]);
+    if (d < (int)sh->comms.size() && sh->comms[d]) rccl_api().comm_destroy(sh->comms[d]);
+    if (d < (int)sh->a.size()) { sh->a[d].release(); sh->b[d].release(); sh->c[d].release(); }
+    if (d < (int)sh->streams.size() && sh->streams[d]) (void)hipStreamDestroy(sh->streams[d]);
+    if (d < (int)sh->ctx.size()) destroy_context(sh->ctx[d]);
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  delete sh;
+  return MMH_OK;
+}
+
+int mmh_shard_create(mmh_shard_t *out, int ngpus, const int *devices) {
+  if (!out) return MMH_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (ngpus <= 0 || ngpus > 64) return MMH_ERR_INVALID_ARG;
+  int count = 0;
+  mmh_device_count(&count);
+  if (count < ngpus) {
+    set_last_error("fewer visible devices (" + std::to_string(count) + ") than ngpus (" + std::to_string(ngpus) + ")");
+    return MMH_ERR_NO_DEVICE;
+  }
+  if (ngpus > 1 && !rccl_api().ok) {
+    set_last_error("librccl.so could not be loaded");
+    return MMH_ERR_UNSUPPORTED;
+  }
+  mmh_shard *sh = new (std::nothrow) mmh_shard;
+  if (!sh) return MMH_ERR_ALLOC;
+  sh->ngpus = ngpus;
+  for (int d = 0; d < ngpus; ++d) {
+    const int dev = devices ? devices[d] : d;
+    if (dev < 0 || dev >= count || std::find(sh->devices.begin(), sh->devices.end(), dev) != sh->devices.end()) {
+      delete sh;
+      set_last_error("device list names a device twice or out of range");
+      return MMH_ERR_INVALID_ARG;
+    }
+    sh->devices.push_back(dev);
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  sh->ctx.assign(ngpus, nullptr);
+  sh->streams.assign(ngpus, nullptr);
+  sh->a.resize(ngpus);
+  sh->b.resize(ngpus);
+  sh->c.resize(ngpus);
+  sh->comms.assign(ngpus, nullptr);
+  int rc = MMH_OK;
+  for (int d = 0; d < ngpus && rc == MMH_OK; ++d) {
+    rc = create_context(&sh->ctx[d], sh->devices[d]);
+    if (rc != MMH_OK) break;
+    if (hipSetDevice(sh->devices[d]) != hipSuccess || hipStreamCreate(&sh->streams[d]) != hipSuccess) {
+      set_last_error("hipStreamCreate failed");
+      rc = MMH_ERR_HIP;
+    }
+  }
+  if (rc == MMH_OK && ngpus > 1) {
+    // ONE communicator for the life of the handle (creating it costs far more than any GEMM here)
+    if (rccl_api().comm_init_all(sh->comms.data(), ngpus, sh->devices.data()) != 0) {
+      set_last_error("ncclCommInitAll failed");
+      rc = MMH_ERR_COMM;
+    } else {
+      int ranks = 0;
+      if (rccl_api().comm_count(sh->comms[0], &ranks) == 0) sh->rccl_ranks = ranks;
+    }
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (rc != MMH_OK) {
+    mmh_shard_destroy(sh);
+    return rc;
+  }
+  *out = sh;
+  return MMH_OK;
+}
+
+int mmh_shard_set_kernel(mmh_shard_t sh, int kernel) {
+  if (!sh || !known_kernel(kernel)) return MMH_ERR_INVALID_ARG;
+  sh->kernel = kernel;
+  return MMH_OK;
+}
+
+int mmh_shard_info(mmh_shard_t sh, int *ngpus, int *rccl_ranks) {
+  if (!sh) return MMH_ERR_INVALID_ARG;
+  if (ngpus) *ngpus = sh->ngpus;
+  if (rccl_ranks) *rccl_ranks = sh->rccl_ranks;
+  return MMH_OK;
+}
+
+int mmh_shard_sgemm(mmh_shard_t sh, int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
+                    int ldc, int gemm_reps, float *timings_ms) {
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point t) { return std::chrono::duration<float, std::milli>(clk::now() - t).count(); };
+  if (!sh || gemm_reps < 1) return MMH_ERR_INVALID_ARG;
+  int rc = check_gemm_args(m, n, k, A, lda, B, ldb, C, ldc);
+  if (rc != MMH_OK) return rc;
+  if (timings_ms) timings_ms[0] = timings_ms[1] = timings_ms[2] = timings_ms[3] = 0.f;
+  if (m == 0 || n == 0) return MMH_OK;
+  const int G = sh->ngpus;
+  for (int d = 0; d < G; ++d)
+    if ((rc = check_sticky(sh->ctx[d])) != MMH_OK) return rc;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  struct Restore {
+    int prev;
+    ~Restore() { if (prev >= 0) (void)hipSetDevice(prev); }
+  } restore{prev};
+  std::vector<int> row0(G), rows(G);
+  const size_t kk = k > 0 ? k : 1;
+  for (int d = 0; d < G; ++d) {
+    mmh_shard_rows(m, G, d, &row0[d], &rows[d]);
+    HIP_TRY(hipSetDevice(sh->devices[d]));
+    const size_t r = rows[d] > 0 ? rows[d] : 1;
+    if ((rc = sh->a[d].reserve(r * kk * sizeof(float))) != MMH_OK) return rc;
+    if ((rc = sh->b[d].reserve(kk * n * sizeof(float))) != MMH_OK) return rc;
+    if ((rc = sh->c[d].reserve(r * n * sizeof(float))) != MMH_OK) return rc;
+  }
+  // One host thread per device for the host <-> device phases: a copy from/to pageable memory blocks
+  // its calling thread, and every device has a PCIe link of its own.
+  std::vector<hipError_t> err(G, hipSuccess);
+  auto per_device = [&](auto &&fn) {
+    std::vector<std::thread> pool;
+    for (int d = 0; d < G; ++d)
+      pool.emplace_back([&, d] {
+        hipError_t e = hipSetDevice(sh->devices[d]);
+        if (e == hipSuccess) e = fn(d);
+        if (e == hipSuccess) e = hipStreamSynchronize(sh->streams[d]);
+        err[d] = e;
+      });
+    for (auto &t : pool) t.join();
+    for (int d = 0; d < G; ++d)
+      if (err[d] != hipSuccess) return hip_fail(err[d], "row-panel shard: host <-> device phase");
+    return (int)MMH_OK;
+  };
+  // ---- host -> device: A panels to their owners, B to device 0 only (every device when there is no
+  // communicator, i.e. G == 1) ----
+  auto t = clk::now();
+  if (k > 0) {
+    rc = per_device([&](int d) -> hipError_t {
+      hipError_t e = hipSuccess;
+      if (rows[d] > 0)
+        e = hipMemcpy2DAsync(sh->a[d].p, (size_t)k * 4, A + (size_t)row0[d] * lda, (size_t)lda * 4, (size_t)k * 4,
+                             rows[d], hipMemcpyHostToDevice, sh->streams[d]);
+      if (e == hipSuccess && d == 0)
+        e = hipMemcpy2DAsync(sh->b[0].p, (size_t)n * 4, B, (size_t)ldb * 4, (size_t)n * 4, k, hipMemcpyHostToDevice,
+                             sh->streams[0]);
+      return e;
+    });
+    if (rc != MMH_OK) return rc;
+  }
+  if (timings_ms) timings_ms[0] = ms_since(t);
+  // ---- the one collective: broadcast B from device 0 over xGMI ----
+  t = clk::now();
+  if (G > 1 && k > 0) {
+    RcclApi &api = rccl_api();
+    bool bad = api.group_start() != 0;
+    for (int d = 0; d < G && !bad; ++d) {
+      constexpr int nccl_float = 7;
+      bad = api.broadcast(sh->b[0].p, sh->b[d].p, (size_t)k * n, nccl_float, 0, sh->comms[d], sh->streams[d]) != 0;
+    }
+    if (api.group_end() != 0) bad = true;
+    if (bad) {
+      set_last_error("ncclBroadcast failed");
+      return MMH_ERR_COMM;
+    }
+    for (int d = 0; d < G; ++d) {
+      HIP_TRY(hipSetDevice(sh->devices[d]));
+      HIP_TRY(hipStreamSynchronize(sh->streams[d]));
+    }
+  }
+  if (timings_ms) timings_ms[1] = (G > 1 && k > 0) ? ms_since(t) : 0.f;
+  // ---- independent row-panel GEMMs (gemm_reps back-to-back launches per device: phase time / reps) ----
+  t = clk::now();
+  for (int rep = 0; rep < gemm_reps; ++rep)
+    for (int d = 0; d < G; ++d) {
+      if (rows[d] == 0) continue;
+      HIP_TRY(hipSetDevice(sh->devices[d]));
+      rc = sgemm_on(sh->ctx[d], sh->kernel, rows[d], n, k, static_cast<float *>(sh->a[d].p), k,
+                    static_cast<float *>(sh->b[d].p), n, static_cast<float *>(sh->c[d].p), n, 0, sh->streams[d]);
+      if (rc != MMH_OK) return rc;
+    }
+  for (int d = 0; d < G; ++d) {
+    HIP_TRY(hipSetDevice(sh->devices[d]));
+    HIP_TRY(hipStreamSynchronize(sh->streams[d]));
+  }
+  if (timings_ms) timings_ms[2] = ms_since(t) / gemm_reps;
+  for (int d = 0; d < G; ++d)
+    if ((rc = check_sticky(sh->ctx[d])) != MMH_OK) return rc;
+  // ---- device -> host: disjoint C panels ----
+  t = clk::now();
+  rc = per_device([&](int d) -> hipError_t {
+    if (rows[d] == 0) return hipSuccess;
+    return hipMemcpy2DAsync(C + (size_t)row0[d] * ldc, (size_t)ldc * 4, sh->c[d].p, (size_t)n * 4, (size_t)n * 4,
+                            rows[d], hipMemcpyDeviceToHost, sh->streams[d]);
+  });
+  if (rc != MMH_OK) return rc;
+  if (timings_ms) timings_ms[3] = ms_since(t);
+  return MMH_OK;
+}
+
+// one-shot convenience form: create, run once, destroy (what the round-1 entry point did on every call)
+int mmh_sgemm_sharded(int ngpus, int m, int n, int k, const float *A, int lda, const float *B,
+                      int ldb, float *C, int ldc, int kernel, float *timings_ms) {
+  int rc = check_gemm_args(m, n, k, A, lda, B, ldb, C, ldc);
+  if (rc != MMH_OK) return rc;
+  if (ngpus <= 0 || !known_kernel(kernel)) return MMH_ERR_INVALID_ARG;
+  mmh_shard_t sh = nullptr;
+  if ((rc = mmh_shard_create(&sh, ngpus, nullptr)) != MMH_OK) return rc;
+  rc = mmh_shard_set_kernel(sh, kernel);
+  if (rc == MMH_OK) rc = mmh_shard_sgemm(sh, m, n, k, A, lda, B, ldb, C, ldc, 1, timings_ms);
+  mmh_shard_destroy(sh);
+  return rc;
+}
+
+}  // extern "C"

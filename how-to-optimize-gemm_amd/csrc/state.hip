@@ -1,0 +1,382 @@
+// state.hip -- the handle: life cycle, sticky error, the stream-K / split-K workspaces and who may use
+// them when, the phase-order tables of stream-K launches, and mmh_warm.  Host code only.
+#include <algorithm>
+#include <cstdlib>
+#include <new>
+
+#include "internal.hpp"
+
+namespace mmh {
+
+namespace {
+thread_local std::string g_last_error;
+thread_local std::string g_last_launch;   // which kernel configuration the last sgemm call ran
+}  // namespace
+
+void set_last_error(const std::string &s) { g_last_error = s; }
+void set_last_launch(const std::string &s) { g_last_launch = s; }
+const std::string &last_error_ref() { return g_last_error; }
+const std::string &last_launch_ref() { return g_last_launch; }
+
+int hip_fail(hipError_t e, const char *what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return MMH_ERR_HIP;
+}
+
+int DevBuf::reserve(size_t need, std::vector<void *> *retire_to) {
+  if (need <= bytes) return MMH_OK;
+  if (p) {
+    if (retire_to) retire_to->push_back(p);
+    else (void)hipFree(p);
+  }
+  p = nullptr;
+  bytes = 0;
+  hipError_t e = hipMalloc(&p, need);
+  if (e != hipSuccess) {
+    set_last_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+    return MMH_ERR_ALLOC;
+  }
+  bytes = need;
+  return MMH_OK;
+}
+
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  bytes = 0;
+}
+
+hipError_t DeviceGuard::enter(int device) {
+  hipError_t e = hipGetDevice(&prev);
+  if (e != hipSuccess) return e;
+  if (prev == device) return hipSuccess;
+  e = hipSetDevice(device);
+  switched = e == hipSuccess;
+  return e;
+}
+DeviceGuard::~DeviceGuard() {
+  if (switched) (void)hipSetDevice(prev);
+}
+
+int check_sticky(mmh_context *h) {
+  if (h && h->sticky && *reinterpret_cast<volatile int *>(h->sticky) != 0) {
+    set_last_error("an earlier split-K launch on this handle timed out waiting for its partial tiles: "
+                   "its result is invalid (clear with mmh_set_option(h, MMH_OPT_STREAMK_TIMEOUTS, 0))");
+    return MMH_ERR_HIP;
+  }
+  return MMH_OK;
+}
+
+int check_gemm_args(int m, int n, int k, const void *A, int lda, const void *B, int ldb, const void *C, int ldc) {
+  if (m < 0 || n < 0 || k < 0) return MMH_ERR_INVALID_ARG;
+  if (m == 0 || n == 0) return MMH_OK;
+  if (!C || ldc < n) return MMH_ERR_INVALID_ARG;
+  if (k > 0 && (!A || !B || lda < k || ldb < n)) return MMH_ERR_INVALID_ARG;
+  return MMH_OK;
+}
+
+bool known_kernel(int kernel) { return mmh_kernel_name(kernel) != nullptr; }
+
+// ---------------------------------------------------------------------------------------------------
+// The hand-off workspaces (flags, partial tiles) belong to the handle.  Launches on ONE stream are
+// ordered by the stream.  An eager launch on ANOTHER stream than the previous workspace-using launch is
+// ordered behind it on the DEVICE: an event recorded on the previous stream, waited for by the new one --
+// no host block, and the handle keeps no claim on a stream the caller may have destroyed meanwhile (if
+// the record fails because the stream is gone, everything in flight on the device is waited for instead,
+// once).  A launch that is being CAPTURED into a hipGraph executes nothing now and may not synchronise
+// anything: it is recorded as it is, and whoever replays the graph orders it against other work on the
+// handle (as for any buffer a graph owns) -- include/mmult_hip.h says so.
+// ---------------------------------------------------------------------------------------------------
+int claim_workspaces(mmh_context *ctx, hipStream_t s) {
+  if (capturing(s)) {
+    ctx->ws_captured = true;   // flags / parts are now part of a graph: they may grow, never move
+    return MMH_OK;
+  }
+  if (ctx->ws_used && ctx->ws_stream != s) {
+    if (!ctx->ws_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
+    if (hipEventRecord(ctx->ws_event, ctx->ws_stream) == hipSuccess) {
+      HIP_TRY(hipStreamWaitEvent(s, ctx->ws_event, 0));
+    } else {
+      (void)hipGetLastError();             // the previous stream no longer exists
+      HIP_TRY(hipDeviceSynchronize());
+    }
+  }
+  ctx->ws_stream = s;
+  ctx->ws_used = true;
+  return MMH_OK;
+}
+
+void workspaces_launched(mmh_context *, hipStream_t) {}
+
+// The hand-off words of `tiles` tiles, all zero.  The kernels restore the zeros themselves (the part that
+// finishes a tile resets its word), so the fill runs only when the buffer is new, has grown, or a
+// launch may have died half-way (a sticky error was cleared).
+int prepare_flags(mmh_context *ctx, long tiles, hipStream_t s, int **flags) {
+  const size_t need = (size_t)tiles * sizeof(int);
+  const bool cap = capturing(s);
+  if (need > ctx->flags.bytes) {
+    const int rc = ctx->flags.reserve(std::max(need, (size_t)(256u << 10)), ctx->ws_captured ? &ctx->retired : nullptr);
+    if (rc != MMH_OK) return rc;
+    ctx->flags_dirty = true;
+  }
+  if (ctx->flags_dirty) {
+    HIP_TRY(hipMemsetAsync(ctx->flags.p, 0, ctx->flags.bytes, s));
+    // a fill recorded into a graph does not clean the buffer NOW: stay dirty until an eager launch
+    if (!cap) ctx->flags_dirty = false;
+  }
+  *flags = static_cast<int *>(ctx->flags.p);
+  return MMH_OK;
+}
+
+int reserve_parts(mmh_context *ctx, size_t bytes, hipStream_t, float **parts) {
+  // (a buffer that has to grow while an eager launch on another stream still uses it: claim_workspaces has
+  // already ordered this stream behind that launch, but hipFree does not wait for streams -- retire it)
+  if (bytes > ctx->parts.bytes) {
+    const int rc = ctx->parts.reserve(std::max(bytes, (size_t)(64u << 20)), &ctx->retired);
+    if (rc != MMH_OK) return rc;
+  }
+  *parts = static_cast<float *>(ctx->parts.p);
+  return MMH_OK;
+}
+
+// The two tables of a stream-K launch (streamk_body's `order` and `place`), per shape, cached in the handle.
+// Range r of the G ranges covers units [U r / G, U (r + 1) / G) of the U = tiles x nk (tile slot, K-slice)
+// units; its PHASE is the length of its head (the slices of its last slot it computes first): its whole
+// tiles start that many slice-times into the launch.
+//   order[rho]: the range taken by the workgroup at chip position rho (XCD-contiguous) -- ranges sorted by
+//               phase, so that neighbours on the chip are a slice or two apart in K, not half a tile;
+//   place[j]  : the tile computed in slot j -- dealt out level by level (the o-th slot each range owns),
+//               within a level in phase order: what neighbouring workgroups compute at the same time are
+//               neighbouring tiles of the grouped raster.
+// Any pair of bijections is CORRECT (the chain only needs every workgroup to agree on them); these restore
+// the L2 reuse a plain launch has.  (pure host arithmetic: mmh_streamk_plan exposes it to the CPU tests)
+bool build_sk_tables(long tiles, int nk, int grid, int *order, int *place) {
+  if (tiles <= 0 || nk <= 0 || grid <= 0 || tiles < grid) return false;
+  const long long U = (long long)tiles * nk;
+  auto S = [&](long long r) { return U * r / grid; };
+  std::vector<int> first(grid + 1);
+  std::vector<std::pair<int, int>> by_phase(grid);
+  for (int r = 0; r <= grid; ++r) first[r] = r == grid ? (int)tiles : (int)((S(r) + nk - 1) / nk);
+  for (int r = 0; r < grid; ++r) by_phase[r] = {(int)(S(r + 1) % nk), r};
+  std::sort(by_phase.begin(), by_phase.end());
+  int levels = 0;
+  for (int i = 0; i < grid; ++i) {
+    order[i] = by_phase[i].second;
+    levels = std::max(levels, first[by_phase[i].second + 1] - first[by_phase[i].second]);
+  }
+  int next = 0;
+  for (int o = 0; o < levels; ++o)
+    for (int i = 0; i < grid; ++i) {
+      const int r = by_phase[i].second;
+      if (first[r + 1] - first[r] > o) place[first[r] + o] = next++;
+    }
+  return next == (int)tiles;
+}
+
+// Built on the host at a shape's first launch into PINNED staging memory and uploaded with an asynchronous
+// copy on the launch's own stream: no host synchronisation, and a launch that is being captured into a
+// hipGraph records the same copy as a node of the graph -- its entry is then pinned in the cache (never
+// evicted or rewritten), so a replay finds staging, tables and kernel arguments as they were captured.
+int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place) {
+  *order = *place = nullptr;
+  // Worth it from ~1.8 tiles per workgroup (measured): phase order puts the two workgroups that share a
+  // tile on different XCDs, so the partial tile crosses the fabric instead of being an L2 hit -- with one
+  // tile per workgroup that hand-over is a tenth of the launch (N = 2176 on 128x64 tiles: 139.5 -> 125.0),
+  // with two or more the restored L2 reuse wins (N = 3584 on 64x64 tiles: 138.5 -> 146.0).
+  if (!ctx->sk_order || tiles > (1L << 20) || tiles * 10 < (long)grid * 18) return MMH_OK;
+  const bool cap = capturing(s);
+  for (auto *t : ctx->sk_tables)
+    if (t->tiles == tiles && t->nk == nk && t->grid == grid && t->uploaded) {
+      t->stamp = ++ctx->sk_stamp;
+      if (cap) {
+        // the graph must carry its own upload (the eager one is not ordered against the replay) and the
+        // entry must outlive it
+        t->pinned = true;
+        HIP_TRY(hipMemcpyAsync(t->buf.p, t->host, t->host_ints * sizeof(int), hipMemcpyHostToDevice, s));
+      }
+      *order = static_cast<const int *>(t->buf.p);
+      *place = *order + grid;
+      return MMH_OK;
+    }
+  // a new shape: a free entry, else the least recently used one that no graph points at; beyond 32 live
+  // entries pinned ones only make the cache grow
+  mmh_context::SkTable *slot = nullptr;
+  size_t unpinned = 0;
+  for (auto *t : ctx->sk_tables) unpinned += t->pinned ? 0 : 1;
+  if (unpinned < 32) {
+    slot = new (std::nothrow) mmh_context::SkTable;
+    if (!slot) return MMH_ERR_ALLOC;
+    ctx->sk_tables.push_back(slot);
+  } else {
+    for (auto *t : ctx->sk_tables)
+      if (!t->pinned && (!slot || t->stamp < slot->stamp)) slot = t;
+    // the evicted tables may still be read by a launch in flight: wait for the streams that can hold one
+    if (!cap) {
+      HIP_TRY(hipStreamSynchronize(s));
+      if (ctx->ws_used && ctx->ws_stream != s && hipStreamSynchronize(ctx->ws_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipDeviceSynchronize());
+      }
+    } else {
+      // nothing may synchronise during capture: take a fresh entry instead
+      slot = new (std::nothrow) mmh_context::SkTable;
+      if (!slot) return MMH_ERR_ALLOC;
+      ctx->sk_tables.push_back(slot);
+    }
+  }
+  const size_t ints = (size_t)grid + (size_t)tiles;
+  slot->uploaded = false;
+  slot->tiles = 0;
+  if (ints > slot->host_ints) {
+    if (slot->host) (void)hipHostFree(slot->host);
+    slot->host = nullptr;
+    slot->host_ints = 0;
+    void *hp = nullptr;
+    if (hipHostMalloc(&hp, ints * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return MMH_OK;   // identity tables are always right
+    }
+    slot->host = static_cast<int *>(hp);
+    slot->host_ints = ints;
+  }
+  if (!build_sk_tables(tiles, nk, grid, slot->host, slot->host + grid)) return MMH_OK;   // identity is always right
+  const int rc = slot->buf.reserve(ints * sizeof(int), cap ? &ctx->retired : nullptr);
+  if (rc != MMH_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(slot->buf.p, slot->host, ints * sizeof(int), hipMemcpyHostToDevice, s));
+  slot->host_ints = std::max(slot->host_ints, ints);
+  slot->tiles = tiles;
+  slot->nk = nk;
+  slot->grid = grid;
+  slot->stamp = ++ctx->sk_stamp;
+  slot->uploaded = true;
+  slot->pinned = cap;
+  *order = static_cast<const int *>(slot->buf.p);
+  *place = *order + grid;
+  return MMH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+namespace {
+bool is_gfx950(int device) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+}  // namespace
+
+int create_context(mmh_context **out, int device) {
+  *out = nullptr;
+  int count = 0;
+  mmh_device_count(&count);
+  if (count <= 0 || device < 0 || device >= count) {
+    set_last_error("no such HIP device");
+    return MMH_ERR_NO_DEVICE;
+  }
+  if (!is_gfx950(device)) {
+    set_last_error("device is not gfx950 (this library carries gfx950 code objects only)");
+    return MMH_ERR_NO_DEVICE;
+  }
+  DeviceGuard guard;
+  HIP_TRY(guard.enter(device));
+  mmh_context *ctx = new (std::nothrow) mmh_context;
+  if (!ctx) return MMH_ERR_ALLOC;
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+  if (const char *e = std::getenv("MMH_NO_PIN")) ctx->pin = (*e && *e != '0') ? 0 : 1;   // diagnostic A/B switches
+  if (const char *e = std::getenv("MMH_NO_SK_ORDER")) ctx->sk_order = (*e && *e != '0') ? 0 : 1;
+  // the sticky error word: pinned, mapped host memory (the device adds to it with a system-scope atomic)
+  void *host = nullptr, *dev = nullptr;
+  if (hipHostMalloc(&host, 64, hipHostMallocMapped) == hipSuccess) {
+    memset(host, 0, 64);
+    if (hipHostGetDevicePointer(&dev, host, 0) == hipSuccess) {
+      ctx->sticky = static_cast<int *>(host);
+      ctx->sticky_dev = static_cast<int *>(dev);
+    } else {
+      (void)hipHostFree(host);
+    }
+  }
+  (void)hipGetLastError();   // without the word the opt-in split-K launches are simply not used
+  *out = ctx;
+  // Everything a first launch would otherwise pay for -- code-object load, the > 64 KiB LDS opt-ins, the
+  // residency queries, the stream-K workspaces -- happens HERE, where the reference creates its cuBLAS
+  // handle (cuda/test_MMult.cpp:43-44), not inside the first timed MY_MMult.  MMH_LAZY=1 defers it to
+  // mmh_warm / first use.
+  const char *lazy = std::getenv("MMH_LAZY");
+  if (!(lazy && *lazy && *lazy != '0')) {
+    const int rc = warm_context(ctx);
+    if (rc != MMH_OK) {
+      destroy_context(ctx);
+      *out = nullptr;
+      return rc;
+    }
+  }
+  return MMH_OK;
+}
+
+int warm_context(mmh_context *h) {
+  if (h->warmed) return MMH_OK;
+  // scratch: a 128 K-float buffer every kernel family runs ONE tile of itself on (contents irrelevant)
+  DevBuf scratch;
+  int rc = scratch.reserve((size_t)(1u << 17) * sizeof(float) + (1u << 20));
+  if (rc != MMH_OK) return rc;
+  HIP_TRY(hipMemsetAsync(scratch.p, 0, scratch.bytes, nullptr));
+  float *p = static_cast<float *>(scratch.p);
+  if ((rc = warm_reg(h, p, nullptr)) == MMH_OK && (rc = warm_dma(h, p, nullptr)) == MMH_OK) rc = warm_valu(h, p, nullptr);
+  // the hand-off workspaces at the size the largest stream-K launch of a square sweep needs
+  if (rc == MMH_OK) {
+    int *flags = nullptr;
+    float *parts = nullptr;
+    rc = prepare_flags(h, 1 << 16, nullptr, &flags);
+    if (rc == MMH_OK) rc = reserve_parts(h, (size_t)(64u << 20), nullptr, &parts);
+  }
+  const hipError_t e = hipStreamSynchronize(nullptr);
+  scratch.release();
+  if (rc != MMH_OK) return rc;
+  if (e != hipSuccess) return hip_fail(e, "mmh_warm: hipStreamSynchronize");
+  h->warmed = true;
+  set_last_launch("");
+  return MMH_OK;
+}
+
+void destroy_context(mmh_context *h) {
+  if (!h) return;
+  DeviceGuard guard;
+  (void)guard.enter(h->device);
+  (void)hipDeviceSynchronize();
+  h->a.release();
+  h->b.release();
+  h->c.release();
+  h->flags.release();
+  h->parts.release();
+  h->bt.release();
+  h->qa.release();
+  h->qb.release();
+  h->qc.release();
+  h->qs.release();
+  for (void *p : h->retired) (void)hipFree(p);
+  for (auto *t : h->sk_tables) {
+    t->buf.release();
+    if (t->host) (void)hipHostFree(t->host);
+    delete t;
+  }
+  if (h->pipeline_ready) {
+    for (int i = 0; i < kMaxHostPanels; ++i) {
+      if (h->ev_in[i]) (void)hipEventDestroy(h->ev_in[i]);
+      if (h->ev_run[i]) (void)hipEventDestroy(h->ev_run[i]);
+    }
+    if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+    if (h->hs_in) (void)hipStreamDestroy(h->hs_in);
+    if (h->hs_run) (void)hipStreamDestroy(h->hs_run);
+    if (h->hs_out) (void)hipStreamDestroy(h->hs_out);
+  }
+  if (h->ws_event) (void)hipEventDestroy(h->ws_event);
+  if (h->t0) (void)hipEventDestroy(h->t0);
+  if (h->t1) (void)hipEventDestroy(h->t1);
+  if (h->sticky) (void)hipHostFree(h->sticky);
+  rocblas_release(h->rocblas);
+  hipblaslt_release(h->blaslt);
+  delete h;
+}
+
+}  // namespace mmh

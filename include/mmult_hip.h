@@ -34,7 +34,11 @@
  *                     cuda/test_MMult.cpp:24-25); BASELINE.json config 4.
  *   mmh_igemm_s8      no reference code (aarch64-int8/ is an empty submodule,
  *                     README.md:71-85); BASELINE.json config 5.
- *   mmh_sgemm_rocblas vendor comparator, cuda/MMult_cuBLAS_1.cpp:11-19.
+ *   mmh_sgemm_rocblas vendor comparator, cuda/MMult_cuBLAS_1.cpp:11-19 (cublasSgemm -> rocblas_sgemm).
+ *   mmh_sgemm_hipblaslt  the second vendor comparator, cuda/MMult_cuBLAS_2.cpp:11-26 (cublasGemmEx with
+ *                     fp32 compute -> hipblasLtMatmul, HIPBLAS_COMPUTE_32F).
+ *   mmh_warm          what cublasCreate does for the reference before its timed loop
+ *                     (cuda/test_MMult.cpp:43-44): every one-off a first launch would pay.
  *   mmh_probe_*       peak probes, the idea of aarch64/gflops_benchmark/main.c:19-25
  *                     and vulkan/benchmark/{gflops_fmla,gmem_bandwidth}.cpp.
  *
@@ -119,33 +123,55 @@ int mmh_device_count(int *count);
 /* name must hold >= 256 bytes; cu_count / clock_mhz may be NULL. */
 int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
 
-/* A handle owns device workspaces (host-flavour staging, stream-K hand-off flags and partial-tile
- * slots, int8 / quantisation scratch) that consecutive calls reuse: use one handle per host thread.
- * Calls on ONE stream through one handle are ordered by the stream (as cublasHandle_t with
- * cublasSetStream); a stream-K / split-K launch on ANOTHER stream than the previous one first waits
- * for that stream (so the hand-off workspaces are never in use twice), which costs the overlap --
- * use one handle per stream that should run concurrently.  A launch captured into a hipGraph is
- * recorded without that wait (nothing may synchronise during capture; a captured stream-K launch is
- * recorded with plain-order ranges -- it must not point into the handle's per-shape table cache,
- * MMH_OPT_STREAMK_ORDER): a graph that contains stream-K launches owns the handle's workspaces while it
- * runs, like any buffer it was captured with.  Every entry point runs on the handle's device and restores
- * the caller's current device before it returns. */
+/* A handle owns device workspaces (host-flavour staging, stream-K partial-tile slots and hand-off words,
+ * int8 / quantisation scratch) that consecutive calls reuse: use one handle per host thread.
+ *
+ * mmh_create also WARMS the handle (unless the environment says MMH_LAZY=1): every kernel MMH_KERNEL_AUTO can
+ * pick is run once on one tile of scratch -- code objects loaded, > 64 KiB LDS opted into, residency queried --
+ * and the stream-K workspaces are allocated, so that the first mmh_sgemm of a process is a launch and nothing
+ * else (the reference creates its cuBLAS handle before its timed loop for the same reason,
+ * cuda/test_MMult.cpp:43-44).  mmh_warm does the same for a lazily created handle; it is idempotent.
+ *
+ * Streams.  Calls on ONE stream through one handle are ordered by the stream (as cublasHandle_t with
+ * cublasSetStream).  A stream-K / split-K launch on ANOTHER stream than the handle's previous one is ordered
+ * behind it on the device (an event, no host block) so that the workspaces are never in use twice -- which
+ * costs the overlap: use one handle per stream that should run concurrently.  The handle keeps no claim on a
+ * stream after the call returns: destroying a stream the handle has launched on is fine.
+ *
+ * Progress guarantee.  Stream-K launches are persistent grids whose workgroups hand partial tiles to each
+ * other, but NO workgroup ever waits for another (sgemm_mfma.hpp, K2p: the hand-over is an atomic exchange;
+ * whoever arrives second finishes the tile).  A launch therefore completes with any number of its workgroups
+ * resident, in any dispatch order: several handles may run stream-K launches on concurrent streams, next to
+ * RCCL kernels or anything else that occupies CUs -- co-residency changes the speed, never the result, and
+ * there is no time-out.  (Only the OPT-IN split-K kernels wait, bounded, and raise the sticky error below.)
+ *
+ * hipGraphs.  After one eager call of a shape, launches capture into a graph: a captured stream-K launch
+ * records the upload of its phase-order tables as a node of the graph and pins them, and from the first
+ * capture on the handle never frees or moves a workspace a graph may point at (a buffer that must grow is
+ * replaced, the old one lives as long as the handle).  A graph that contains stream-K launches owns the
+ * handle's workspaces while it RUNS, like any buffer it was captured with: do not run the same handle
+ * eagerly on another stream at the same time.  Every entry point runs on the handle's device and restores the
+ * caller's current device before it returns. */
 int mmh_create(mmh_handle_t *handle, int device);
 int mmh_destroy(mmh_handle_t handle);
+int mmh_warm(mmh_handle_t handle);
 int mmh_set_kernel(mmh_handle_t handle, int kernel);
 int mmh_get_kernel(mmh_handle_t handle, int *kernel);
-/* Name of a kernel variant ("MMult_hip_mfma", ...), NULL if unknown. */
+/* Name of a kernel variant ("MMult_hip_mfma", ...), NULL if unknown; and the id of a short name ("mfma",
+ * "auto", "mfma_128x64_dma", ...: the name without its "MMult_hip_" prefix), -1 if unknown. */
 const char *mmh_kernel_name(int kernel);
+int mmh_kernel_id(const char *short_name);
 
 /* Options.  MMH_OPT_STREAMK (default 1): let MMH_KERNEL_MFMA/AUTO run tile counts
  * that do not divide the chip as ONE persistent chained stream-K launch (bit-identical
  * results) -- from 128x128 tiles up whenever the count is ragged, for smaller tiles when the plain
  * launch would leave a round more than 7 % empty; 0 never, 2 whenever the count is ragged.
- * MMH_OPT_STREAMK_TIMEOUTS: the handle's STICKY error.  A stream-K / split-K hand-off wait that
- * times out (never seen outside fault injection) adds to a host-visible word and the waiting
- * workgroup stops; from then on EVERY mmh_* call on the handle returns MMH_ERR_HIP -- the launch
- * that timed out produced an invalid result and nobody has to poll to learn it.  get: synchronises
- * the device and returns the count; set 0: synchronises and clears it. */
+ * MMH_OPT_STREAMK_TIMEOUTS: the handle's STICKY error.  Stream-K launches cannot time out (their hand-over is
+ * wait-free); the finisher of an OPT-IN split-K tile waits, bounded, for its partial tiles, and a wait that
+ * times out (never seen outside fault injection) adds to a host-visible word and stops without storing; from
+ * then on EVERY mmh_* call on the handle returns MMH_ERR_HIP -- the launch that timed out produced an invalid
+ * result and nobody has to poll to learn it.  get: synchronises the device and returns the count; set 0:
+ * synchronises and clears it. */
 #define MMH_OPT_STREAMK 1
 #define MMH_OPT_STREAMK_TIMEOUTS 2
 /* MMH_OPT_IGEMM_MODE: 0 (default) B read in place (LDS-DMA of its row-major slices, fragments by
@@ -162,9 +188,9 @@ const char *mmh_kernel_name(int kernel);
 /* MMH_OPT_HOST_PANELS (default -1 = automatic): row panels of the host-pointer flavour's copy/compute
  * pipeline (mmh_sgemm_host); 0 or 1 = the plain copy-in, GEMM, copy-out sequence; 2..16 panels. */
 #define MMH_OPT_HOST_PANELS 5
-/* Test hooks.  MMH_OPT_STREAMK_SPIN_LIMIT: hand-off wait bound in units of 1024 polls (default
- * 65536, seconds).  MMH_OPT_FAULT_INJECT (default 0): 1 = stream-K producers do not publish their
- * partial tiles, so that every dependent wait times out and the sticky error path can be exercised.
+/* Test hooks.  MMH_OPT_STREAMK_SPIN_LIMIT: bound of the split-K finisher's wait in units of 1024 polls (default
+ * 65536, seconds).  MMH_OPT_FAULT_INJECT (default 0): 1 = split-K producers do not announce their
+ * partial tiles, so that every finisher times out and the sticky error path can be exercised.
  * (Diagnostic environment switch, read at mmh_create: MMH_NO_PIN=1 -- persistent launches then do not
  * ask for 160 KiB / w of LDS to pin w workgroups per CU.) */
 #define MMH_OPT_STREAMK_SPIN_LIMIT 6
@@ -177,6 +203,10 @@ const char *mmh_kernel_name(int kernel);
  * in L2 as a plain launch does (hit rate 22-35 % -> 75 %).  Same chain, same bits; 0 = ranges in plain
  * order (the A/B baseline; environment MMH_NO_SK_ORDER=1 does the same at mmh_create). */
 #define MMH_OPT_STREAMK_ORDER 8
+/* MMH_OPT_DMA_EDGE (default 2): which shapes MMH_KERNEL_AUTO and the *_DMA ids may run on the GUARDED LDS-DMA
+ * tiles (sgemm_dma.hpp): 0 none (ragged or unaligned shapes run the register-staged tiles, the round-2
+ * behaviour), 1 any m, n, k whose A and B rows are 16-byte aligned, 2 any 4-byte aligned operands. */
+#define MMH_OPT_DMA_EDGE 9
 int mmh_set_option(mmh_handle_t handle, int option, int value);
 /* The two tables of a phase-ordered stream-K launch (MMH_OPT_STREAMK_ORDER) for `tiles` tile slots of `nk`
  * K-slices on `grid` persistent workgroups, computed on the host (no device needed): order[grid] = the range
@@ -236,6 +266,11 @@ int mmh_qgemm_f32(mmh_handle_t handle, int m, int n, int k, const float *dA, int
  * cannot be loaded. */
 int mmh_sgemm_rocblas(mmh_handle_t handle, int m, int n, int k, const float *dA, int lda,
                       const float *dB, int ldb, float *dC, int ldc, void *stream);
+/* The second vendor comparator (hipBLASLt, fp32 compute, same swapped-operand trick; the algorithm the
+ * library's own heuristic ranks first, looked up once per shape and cached in the handle; 64 MiB of
+ * workspace offered).  MMH_ERR_UNSUPPORTED if libhipblaslt cannot be loaded or offers no fp32 algorithm. */
+int mmh_sgemm_hipblaslt(mmh_handle_t handle, int m, int n, int k, const float *dA, int lda,
+                        const float *dB, int ldb, float *dC, int ldc, void *stream);
 
 /* Multi-GPU row-panel shard ---------------------------------------------- */
 /* Rows [*row0, *row0 + *rows) of C (and A) owned by `rank` of `nranks`:
