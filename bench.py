@@ -33,13 +33,16 @@ Cold vs sustained.  The reference times NREPEATS = 20 launches with no warm-up
 (cuda/test_MMult.cpp:98-118).  An idle MI355X starts a launch train below its
 sustained clock, so that convention and the contract's (W warm-ups, K timed
 steps at steady state) give different numbers; both are reported:
-  * the run opens with a per-launch trace of the first launches (up to 400, about half a second)
-    (mmh_trace_sgemm, one hipEvent pair each) -> `cold`: launch #1 (code-object
-    load, attribute calls), the mean of launches 2..21 (= the reference
-    convention without the one-off), and where the ramp ends;
-  * `value` / `ms_per_step` = K steps after that trace and W further warm-ups
-    (`warmup` echoes W as the contract asks; `untimed_launches` is everything
-    that ran before the timed region).
+  * the run opens with a per-launch trace of the process's first launches (`ramp_launches` of them: up to 400,
+    about half a second; --ramp 0 switches it off, --ramp N bounds it) (mmh_trace_sgemm, one hipEvent pair
+    each) -> `cold`: launch #1 (nothing but a launch since mmh_create warms the handle), the mean of launches
+    1..20 (= the reference convention) and 2..21, and where the ramp ends;
+  * then W warm-up steps and K timed steps: `warmup` = W exactly, `ramp_launches` = the traced launches in
+    front of them, `untimed_launches` = their sum.  With --ramp 0 the W warm-ups are the only untimed
+    launches of the process.
+  --sweep adds the reference's square sweep (cuda/parameters.h:5-7: 1024 .. 4096 step 128, plus 8192 and
+  16384) under the same sharding as the headline workload -> `extras.sweep_gflops_sharded`: the north star's
+  "GFLOPS on the square-N sweep at 1/2/4/8 GPUs".
 """
 from __future__ import annotations
 
@@ -75,6 +78,9 @@ def parse_args():
     ap.add_argument("--force-shard", action="store_true",
                     help="run the multi-GPU code path (process group, broadcast, all_reduce) even with one rank")
     ap.add_argument("--ramp-csv", default="", help="write the per-launch clock-ramp trace to this CSV")
+    ap.add_argument("--ramp", type=int, default=RAMP, help="per-launch traced launches that open the run (0: none)")
+    ap.add_argument("--sweep", action="store_true",
+                    help="also run the reference's square sweep under this run's sharding (extras.sweep_gflops_sharded)")
     return ap.parse_args()
 
 
@@ -250,7 +256,7 @@ def main():
         m = n
         row0, rows = 0, n
         workload = f"sgemm fp32 square N={n}, 1xMI355X, kernel={args.kernel} (BASELINE configs[2])"
-        parallelism, scaling = "single", "weak"
+        parallelism, scaling = "single", "strong"      # total work is fixed for every --gpus N (see N > 1 below)
     else:
         n = args.n or 16384
         m = n
@@ -274,9 +280,10 @@ def main():
     # (before the broadcast on purpose: B's contents do not matter for timing, and the chip is as
     # cold here as it will ever be)
     trace = []
-    if rows:
-        trace = mm.trace_sgemm(rows, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, count=25, stream=stream)
-        more = max(0, min(RAMP - 25, int(RAMP_SECONDS / (max(trace[-1], 1e-3) * 1e-3)) - 25))
+    if rows and args.ramp > 0:
+        trace = mm.trace_sgemm(rows, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, count=min(25, args.ramp),
+                               stream=stream)
+        more = max(0, min(args.ramp - 25, int(RAMP_SECONDS / (max(trace[-1], 1e-3) * 1e-3)) - 25))
         if more:
             trace += mm.trace_sgemm(rows, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, count=more,
                                     stream=stream)
@@ -356,6 +363,32 @@ def main():
     kern_ms = mm.time_sgemm(rows, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n,
                             warmup=1, reps=args.steps, stream=stream) if rows else 0.0
     launched = H.last_launch()
+
+    # --sweep: the reference's square sweep under this run's sharding (row panels over the ranks, B replicated
+    # before the timed launches -- data placement, as above).  Every rank times its own panel with a hipEvent pair
+    # around K launches after a barrier; the slowest rank sets the rate.
+    sweep_sharded = None
+    if args.sweep:
+        sweep_sharded = {}
+        from how_to_optimize_gemm_amd.shard import RowPanelShard
+        sizes = [p for p in list(range(1024, 4097, 128)) + [8192, 16384] if p <= n]
+        for p in sizes:
+            shp = RowPanelShard(p, p, p, rank, world)
+            pa = a[:max(shp.rows, 1), :p].contiguous()
+            pb = b[:p, :p].contiguous()
+            pc = torch.empty((max(shp.rows, 1), p), device=dev)
+            if dist:
+                dist.barrier()
+            ms = 0.0
+            if shp.rows:
+                ms = mm.time_sgemm(shp.rows, p, p, pa.data_ptr(), p, pb.data_ptr(), p, pc.data_ptr(), p, warmup=args.warmup,
+                                   reps=args.steps, stream=stream)
+            if dist:
+                t = torch.tensor([ms], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = float(t.item())
+            sweep_sharded[str(p)] = round(2.0 * p ** 3 * 1e-9 / (ms * 1e-3), 1) if ms else None
+            del pa, pb, pc
     # Correctness of what was just timed, outside the timed region:
     #  (1) the FULL C of the timed kernel is bit-equal to the plain one-workgroup-per-128x128-tile
     #      launch (mfma_tiles) -- the configuration the parity tests pin to the oracle element by
@@ -400,7 +433,7 @@ def main():
             "data": "synthetic uniform [-1,1) fp32, seeded on device",
             "config": {"workload": workload, "m": m, "n": n, "k": n, "kernel": H.kernel_name(mm.get_kernel()),
                        "parallelism": parallelism, "rows_per_rank": rows},
-            "untimed_launches": len(trace) + args.warmup,
+            "ramp_launches": len(trace), "untimed_launches": len(trace) + args.warmup,
             "cold": {
                 "what": f"per-launch hipEvent trace of this process's first {len(trace)} launches (rank 0's panel)",
                 "launch_1_ms": round(trace[0], 4) if trace else None,
@@ -435,6 +468,12 @@ def main():
             elif streamed_error:
                 out["streamed_b_error"] = streamed_error
             out["streamed_equals_plain"] = bool(streamed_equal)
+        if sweep_sharded is not None:
+            out["sweep_gflops_sharded"] = {"what": f"square sweep, C row panels over {world} rank(s), kernel-only "
+                                                   f"(B replicated beforehand), max over ranks of the mean of {args.steps} launches",
+                                           "pct_of_peak_at_4096": (round(100.0 * sweep_sharded["4096"] / (world * PEAK_FP32_MFMA_TFLOPS * 1e3), 2)
+                                                                   if sweep_sharded.get("4096") else None),
+                                           "gflops": sweep_sharded}
         if not sharded and not args.no_extras:
             extras = {}
             try:
@@ -451,31 +490,10 @@ def main():
                             continue
                         pa, pb = a[:p, :p].contiguous(), b[:p, :p].contiguous()
                         pc = torch.empty((p, p), device=dev)
-                        if kern == "hipblaslt":      # the second vendor comparator: torch.mm, TF32 off
-                            try:
-                                torch.backends.cuda.matmul.allow_tf32 = False
-                                for _ in range(3):
-                                    torch.mm(pa, pb, out=pc)
-                                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                                e0.record()
-                                for _ in range(20):
-                                    torch.mm(pa, pb, out=pc)
-                                e1.record()
-                                torch.cuda.synchronize()
-                                ms = e0.elapsed_time(e1) / 20
-                            except Exception:
-                                continue
-                        elif kern == "rocblas":
-                            try:
-                                for _ in range(3):
-                                    mm.matmul_rocblas(pa, pb, out=pc)
-                                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                                e0.record()
-                                for _ in range(20):
-                                    mm.matmul_rocblas(pa, pb, out=pc)
-                                e1.record()
-                                torch.cuda.synchronize()
-                                ms = e0.elapsed_time(e1) / 20
+                        if kern in ("rocblas", "hipblaslt"):   # the vendor comparators, behind the same C ABI
+                            try:                                # (cuda/MMult_cuBLAS_1.cpp, cuda/MMult_cuBLAS_2.cpp)
+                                ms = mm.time_comparator(kern, p, p, p, pa.data_ptr(), p, pb.data_ptr(), p, pc.data_ptr(), p,
+                                                        warmup=3, reps=20, stream=stream)
                             except H.MMultError:
                                 continue
                         else:

@@ -46,7 +46,7 @@ EXPORTS = [
     "mmh_sgemm_rocblas", "mmh_sgemm_hipblaslt", "mmh_shard_rows",
     "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm",
     "mmh_rccl_version",
-    "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
+    "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_time_comparator", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
     "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy", "mmh_probe_hbm_read", "mmh_probe_lds_read", "mmh_streamk_plan",
 ]
 
@@ -167,6 +167,7 @@ def lib() -> C.CDLL:
     L.mmh_shard_sgemm.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, fp]
     L.mmh_rccl_version.argtypes = [ip]
     L.mmh_time_sgemm.argtypes = gemm + [C.c_int, C.c_int, vp, fp]
+    L.mmh_time_comparator.argtypes = [vp, C.c_int] + gemm[1:] + [C.c_int, C.c_int, vp, fp]
     L.mmh_trace_sgemm.argtypes = gemm + [C.c_int, vp, fp]
     L.mmh_probe_hbm_read.argtypes = [vp, C.c_size_t, fp]
     L.mmh_probe_lds_read.argtypes = [vp, C.c_int, fp]
@@ -509,6 +510,13 @@ class MMult:
         ms = C.c_float(0)
         _check(lib().mmh_time_sgemm(self._h, m, n, k, dA, lda, dB, ldb, dC, ldc, warmup, reps, stream,
                                     C.byref(ms)), "mmh_time_sgemm")
+        return ms.value
+
+    def time_comparator(self, which: str, m, n, k, dA, lda, dB, ldb, dC, ldc, warmup=1, reps=20, stream: int = 0) -> float:
+        """time_sgemm for a vendor comparator ("rocblas" / "hipblaslt"): calls issued from C, one event pair."""
+        ms = C.c_float(0)
+        _check(lib().mmh_time_comparator(self._h, {"rocblas": 1, "hipblaslt": 2}[which], m, n, k, dA, lda, dB, ldb, dC, ldc,
+                                         warmup, reps, stream, C.byref(ms)), "mmh_time_comparator")
         return ms.value
 
     def trace_sgemm(self, m, n, k, dA, lda, dB, ldb, dC, ldc, count=400, stream: int = 0):

@@ -275,6 +275,38 @@ int mmh_sgemm_hipblaslt(mmh_handle_t h, int m, int n, int k, const float *dA, in
   return hipblaslt_sgemm_rowmajor(&h->blaslt, m, n, k, dA, lda, dB, ldb, dC, ldc, stream);
 }
 
+// mmh_time_sgemm for the comparators: the same event pair around `reps` back-to-back calls issued from C
+int mmh_time_comparator(mmh_handle_t h, int which, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
+                        float *dC, int ldc, int warmup, int reps, void *stream, float *ms_per_call) {
+  if (!h || reps <= 0 || warmup < 0 || !ms_per_call || (which != MMH_COMPARATOR_ROCBLAS && which != MMH_COMPARATOR_HIPBLASLT))
+    return MMH_ERR_INVALID_ARG;
+  int rc = check_gemm_args(m, n, k, dA, lda, dB, ldb, dC, ldc);
+  if (rc != MMH_OK || m == 0 || n == 0 || k == 0) return rc != MMH_OK ? rc : MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto call = [&] {
+    return which == MMH_COMPARATOR_ROCBLAS ? rocblas_sgemm_rowmajor(&h->rocblas, m, n, k, dA, lda, dB, ldb, dC, ldc, stream)
+                                           : hipblaslt_sgemm_rowmajor(&h->blaslt, m, n, k, dA, lda, dB, ldb, dC, ldc, stream);
+  };
+  for (int i = 0; i < warmup; ++i)
+    if ((rc = call()) != MMH_OK) return rc;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  HIP_TRY(hipEventCreate(&t0));
+  hipError_t e = hipEventCreate(&t1);
+  if (e == hipSuccess) e = hipEventRecord(t0, s);
+  for (int i = 0; i < reps && rc == MMH_OK && e == hipSuccess; ++i) rc = call();
+  if (e == hipSuccess) e = hipEventRecord(t1, s);
+  if (e == hipSuccess) e = hipEventSynchronize(t1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, t0, t1);
+  (void)hipEventDestroy(t0);
+  if (t1) (void)hipEventDestroy(t1);
+  if (rc != MMH_OK) return rc;
+  if (e != hipSuccess) return hip_fail(e, "mmh_time_comparator");
+  *ms_per_call = ms / reps;
+  return MMH_OK;
+}
+
 int mmh_rccl_version(int *version) {
   if (!version) return MMH_ERR_INVALID_ARG;
   *version = 0;

@@ -14,8 +14,8 @@
 // C = A*B, returns the device milliseconds of the GEMM -- _Z8MY_MMultiiiPfS_S_).
 //
 // Kernel variant: environment variable MMULT_KERNEL = auto (default) | mfma | mfma256 |
-// mfma_256x256 | mfma_128x64 | mfma_64x64 | mfma_pipe | mfma_simple | valu | naive (the run-time form of the reference's
-// `NEW := MMult_xxx`, cuda/makefile:3).  MMULT_HOST_PANELS = -1 (default, automatic) | 0 (plain staged
+// mfma_256x256 | mfma_128x64 | mfma_64x64 | mfma_*_dma | mfma_pipe | mfma_simple | valu | naive ... -- any short name
+// mmh_kernel_id knows (the run-time form of the reference's `NEW := MMult_xxx`, cuda/makefile:3).  MMULT_HOST_PANELS = -1 (default, automatic) | 0 (plain staged
 // form) | 2..16: row panels of mmh_sgemm_host's copy/compute pipeline.
 #include <cstdio>
 #include <cstdlib>
@@ -28,14 +28,8 @@ namespace {
 int kernel_from_env() {
   const char *e = std::getenv("MMULT_KERNEL");
   if (!e || !*e) return MMH_KERNEL_AUTO;
-  struct { const char *name; int id; } table[] = {
-      {"mfma", MMH_KERNEL_MFMA}, {"mfma256", MMH_KERNEL_MFMA_256}, {"mfma_64x64", MMH_KERNEL_MFMA_64X64}, {"mfma_256x256", MMH_KERNEL_MFMA_256X256}, {"mfma_128x64", MMH_KERNEL_MFMA_128X64}, {"mfma_pipe", MMH_KERNEL_MFMA_PIPE},
-      {"mfma_simple", MMH_KERNEL_MFMA_SIMPLE}, {"valu", MMH_KERNEL_VALU}, {"naive", MMH_KERNEL_NAIVE},
-      {"valu_128x128", MMH_KERNEL_VALU_128X128}, {"valu_64x64", MMH_KERNEL_VALU_64X64}, {"mfma_tiles", MMH_KERNEL_MFMA_TILES},
-      {"mfma_splitk", MMH_KERNEL_MFMA_SPLITK}, {"mfma_splitk_128x64", MMH_KERNEL_MFMA_SPLITK_128X64},
-      {"auto", MMH_KERNEL_AUTO}};
-  for (auto &t : table)
-    if (!std::strcmp(e, t.name)) return t.id;
+  const int id = mmh_kernel_id(e);   // the library's own table of short names
+  if (id >= 0) return id;
   std::fprintf(stderr, "MMULT_KERNEL=%s is not a kernel variant\n", e);
   std::exit(EXIT_FAILURE);
 }

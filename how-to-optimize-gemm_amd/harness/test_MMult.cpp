@@ -18,8 +18,10 @@
 // (environment variable NAME or --NAME=value), defaults from parameters.h:
 //
 //   PFIRST PLAST PINC M N K NREPEATS LDA LDB LDC   sweep shape
-//   KERNEL=auto|mfma|mfma256|mfma_256x256|mfma_128x64|mfma_64x64|mfma_pipe|mfma_simple|valu|valu_128x128|
-//          valu_64x64|naive|rocblas|mfma_splitk|mfma_splitk_128x64   (the last two: opt-in split-K)
+//   KERNEL=auto|mfma|mfma256|mfma_256x256|mfma_128x64|mfma_64x64|mfma_64x64_dma|mfma_128x64_dma|mfma_128x128_dma|
+//          mfma_pipe|mfma_simple|valu|valu_128x128|valu_64x64|naive|mfma_splitk|mfma_splitk_128x64 (the last two:
+//          opt-in split-K) -- any short name mmh_kernel_id knows -- or rocblas | hipblaslt, the vendor comparators
+//          (cuda/MMult_cuBLAS_1.cpp, cuda/MMult_cuBLAS_2.cpp)
 //   SPLITK=<n>                 MMH_OPT_SPLITK for KERNEL=auto (0 off, 1 auto, 2..16 parts)
 //   FLAVOUR=device|host|cpu|sharded
 //                                device: C=A*B on device pointers (cuda/ flavour)
@@ -95,23 +97,14 @@ void opt_str(int argc, char **argv, const char *name, std::string &dst) {
   if (const char *v = lookup(argc, argv, name)) dst = v;
 }
 
+// KERNEL=<short name>: the library's own table (mmh_kernel_id), plus the two vendor comparators the
+// reference links as MMult_cuBLAS_1 / MMult_cuBLAS_2 (cuda/makefile:1)
+constexpr int kRocblas = -100, kHipblaslt = -101;
 int kernel_id(const std::string &s) {
-  if (s == "mfma") return MMH_KERNEL_MFMA;
-  if (s == "auto") return MMH_KERNEL_AUTO;
-  if (s == "mfma256") return MMH_KERNEL_MFMA_256;
-  if (s == "mfma_64x64") return MMH_KERNEL_MFMA_64X64;
-  if (s == "mfma_256x256") return MMH_KERNEL_MFMA_256X256;
-  if (s == "mfma_128x64") return MMH_KERNEL_MFMA_128X64;
-  if (s == "mfma_pipe") return MMH_KERNEL_MFMA_PIPE;
-  if (s == "mfma_simple") return MMH_KERNEL_MFMA_SIMPLE;
-  if (s == "valu") return MMH_KERNEL_VALU;
-  if (s == "valu_128x128") return MMH_KERNEL_VALU_128X128;
-  if (s == "valu_64x64") return MMH_KERNEL_VALU_64X64;
-  if (s == "mfma_splitk") return MMH_KERNEL_MFMA_SPLITK;
-  if (s == "mfma_splitk_128x64") return MMH_KERNEL_MFMA_SPLITK_128X64;
-  if (s == "mfma_tiles") return MMH_KERNEL_MFMA_TILES;
-  if (s == "naive") return MMH_KERNEL_NAIVE;
-  if (s == "rocblas") return -100;
+  if (s == "rocblas") return kRocblas;
+  if (s == "hipblaslt") return kHipblaslt;
+  const int id = mmh_kernel_id(s.c_str());
+  if (id >= 0) return id;
   std::fprintf(stderr, "unknown KERNEL=%s\n", s.c_str());
   std::exit(EXIT_FAILURE);
 }
@@ -275,8 +268,10 @@ int main(int argc, char **argv) {
       HIP_CHECK(hipMemcpy(d_A, a.data(), a.size() * sizeof(float), hipMemcpyHostToDevice));
       HIP_CHECK(hipMemcpy(d_B, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
       auto call = [&] {
-        if (kid == -100)
+        if (kid == kRocblas)
           MMH_CHECK(mmh_sgemm_rocblas(handle, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, nullptr));
+        else if (kid == kHipblaslt)
+          MMH_CHECK(mmh_sgemm_hipblaslt(handle, m, n, k, d_A, lda, d_B, ldb, d_C, ldc, nullptr));
         else
           MY_MMult(handle, m, n, k, d_A, lda, d_B, ldb, d_C, ldc);
       };

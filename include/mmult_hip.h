@@ -314,6 +314,14 @@ int mmh_time_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, in
                    const float *dB, int ldb, float *dC, int ldc, int warmup, int reps,
                    void *stream, float *ms_per_call);
 
+/* The same measurement for a vendor comparator (the calls are issued from C, like mmh_time_sgemm's, so that
+ * a 20 us kernel is not timed through an interpreter's call overhead). */
+#define MMH_COMPARATOR_ROCBLAS 1
+#define MMH_COMPARATOR_HIPBLASLT 2
+int mmh_time_comparator(mmh_handle_t handle, int which, int m, int n, int k, const float *dA, int lda,
+                        const float *dB, int ldb, float *dC, int ldc, int warmup, int reps, void *stream,
+                        float *ms_per_call);
+
 /* Per-launch milliseconds of `count` (<= 4096) back-to-back mmh_sgemm launches, one hipEvent pair
  * each: the clock-ramp trace (profiles/r02_clock_ramp.csv). */
 int mmh_trace_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, int lda,

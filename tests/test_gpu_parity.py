@@ -107,7 +107,8 @@ def test_lds_dma_small_tile_kernel_is_the_same_chain(mm, oracle, kernel):
     """K2L (sgemm_dma.hpp): both operands by LDS-DMA into a ring of K-slice buffers, A as a ROW-major
     image read with ds_read2st64_b32.  Same MFMA, same k order -> the oracle's bits, for one slice, for
     slice counts on every phase of the ring (1 .. 7, 16, 18 slices of 64), overwrite and accumulate;
-    shapes it does not take (ragged, k not a multiple of 64) fall back to the register-staged kernel."""
+    ragged shapes run the GUARDED instantiation of the same tile (round 3), or -- with MMH_OPT_DMA_EDGE = 0 --
+    fall back to the register-staged kernel as they did in round 2."""
     import torch
     import how_to_optimize_gemm_amd as H
     mm.set_kernel(kernel)
@@ -136,11 +137,18 @@ def test_lds_dma_small_tile_kernel_is_the_same_chain(mm, oracle, kernel):
     assert "LDS-DMA" in H.last_launch()
     assert np.array_equal(cbuf[:, :384].cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
     assert torch.isnan(cbuf[:, 384:]).all()
-    for (m, n, k) in [(130, 129, 37), (256, 256, 100), (1000, 1000, 1000)]:     # not taken: falls back, same bits
+    for (m, n, k) in [(130, 129, 37), (256, 256, 100), (1000, 1000, 1000)]:     # ragged: the guarded DMA tile, same bits
         a, b = oracle.harness_inputs(m, n, k, seed=m)
         got = mm.matmul(dev(a), dev(b)).cpu().numpy()
-        assert "LDS-DMA" not in H.last_launch()
+        assert "LDS-DMA" in H.last_launch() and "guarded" in H.last_launch(), H.last_launch()
         assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
+        mm.set_option(H.OPT_DMA_EDGE, 0)                                         # ... or, switched off, the round-2 fall-back
+        try:
+            got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+            assert "LDS-DMA" not in H.last_launch()
+            assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
+        finally:
+            mm.set_option(H.OPT_DMA_EDGE, 2)
     # ragged tile counts: the same tile under the chained stream-K control flow, with and without
     if True:
         for (m, n, k) in [(1152, 1152, 512), (1536, 1536, 256), (1792, 1280, 192), (2176, 2176, 128), (2944, 2432, 64),
@@ -221,8 +229,9 @@ def test_big_tile_full_matrix_vs_oracle(mm, oracle, shape, expect):
     assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
     d, _ = oracle.compare_matrices(got, oracle.ref_mmult(a, b, fma=False))
     assert d <= tol(k)
-    # whatever AUTO picks for the shape (4352^3: the 128x64 LDS-DMA tile as a phase-ordered stream-K
-    # launch; the ragged ones: the guarded 256x256 tile) -- the same bits
+    # whatever AUTO picks for the shape (4352^3 and the ragged counts of 256x256 tiles: the 128x64 LDS-DMA tile
+    # as a phase-ordered stream-K launch, guarded where the shape is ragged; 4000 x 4000: the guarded 256x256
+    # tile) -- the same bits
     mm.set_kernel("auto")
     assert np.array_equal(mm.matmul(dev(a), dev(b)).cpu().numpy(), got), H.last_launch()
     assert mm.streamk_timeouts() == 0
@@ -365,17 +374,18 @@ def test_stream_k_is_bit_identical(mm, oracle, shape):
 
 
 def test_auto_on_large_ragged_shapes_uses_the_big_tile_and_keeps_the_bits(mm, oracle):
-    """AUTO sends large shapes to the 256x256 tile when its edge padding is no worse than 128x128's:
-    guarded plain launch (4000 x 4000: 256 tiles) or guarded stream-K (5000 x 5000: 400 tiles on 256
-    workgroups).  Same bits as one workgroup per 128x128 tile and as the oracle."""
+    """AUTO on large ragged shapes: whole rounds of 256x256 tiles whose edge padding is no worse than
+    128x128's run the guarded 256x256 tile (4000 x 4000: 256 tiles); a ragged COUNT of them (5000 x 5000:
+    400 tiles for 256 workgroups) runs the guarded 128x64 LDS-DMA tile as a phase-ordered stream-K launch,
+    as the same count does on the grid (4352).  Same bits as one workgroup per 128x128 tile and as the oracle."""
     import torch
     import how_to_optimize_gemm_amd as H
-    for (m, n, k) in [(4000, 4000, 40), (5000, 5000, 72)]:
+    for (m, n, k, expect) in [(4000, 4000, 40, "sgemm_mfma_kernel<256,256>"), (5000, 5000, 72, "sgemm_dma_streamk_kernel<128,64>")]:
         a, b = oracle.harness_inputs(m, n, k, seed=m + k)
         da, db = dev(a), dev(b)
         mm.set_kernel("auto")
         got = mm.matmul(da, db)
-        assert "<256,256>" in H.last_launch(), H.last_launch()
+        assert expect in H.last_launch() and "guarded" in H.last_launch(), H.last_launch()
         assert mm.streamk_timeouts() == 0
         mm.set_kernel("mfma_tiles")
         assert torch.equal(got, mm.matmul(da, db))
@@ -516,7 +526,8 @@ def test_unaligned_pointers_take_the_guarded_path(mm, oracle):
     assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "mfma_64x64_dma",
+                                    "mfma_128x64_dma", "mfma_128x128_dma", "auto"])
 def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
     """Every operand only 4-byte aligned, odd lda/ldb/ldc, ragged m/n/k, with
     poison around the matrices: the descriptor-bounded path must neither read
@@ -547,17 +558,22 @@ def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
             assert torch.isnan(bufs["c"][0][0]) and torch.isnan(bufs["c"][0][1 + m * ldc:]).all()
 
 
-def test_nonfinite_padding_does_not_leak_through_the_k_tail(mm, oracle):
+@pytest.mark.parametrize("kernel", ["mfma", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma", "auto"])
+def test_nonfinite_padding_does_not_leak_through_the_k_tail(mm, oracle, kernel):
     """k not a multiple of the K-slice: the loads run into the next row / the
-    padding, which here holds inf/nan; masked lanes must not poison C."""
+    padding, which here holds inf/nan (A's padding, B's padding and the rows of the buffer below B);
+    masked lanes must not poison C.  The LDS-DMA tiles cannot mask on the way in: they zero the fragments."""
     import torch
+    mm.set_kernel(kernel)
+    for (m, n, k, lda, ldb) in [(256, 256, 100, 104, 260), (128, 192, 37, 37, 193), (300, 130, 33, 64, 131), (64, 64, 1, 8, 64)]:
+        a, b = oracle.harness_inputs(m, n, k, seed=9 + k)
+        abuf = torch.full((m + 2, lda), float("inf"), device="cuda")
+        abuf[:m, :k] = torch.from_numpy(a).cuda()
+        bbuf = torch.full((k + 40, ldb), float("nan"), device="cuda")
+        bbuf[:k, :n] = torch.from_numpy(b).cuda()
+        got = mm.matmul(abuf[:m, :k], bbuf[:k, :n]).cpu().numpy()
+        assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True)), (kernel, m, n, k)
     mm.set_kernel("mfma")
-    m, n, k, lda = 256, 256, 100, 104
-    a, b = oracle.harness_inputs(m, n, k, seed=9)
-    abuf = torch.full((m, lda), float("inf"), device="cuda")
-    abuf[:, :k] = torch.from_numpy(a).cuda()
-    got = mm.matmul(abuf[:, :k], dev(b)).cpu().numpy()
-    assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
 
 
 def test_huge_leading_dimension_uses_64bit_addressing(mm, oracle):
@@ -849,21 +865,23 @@ def test_peak_probes_are_sane(mm):
     assert 2000.0 < gb < 8000.0, gb
 
 
-def test_stream_k_timeout_is_a_sticky_error(oracle):
-    """Fault injection: stream-K producers do not publish, every dependent hand-off wait runs into the
-    (shortened) spin limit.  The waiting workgroups stop instead of continuing from an unpublished slot,
-    and the handle turns sticky: the NEXT mmh_* call -- and every one after it -- fails with
+def test_split_k_timeout_is_a_sticky_error(oracle):
+    """The only kernels that still WAIT for another workgroup are the opt-in split-K finishers (stream-K's
+    hand-over is wait-free, see test_stream_k_needs_no_co_residency).  Fault injection: split-K producers do
+    not announce their partial tiles, every finisher runs into the (shortened) spin limit, stops WITHOUT
+    storing, and the handle turns sticky: the NEXT mmh_* call -- and every one after it -- fails with
     MMH_ERR_HIP, no polling needed.  Clearing the word makes the handle usable again, same bits."""
     import torch
     import how_to_optimize_gemm_amd as H
-    h = H.MMult(0, "mfma")
+    h = H.MMult(0, "mfma_splitk")
     try:
-        m = n = 3072                                   # 576 tiles on 512 workgroup slots: stream-K
-        k = 256
+        m = n = 1024                                   # 64 tiles of 128x128 for 256 CUs: split-K's case
+        k = 2048
         a, b = oracle.harness_inputs(m, n, k, seed=5)
         da, db = dev(a), dev(b)
+        h.set_splitk(4)
         good = h.matmul(da, db)
-        assert "streamk" in H.last_launch()
+        assert "splitk" in H.last_launch(), H.last_launch()
         assert h.streamk_timeouts() == 0
         h.set_option(H.OPT_STREAMK_SPIN_LIMIT, 4)      # 4096 polls instead of seconds
         h.set_option(H.OPT_FAULT_INJECT, 1)
@@ -887,6 +905,15 @@ def test_stream_k_timeout_is_a_sticky_error(oracle):
         c = torch.empty((m, n), device="cuda")
         with pytest.raises(H.MMultError):
             h.time_sgemm(m, n, k, da.data_ptr(), k, db.data_ptr(), n, c.data_ptr(), n, warmup=0, reps=1)
+        # a stream-K launch has nothing to time out on: fault injection does not touch it
+        h.clear_error()
+        h.set_kernel("mfma")
+        a2, b2 = oracle.harness_inputs(3072, 3072, 256, seed=6)
+        got = h.matmul(dev(a2), dev(b2))
+        assert "streamk" in H.last_launch()
+        torch.cuda.synchronize()
+        assert h.streamk_timeouts() == 0
+        assert np.array_equal(got.cpu().numpy(), oracle.ref_mmult(a2, b2, fma=True))
     finally:
         h.close()
 
