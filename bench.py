@@ -184,7 +184,8 @@ def live_traffic(n: int, kernel: str):
             try:
                 # its own process group, so that a profiler that stops responding is killed WITH the child it started
                 p = subprocess.Popen([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc",
-                                      "--", sys.executable, "-c", child], cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"},
+                                      "--", sys.executable, "-c", child], cwd="/tmp",
+                                     env={**os.environ, "TMPDIR": "/tmp", "MMH_LAZY": "1"},   # no warm-up launches in the trace
                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
                 try:
                     p.wait(timeout=90)

@@ -92,7 +92,7 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       h->flags_dirty = true;   // a launch that timed out may have left hand-off counters behind
       return MMH_OK;
     case MMH_OPT_IGEMM_MODE:
-      if ((value >= 0 && value <= 6)
+      if ((value >= 0 && value <= 7)
 #ifdef MMH_AB_BUILD
           || (value >= 10 && value <= 13)
 #endif
@@ -120,6 +120,15 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
     case MMH_OPT_STREAMK_ORDER:
       h->sk_order = value ? 1 : 0;
       return MMH_OK;
+    case MMH_OPT_STREAMK_DELEGATIONS:   // writing 0 resets the counter
+      if (value != 0) return MMH_ERR_INVALID_ARG;
+      if (h->sk_stats) {
+        DeviceGuard guard;
+        HIP_TRY(guard.enter(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(h->sk_stats, 0, 64));
+      }
+      return MMH_OK;
     case MMH_OPT_DMA_EDGE:   // 0: ragged / unaligned shapes on the register-staged tiles only; 1: guarded LDS-DMA tiles
       h->dma_edge = value ? 1 : 0;     //    for rows that are 16-byte aligned; 2 (default): for any 4-byte aligned rows
       h->dma_dword_rows = value >= 2 ? 1 : 0;
@@ -144,6 +153,15 @@ int mmh_get_option(mmh_handle_t h, int option, int *value) {
     case MMH_OPT_STREAMK_SPIN_LIMIT: *value = (int)(h->spin_limit >> 10); return MMH_OK;
     case MMH_OPT_FAULT_INJECT: *value = h->fault; return MMH_OK;
     case MMH_OPT_STREAMK_ORDER: *value = h->sk_order; return MMH_OK;
+    case MMH_OPT_STREAMK_DELEGATIONS: {
+      *value = 0;
+      if (!h->sk_stats) return MMH_OK;
+      DeviceGuard guard;
+      HIP_TRY(guard.enter(h->device));
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemcpy(value, h->sk_stats, sizeof(int), hipMemcpyDeviceToHost));
+      return MMH_OK;
+    }
     case MMH_OPT_DMA_EDGE: *value = h->dma_edge ? (h->dma_dword_rows ? 2 : 1) : 0; return MMH_OK;
     case MMH_OPT_STREAMK_TIMEOUTS: {
       // synchronises, then reads the sticky word: how many hand-off waits have timed out on this

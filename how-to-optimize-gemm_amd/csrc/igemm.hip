@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "igemm_s8.hpp"
+#include "igemm_s8_pp.hpp"
 #include "internal.hpp"
 #include "quant_s8.hpp"
 
@@ -23,6 +24,11 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
   if (k == 0) {
     if (!accumulate)
       HIP_TRY(hipMemset2DAsync(dC, (size_t)ldc * 4, 0, (size_t)n * 4, (size_t)m, s));
+    return MMH_OK;
+  }
+  // mode 7 (A/B switch while K3p is being measured): the ping-pong schedule of the 256x256 in-place kernel
+  if (h->igemm_mode == 7 && igemm_s8_inplace_ok(dA, lda, dB, ldb, k)) {
+    HIP_TRY(launch_igemm_s8_pp(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
     return MMH_OK;
   }
   // Default mode: operands the in-place kernel cannot take as they are (an odd leading dimension, a

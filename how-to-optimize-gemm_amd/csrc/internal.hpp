@@ -90,6 +90,7 @@ struct mmh_context {
                            // last reader of a word resets it), so only a fresh or suspect buffer is memset
   bool flags_dirty = true;
   mmh::DevBuf parts;       // stream-K / split-K partial tiles
+  int *sk_stats = nullptr;           // device: [0] stream-K hand-overs finished by the head's owner (diagnostic)
   bool ws_captured = false;          // a captured launch points at flags / parts: retire, never free
   std::vector<void *> retired;       // allocations a captured graph may still point at
   int streamk = 1;         // allow the persistent stream-K launch for ragged tile counts

@@ -92,7 +92,7 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB,
   const int *order = nullptr, *place = nullptr;
   if ((rc = sk_tables_for(ctx, tiles, (g.k + KB - 1) / KB, grid, g.s, &order, &place)) != MMH_OK) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds_launch, g.s, g.m, g.n, g.k, g.A, g.lda, g.B, g.ldb, g.C,
-                     g.ldc, g.acc, nbm, nbn, flags, parts, order, place);
+                     g.ldc, g.acc, nbm, nbn, flags, parts, order, place, ctx->sk_stats);
   HIP_TRY(hipGetLastError());
   workspaces_launched(ctx, g.s);
   {
@@ -111,7 +111,7 @@ int warm_streamk_kernel(K kern, int BM, int BN, int KB, int threads, size_t lds,
   if (ok != MMH_OK) return ok;
   hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds, s, BM, BN, KB, scratch, KB, scratch, BN, scratch + 65536, BN, 0, 1, 1,
                      static_cast<int *>(nullptr), static_cast<float *>(nullptr), static_cast<const int *>(nullptr),
-                     static_cast<const int *>(nullptr));
+                     static_cast<const int *>(nullptr), static_cast<int *>(nullptr));
   HIP_TRY(hipGetLastError());
   return MMH_OK;
 }

@@ -535,20 +535,25 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 // still one fp32 fmaf chain over ascending k and the result is bit-identical to
 // the plain kernel.
 //
-// The hand-over is WAIT-FREE (round 3; rounds 1-2 had the tail's owner spin on a flag, which is only
-// live while every workgroup of the grid is resident -- something HIP never promises and a second
-// stream, a second handle or an RCCL kernel takes away).  A shared tile has one word:
-//     0  nothing yet        1  head published        2  the tail's owner came first
-// The head's owner stores its partial tile, drains, and EXCHANGES 1 into the word; the tail's owner,
-// when it gets there, COMPARE-AND-SWAPs 0 -> 2.  Exactly one of them sees the other's mark:
-//   * the tail's owner reads 1 (always, when the grid is co-resident: the head is the first thing its
-//     owner does, a whole tile earlier): it acquires, continues the chain from the slot, stores C;
-//   * the head's owner reads 2: the tail's owner has LEFT (it never waits); the head's owner runs the
-//     tail itself, from its own slot, after its other work.
-// Whoever finishes the tile puts the 0 back, so the next launch needs no memset.  No workgroup ever
-// waits for another: a launch makes progress with ANY number of resident workgroups, in any dispatch
-// order -- co-residency is a matter of speed (the ranges are sized for it), not of correctness, and
-// there is no time-out left to take.
+// The hand-over never waits for a workgroup that is not RUNNING (round 3; rounds 1-2 had the tail's owner
+// spin on a flag until a time-out, which is only live while every workgroup of the grid is resident --
+// something HIP never promises and a second stream, a second handle or an RCCL kernel takes away).
+// A shared tile has one word:
+//     0  nothing yet      3  the head's owner has started      1  head published      2  the tail's owner has left
+// The head's owner marks 0 -> 3 as its very first action, computes the head (its first piece of work: it depends
+// on nobody), stores the partial tile, drains, and EXCHANGES 1 into the word.  The tail's owner, when it gets there:
+//   * reads 1 (the normal case: the head was due a whole tile earlier): acquires, continues the chain from the
+//     slot, stores C;
+//   * reads 3: the head's owner is resident and will publish after a bounded amount of its OWN work -- polls
+//     (one lane, relaxed, s_sleep) until it reads 1.  This absorbs timing noise between the two (their margin is
+//     a tenth of a tile when ranges are ~1.1 tiles long) without ever depending on a workgroup that has not been
+//     dispatched;
+//   * reads 0: the head's owner is not running yet -- it may be queued behind THIS workgroup's slot.  Marks
+//     0 -> 2 and LEAVES; the head's owner will find the mark when it publishes (its exchange returns 2) and run
+//     the tail itself, from its own slot, after its other work.  (Also taken, as a back-stop, after 2^22 polls.)
+// Whoever finishes the tile puts the 0 back, so the next launch needs no memset.  So: a launch makes progress
+// with ANY number of resident workgroups, in any dispatch order -- co-residency is a matter of speed (the ranges
+// are sized for it), not of correctness, and there is no time-out to report.
 // Visibility across CUs/XCDs (cdna guide G16, recipe R1): producer = write-through (sc1)
 // stores of the partial tile, every wave drains vmcnt, barrier, one lane's relaxed agent-scope
 // atomic on the word; consumer = one lane's atomic, agent-scope acquire fence, barrier, plain loads.
@@ -570,14 +575,15 @@ struct RegSeg {
   }
 };
 
-constexpr int SK_EMPTY = 0, SK_HEAD_DONE = 1, SK_TAIL_LEFT = 2;
+constexpr int SK_EMPTY = 0, SK_HEAD_DONE = 1, SK_TAIL_LEFT = 2, SK_HEAD_RUNNING = 3;
 
 template <class Seg>
 __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
                                              const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                              int accumulate, int nbm, int nbn, int *__restrict__ flags,
                                              float *__restrict__ parts, const int *__restrict__ order = nullptr,
-                                             const int *__restrict__ place = nullptr) {
+                                             const int *__restrict__ place = nullptr, int *__restrict__ stats = nullptr) {
+  // stats (may be NULL): [0] counts the hand-overs finished by the head's owner (the tail's owner came first)
   constexpr int BM = Seg::BM, BN = Seg::BN, KB = Seg::KB;
   const int nk = (k + KB - 1) / KB;
   const int T = nbm * nbn, G = gridDim.x;
@@ -633,6 +639,11 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
   const bool first_partial = k_first != 0, last_partial = k_last_end != nk;
   bool tail_of_last_is_mine = false;
   if (last_partial) {                                                      // 1. head of the last tile
+    if (threadIdx.x == 0) {                                                //    "I am running": whoever needs it may wait for it
+      int none = SK_EMPTY;
+      __hip_atomic_compare_exchange_strong(&flags[t_last], &none, SK_HEAD_RUNNING, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+    }
     segment(t_last, 0, k_last_end, nullptr, my_slot);
     // Publish (cdna guide G16, recipe R1): the partial tile was stored write-through (sc1), so there is
     // nothing for a release fence to write back -- every storing wave drains its stores, the
@@ -649,8 +660,21 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
   if (first_partial) {                                                     // 3. rest of the first tile
     int seen = SK_EMPTY;
     if (threadIdx.x == 0) {
-      __hip_atomic_compare_exchange_strong(&flags[t_first], &seen, SK_TAIL_LEFT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+      long long polls = 0;
+      for (;;) {
+        seen = __hip_atomic_load(&flags[t_first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen == SK_HEAD_DONE) break;
+        if (seen == SK_HEAD_RUNNING && ++polls < (1ll << 22)) {   // resident and on its way: bounded by ITS OWN work
+          __builtin_amdgcn_s_sleep(8);
+          continue;
+        }
+        int expect = seen;                                        // not running (or the back-stop): leave the tail to it
+        if (__hip_atomic_compare_exchange_strong(&flags[t_first], &expect, SK_TAIL_LEFT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+          seen = SK_TAIL_LEFT;
+          break;
+        }
+      }
       if (seen == SK_HEAD_DONE) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // the part that finishes a tile is the last reader of its word: it puts the 0 back, so that the
@@ -660,12 +684,13 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
     }
     if (uniform(seen) == SK_HEAD_DONE)
       segment(t_first, k_first, nk, parts + (size_t)(q - 1) * BM * BN, nullptr);
-    // else: the head is not there yet -- its owner will find our mark and finish the tile itself
+    // else: the head's owner is not running -- it will find our mark and finish the tile itself
   }
   if (tail_of_last_is_mine) {                                              // 4. a tail somebody left to us
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // our own write-through stores, read back through L2
       __hip_atomic_store(&flags[t_last], SK_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (stats) __hip_atomic_fetch_add(stats, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     segment(t_last, k_last_end, nk, my_slot, nullptr);
   }
@@ -676,10 +701,11 @@ __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64, 2)
 sgemm_mfma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                           const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                           int accumulate, int nbm, int nbn, int *__restrict__ flags,
-                          float *__restrict__ parts, const int *__restrict__ order, const int *__restrict__ place) {
+                          float *__restrict__ parts, const int *__restrict__ order, const int *__restrict__ place,
+                          int *__restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   streamk_body<RegSeg<BM, BN, EDGE, WTN, WTM, KB>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn, flags,
-                                                   parts, order, place);
+                                                   parts, order, place, stats);
 }
 
 template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false>
@@ -687,10 +713,10 @@ __global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64)
 sgemm_dma_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B,
                          int ldb, float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn,
                          int *__restrict__ flags, float *__restrict__ parts, const int *__restrict__ order,
-                         const int *__restrict__ place) {
+                         const int *__restrict__ place, int *__restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   streamk_body<DmaSeg<BM, BN, KB, WTM, WTN, NBUF, EDGE>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn,
-                                                         flags, parts, order, place);
+                                                         flags, parts, order, place, stats);
 }
 
 // ---------------------------------------------------------------------------

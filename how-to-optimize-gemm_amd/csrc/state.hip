@@ -297,6 +297,11 @@ int create_context(mmh_context **out, int device) {
     }
   }
   (void)hipGetLastError();   // without the word the opt-in split-K launches are simply not used
+  {
+    void *st = nullptr;
+    if (hipMalloc(&st, 64) == hipSuccess && hipMemset(st, 0, 64) == hipSuccess) ctx->sk_stats = static_cast<int *>(st);
+    else (void)hipGetLastError();
+  }
   *out = ctx;
   // Everything a first launch would otherwise pay for -- code-object load, the > 64 KiB LDS opt-ins, the
   // residency queries, the stream-K workspaces -- happens HERE, where the reference creates its cuBLAS
@@ -374,6 +379,7 @@ void destroy_context(mmh_context *h) {
   if (h->t0) (void)hipEventDestroy(h->t0);
   if (h->t1) (void)hipEventDestroy(h->t1);
   if (h->sticky) (void)hipHostFree(h->sticky);
+  if (h->sk_stats) (void)hipFree(h->sk_stats);
   rocblas_release(h->rocblas);
   hipblaslt_release(h->blaslt);
   delete h;

@@ -139,11 +139,14 @@ int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
  * stream after the call returns: destroying a stream the handle has launched on is fine.
  *
  * Progress guarantee.  Stream-K launches are persistent grids whose workgroups hand partial tiles to each
- * other, but NO workgroup ever waits for another (sgemm_mfma.hpp, K2p: the hand-over is an atomic exchange;
- * whoever arrives second finishes the tile).  A launch therefore completes with any number of its workgroups
- * resident, in any dispatch order: several handles may run stream-K launches on concurrent streams, next to
- * RCCL kernels or anything else that occupies CUs -- co-residency changes the speed, never the result, and
- * there is no time-out.  (Only the OPT-IN split-K kernels wait, bounded, and raise the sticky error below.)
+ * other, but a workgroup only ever waits for one that is ALREADY RUNNING and whose remaining work before the
+ * hand-over depends on nobody (sgemm_mfma.hpp, K2p: a tile's word says whether the head's owner has started;
+ * if it has not, the tail's owner marks the word and leaves, and the head's owner finishes the tile itself).
+ * A launch therefore completes with any number of its workgroups resident, in any dispatch order: several
+ * handles may run stream-K launches on concurrent streams, next to RCCL kernels or anything else that
+ * occupies CUs -- co-residency changes the speed, never the result, and there is no time-out to report
+ * (MMH_OPT_STREAMK_DELEGATIONS counts the hand-overs that took the slow path).  Only the OPT-IN split-K
+ * kernels wait for workgroups that may not be resident -- bounded, raising the sticky error below.
  *
  * hipGraphs.  After one eager call of a shape, launches capture into a graph: a captured stream-K launch
  * records the upload of its phase-order tables as a node of the graph and pins them, and from the first
@@ -207,6 +210,11 @@ int mmh_kernel_id(const char *short_name);
  * tiles (sgemm_dma.hpp): 0 none (ragged or unaligned shapes run the register-staged tiles, the round-2
  * behaviour), 1 any m, n, k whose A and B rows are 16-byte aligned, 2 any 4-byte aligned operands. */
 #define MMH_OPT_DMA_EDGE 9
+/* MMH_OPT_STREAMK_DELEGATIONS (diagnostic, read-only; set 0 resets): how many stream-K hand-overs on this handle were
+ * finished by the HEAD's owner because the tail's owner got there first and left (sgemm_mfma.hpp, K2p).  0 while the
+ * persistent grids are co-resident; > 0 says a launch ran with part of its grid queued -- correct, only slower.
+ * get synchronises the device. */
+#define MMH_OPT_STREAMK_DELEGATIONS 10
 int mmh_set_option(mmh_handle_t handle, int option, int value);
 /* The two tables of a phase-ordered stream-K launch (MMH_OPT_STREAMK_ORDER) for `tiles` tile slots of `nk`
  * K-slices on `grid` persistent workgroups, computed on the host (no device needed): order[grid] = the range

@@ -375,12 +375,12 @@ def test_stream_k_is_bit_identical(mm, oracle, shape):
 
 def test_auto_on_large_ragged_shapes_uses_the_big_tile_and_keeps_the_bits(mm, oracle):
     """AUTO on large ragged shapes: whole rounds of 256x256 tiles whose edge padding is no worse than
-    128x128's run the guarded 256x256 tile (4000 x 4000: 256 tiles); a ragged COUNT of them (5000 x 5000:
-    400 tiles for 256 workgroups) runs the guarded 128x64 LDS-DMA tile as a phase-ordered stream-K launch,
-    as the same count does on the grid (4352).  Same bits as one workgroup per 128x128 tile and as the oracle."""
+    128x128's run the guarded 256x256 tile (4000 x 4000: 256 tiles); 5000 x 5000 -- 6241 tiles of 64x64, 24.4 per
+    CU, a last round 97.5 % full -- runs the guarded 64x64 LDS-DMA tile on a plain launch, as 5120 does on the
+    grid.  Same bits as one workgroup per 128x128 tile and as the oracle."""
     import torch
     import how_to_optimize_gemm_amd as H
-    for (m, n, k, expect) in [(4000, 4000, 40, "sgemm_mfma_kernel<256,256>"), (5000, 5000, 72, "sgemm_dma_streamk_kernel<128,64>")]:
+    for (m, n, k, expect) in [(4000, 4000, 40, "sgemm_mfma_kernel<256,256>"), (5000, 5000, 72, "sgemm_mfma_dma_kernel<64,64>")]:
         a, b = oracle.harness_inputs(m, n, k, seed=m + k)
         da, db = dev(a), dev(b)
         mm.set_kernel("auto")

@@ -99,11 +99,13 @@ def test_stream_k_needs_no_co_residency(oracle):
     there is nothing to wait for, so nothing can time out."""
     import torch
     import how_to_optimize_gemm_amd as H
-    ha, hb, hf = H.MMult(0, "auto"), H.MMult(0, "auto"), H.MMult(0, "mfma_256x256")
+    ha, hb, hf = H.MMult(0, "mfma_128x64_dma"), H.MMult(0, "mfma_128x64_dma"), H.MMult(0, "mfma_256x256")
     try:
+        ha.set_streamk(2)                                    # stream-K whenever the tile count is ragged
+        hb.set_streamk(2)
         sa, sb, sf = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
         jobs = []
-        for h, (m, n, k) in ((ha, (2944, 2944, 512)), (hb, (2176, 3328, 384)), (ha, (1152, 1152, 1024)), (hb, (3001, 2999, 130))):
+        for h, (m, n, k) in ((ha, (2944, 2944, 512)), (hb, (2176, 3328, 384)), (ha, (1920, 2048, 1024)), (hb, (3001, 2999, 130))):
             a, b = oracle.harness_inputs(m, n, k, seed=m + k)
             da, db = dev(a), dev(b)
             solo = h.matmul(da, db)
@@ -128,6 +130,8 @@ def test_stream_k_needs_no_co_residency(oracle):
             assert torch.equal(out, solo)
         assert ha.streamk_timeouts() == 0 and hb.streamk_timeouts() == 0
         assert elapsed < 2.0, elapsed                        # ~25 ms of work; a spinning hand-over would sit here for seconds
+        # how many hand-overs took the slow path (the tail's owner found the head's owner not even started and left)
+        print("stream-K delegations under contention:", ha.get_option(H.OPT_STREAMK_DELEGATIONS), hb.get_option(H.OPT_STREAMK_DELEGATIONS))
     finally:
         ha.close()
         hb.close()
