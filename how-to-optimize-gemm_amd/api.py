@@ -44,7 +44,8 @@ EXPORTS = [
     "mmh_set_option", "mmh_get_option",
     "mmh_sgemm", "mmh_sgemm_host", "mmh_sgemm_host_timed", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
     "mmh_sgemm_rocblas", "mmh_sgemm_hipblaslt", "mmh_shard_rows",
-    "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm",
+    "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm", "mmh_shard_pin",
+    "mmh_shard_unpin",
     "mmh_rccl_version",
     "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_time_comparator", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
     "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy", "mmh_probe_hbm_read", "mmh_probe_lds_read", "mmh_streamk_plan",
@@ -165,6 +166,8 @@ def lib() -> C.CDLL:
     L.mmh_shard_set_kernel.argtypes = [vp, C.c_int]
     L.mmh_shard_info.argtypes = [vp, ip, ip]
     L.mmh_shard_sgemm.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, fp]
+    L.mmh_shard_pin.argtypes = [vp, vp, C.c_size_t]
+    L.mmh_shard_unpin.argtypes = [vp, vp]
     L.mmh_rccl_version.argtypes = [ip]
     L.mmh_time_sgemm.argtypes = gemm + [C.c_int, C.c_int, vp, fp]
     L.mmh_time_comparator.argtypes = [vp, C.c_int] + gemm[1:] + [C.c_int, C.c_int, vp, fp]
@@ -599,6 +602,13 @@ class ShardedMMult:
         n, r = C.c_int(0), C.c_int(0)
         _check(lib().mmh_shard_info(self._h, C.byref(n), C.byref(r)), "mmh_shard_info")
         return {"ngpus": n.value, "rccl_ranks": r.value}
+
+    def pin(self, x: np.ndarray) -> None:
+        """Page-lock a host array that will be passed to sgemm() repeatedly (unpin before it is freed)."""
+        _check(lib().mmh_shard_pin(self._h, _np_ptr(x), x.nbytes), "mmh_shard_pin")
+
+    def unpin(self, x: np.ndarray) -> None:
+        _check(lib().mmh_shard_unpin(self._h, _np_ptr(x)), "mmh_shard_unpin")
 
     def sgemm(self, a: np.ndarray, b: np.ndarray, c: Optional[np.ndarray] = None, gemm_reps: int = 1):
         """C = A @ B on host arrays.  Returns (C, {"h2d","bcast","gemm","d2h"} ms; gemm is per rep)."""

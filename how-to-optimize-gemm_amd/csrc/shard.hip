@@ -3,6 +3,7 @@
 // (cuda/test_MMult.cpp:24-25: cudaSetDevice(0) only).  Part of libmmult_hip.so (see internal.hpp).
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <new>
 #include <thread>
 
@@ -19,6 +20,8 @@ struct mmh_shard {
   std::vector<hipStream_t> streams;
   std::vector<DevBuf> a, b, c;        // per device: A panel, B, C panel
   std::vector<void *> comms;
+  bool shared_device = false;         // test mode: several logical ranks on one device, B replicated by device copies
+  std::vector<std::pair<void *, size_t>> pinned;   // host ranges mmh_shard_pin registered
 };
 
 extern "C" {
@@ -54,9 +57,39 @@ int mmh_shard_destroy(mmh_shard_t sh) {
     if (d < (int)sh->streams.size() && sh->streams[d]) (void)hipStreamDestroy(sh->streams[d]);
     if (d < (int)sh->ctx.size()) destroy_context(sh->ctx[d]);
   }
+  for (auto &r : sh->pinned) (void)hipHostUnregister(r.first);
+  (void)hipGetLastError();
   if (prev >= 0) (void)hipSetDevice(prev);
   delete sh;
   return MMH_OK;
+}
+
+// Page-lock a host range the caller is about to hand to mmh_shard_sgemm repeatedly (A, B, C of one sweep size):
+// copies from / to pageable memory are staged by the runtime at a fraction of the link rate and block their
+// calling thread.  The caller unpins before it frees the memory; mmh_shard_destroy unpins what is left.
+int mmh_shard_pin(mmh_shard_t sh, void *host, size_t bytes) {
+  if (!sh || !host || bytes == 0) return MMH_ERR_INVALID_ARG;
+  for (auto &r : sh->pinned)
+    if (r.first == host) return r.second >= bytes ? MMH_OK : MMH_ERR_INVALID_ARG;
+  const hipError_t e = hipHostRegister(host, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return hip_fail(e, "hipHostRegister");
+  }
+  sh->pinned.emplace_back(host, bytes);
+  return MMH_OK;
+}
+
+int mmh_shard_unpin(mmh_shard_t sh, void *host) {
+  if (!sh || !host) return MMH_ERR_INVALID_ARG;
+  for (size_t i = 0; i < sh->pinned.size(); ++i)
+    if (sh->pinned[i].first == host) {
+      const hipError_t e = hipHostUnregister(host);
+      sh->pinned.erase(sh->pinned.begin() + i);
+      if (e != hipSuccess) return hip_fail(e, "hipHostUnregister");
+      return MMH_OK;
+    }
+  return MMH_ERR_INVALID_ARG;
 }
 
 int mmh_shard_create(mmh_shard_t *out, int ngpus, const int *devices) {
@@ -65,20 +98,32 @@ int mmh_shard_create(mmh_shard_t *out, int ngpus, const int *devices) {
   if (ngpus <= 0 || ngpus > 64) return MMH_ERR_INVALID_ARG;
   int count = 0;
   mmh_device_count(&count);
-  if (count < ngpus) {
+  // Test mode (MMH_SHARD_SHARE_DEVICE=1 and an explicit device list that names ONE device ngpus times): the
+  // ranks are logical, B is replicated with device-to-device copies instead of RCCL -- the phase plumbing of
+  // an N-rank shard (empty panels included) on a box with one GPU.  Never entered silently.
+  bool shared = false;
+  if (devices && ngpus > 1) {
+    const char *e = std::getenv("MMH_SHARD_SHARE_DEVICE");
+    bool all_same = true;
+    for (int d = 1; d < ngpus; ++d) all_same = all_same && devices[d] == devices[0];
+    shared = all_same && e && *e && *e != '0';
+  }
+  if (!shared && count < ngpus) {
     set_last_error("fewer visible devices (" + std::to_string(count) + ") than ngpus (" + std::to_string(ngpus) + ")");
     return MMH_ERR_NO_DEVICE;
   }
-  if (ngpus > 1 && !rccl_api().ok) {
+  if (ngpus > 1 && !shared && !rccl_api().ok) {
     set_last_error("librccl.so could not be loaded");
     return MMH_ERR_UNSUPPORTED;
   }
   mmh_shard *sh = new (std::nothrow) mmh_shard;
   if (!sh) return MMH_ERR_ALLOC;
   sh->ngpus = ngpus;
+  sh->shared_device = shared;
   for (int d = 0; d < ngpus; ++d) {
     const int dev = devices ? devices[d] : d;
-    if (dev < 0 || dev >= count || std::find(sh->devices.begin(), sh->devices.end(), dev) != sh->devices.end()) {
+    if (dev < 0 || dev >= count ||
+        (!shared && std::find(sh->devices.begin(), sh->devices.end(), dev) != sh->devices.end())) {
       delete sh;
       set_last_error("device list names a device twice or out of range");
       return MMH_ERR_INVALID_ARG;
@@ -102,7 +147,7 @@ int mmh_shard_create(mmh_shard_t *out, int ngpus, const int *devices) {
       rc = MMH_ERR_HIP;
     }
   }
-  if (rc == MMH_OK && ngpus > 1) {
+  if (rc == MMH_OK && ngpus > 1 && !shared) {
     // ONE communicator for the life of the handle (creating it costs far more than any GEMM here)
     if (rccl_api().comm_init_all(sh->comms.data(), ngpus, sh->devices.data()) != 0) {
       set_last_error("ncclCommInitAll failed");
@@ -198,7 +243,12 @@ int mmh_shard_sgemm(mmh_shard_t sh, int m, int n, int k, const float *A, int lda
   if (timings_ms) timings_ms[0] = ms_since(t);
   // ---- the one collective: broadcast B from device 0 over xGMI ----
   t = clk::now();
-  if (G > 1 && k > 0) {
+  if (G > 1 && k > 0 && sh->shared_device) {
+    HIP_TRY(hipStreamSynchronize(sh->streams[0]));
+    for (int d = 1; d < G; ++d)
+      HIP_TRY(hipMemcpyAsync(sh->b[d].p, sh->b[0].p, (size_t)k * n * sizeof(float), hipMemcpyDeviceToDevice, sh->streams[d]));
+    for (int d = 1; d < G; ++d) HIP_TRY(hipStreamSynchronize(sh->streams[d]));
+  } else if (G > 1 && k > 0) {
     RcclApi &api = rccl_api();
     bool bad = api.group_start() != 0;
     for (int d = 0; d < G && !bad; ++d) {

@@ -235,10 +235,19 @@ int main(int argc, char **argv) {
     if (sharded) {
       // one call = h2d, ONE broadcast, NREPEATS back-to-back GEMM launches per device, d2h; the GEMM
       // phase is reported per launch (the reference times NREPEATS launches, cuda/test_MMult.cpp:98-118)
+      // the three host arrays of this size are page-locked for the calls below (the role pinned staging plays
+      // for any H2D copy that should run at the link's rate) and released before they are freed
+      const bool pinned = mmh_shard_pin(shard, a.data(), a.size() * sizeof(float)) == MMH_OK &&
+                          mmh_shard_pin(shard, b.data(), b.size() * sizeof(float)) == MMH_OK &&
+                          mmh_shard_pin(shard, cold.data(), cold.size() * sizeof(float)) == MMH_OK;
       for (int rep = 0; rep < o.warmup; ++rep)
         MMH_CHECK(mmh_shard_sgemm(shard, m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc, 1, nullptr));
       MMH_CHECK(mmh_shard_sgemm(shard, m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc, o.nrepeats, phase_ms));
       seconds = phase_ms[2] * 1e-3;
+      (void)pinned;
+      (void)mmh_shard_unpin(shard, a.data());
+      (void)mmh_shard_unpin(shard, b.data());
+      (void)mmh_shard_unpin(shard, cold.data());
     } else if (cpu_only) {
       double best = 0.0;
       for (int rep = 0; rep < o.nrepeats; ++rep) {

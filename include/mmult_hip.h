@@ -303,6 +303,14 @@ int mmh_shard_set_kernel(mmh_shard_t shard, int kernel);
 int mmh_shard_info(mmh_shard_t shard, int *ngpus, int *rccl_ranks);
 int mmh_shard_sgemm(mmh_shard_t shard, int m, int n, int k, const float *A, int lda, const float *B,
                     int ldb, float *C, int ldc, int gemm_reps, float *timings_ms);
+/* Page-lock (hipHostRegister) a host range that is about to be passed to mmh_shard_sgemm more than once -- A, B
+ * and C of one sweep size: copies from / to pageable memory run at a fraction of the PCIe rate.  Unpin before
+ * the memory is freed; mmh_shard_destroy unpins whatever is left.
+ * (Test mode: with MMH_SHARD_SHARE_DEVICE=1 in the environment, a device list that names ONE device ngpus times
+ * creates ngpus LOGICAL ranks on it -- B replicated by device copies, no RCCL -- so that the phase plumbing of
+ * an N-rank shard, empty row panels included, runs on a box with one GPU.  Never entered implicitly.) */
+int mmh_shard_pin(mmh_shard_t shard, void *host, size_t bytes);
+int mmh_shard_unpin(mmh_shard_t shard, void *host);
 /* RCCL as this library sees it: loads librccl (dlopen) and returns ncclGetVersion's code in *version;
  * MMH_ERR_UNSUPPORTED when the library or one of the entry points the shard needs is missing.
  * Needs no GPU. */

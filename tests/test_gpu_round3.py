@@ -304,3 +304,28 @@ def test_one_element_off_the_grid_is_not_a_cliff(mm, n0):
     assert rates[n0 - 1] >= 0.88 * rates[n0], rates
     assert rates[n0 + 1] >= 0.85 * rates[n0], rates
     mm.set_kernel("mfma")
+
+
+def test_single_process_shard_with_empty_panels_and_pinned_host_arrays(oracle, monkeypatch):
+    """mmh_shard_* with more ranks than row tiles (some panels are EMPTY) -- run for real on one GPU through the
+    explicit test mode (MMH_SHARD_SHARE_DEVICE=1 + a device list naming one device per logical rank: B is then
+    replicated by device copies, no RCCL) -- and with the host arrays page-locked by mmh_shard_pin.  The result is
+    the single-GPU chain's bits; without the switch the same device list is refused."""
+    import how_to_optimize_gemm_amd as H
+    with pytest.raises(H.MMultError):
+        H.ShardedMMult(3, devices=[0, 0, 0])
+    monkeypatch.setenv("MMH_SHARD_SHARE_DEVICE", "1")
+    for ranks, (m, n, k) in ((3, (300, 256, 128)), (5, (256, 384, 96)), (8, (1000, 128, 64)), (4, (100, 64, 32))):
+        a, b = oracle.harness_inputs(m, n, k, seed=ranks)
+        empty = sum(1 for r in range(ranks) if H.shard_rows(m, ranks, r)[1] == 0)
+        assert empty > 0 or ranks == 8
+        with H.ShardedMMult(ranks, devices=[0] * ranks, kernel="auto") as sh:
+            assert sh.info() == {"ngpus": ranks, "rccl_ranks": 0}
+            c = np.full((m, n), np.nan, dtype=np.float32)
+            for x in (a, b, c):
+                sh.pin(x)
+            got, t = sh.sgemm(a, b, c, gemm_reps=2)
+            for x in (a, b, c):
+                sh.unpin(x)
+            assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True)), (ranks, m, n, k)
+            assert set(t) == {"h2d", "bcast", "gemm", "d2h"}
