@@ -89,7 +89,7 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
         HIP_TRY(hipDeviceSynchronize());
       }
       if (h->sticky) *reinterpret_cast<volatile int *>(h->sticky) = 0;
-      h->flags_dirty = true;   // a launch that timed out may have left hand-off counters behind
+      workspaces_suspect(h);   // a launch that timed out may have left hand-off counters behind
       return MMH_OK;
     case MMH_OPT_IGEMM_MODE:
       if ((value >= 0 && value <= 7)
@@ -115,7 +115,7 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       return MMH_OK;
     case MMH_OPT_FAULT_INJECT:
       h->fault = value ? 1 : 0;
-      h->flags_dirty = true;
+      workspaces_suspect(h);
       return MMH_OK;
     case MMH_OPT_STREAMK_ORDER:
       h->sk_order = value ? 1 : 0;

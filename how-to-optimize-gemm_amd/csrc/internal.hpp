@@ -86,12 +86,21 @@ struct mmh_context {
   mmh::DevBuf bt;          // int8 GEMM: packed (transposed, padded) B
   int igemm_mode = 0;      // 0 auto, see MMH_OPT_IGEMM_MODE
   mmh::DevBuf qa, qb, qc, qs;   // quantised GEMM workspace: int8 A, int8 B, int32 C, {amax bits, scales}
-  mmh::DevBuf flags;       // stream-K / split-K per-tile hand-off words; every launch leaves them ZERO (the
-                           // last reader of a word resets it), so only a fresh or suspect buffer is memset
-  bool flags_dirty = true;
-  mmh::DevBuf parts;       // stream-K / split-K partial tiles
+  // stream-K / split-K workspaces, one set PER STREAM the handle has launched on: launches on different streams
+  // never share hand-off words or partial tiles, so nothing has to order one stream behind another and the handle
+  // never touches a stream again after the call that used it returns (the caller may destroy it).
+  struct StreamWs {
+    hipStream_t stream = nullptr;
+    mmh::DevBuf flags;     // per-tile hand-off words; every launch leaves them ZERO (the last reader of a word
+                           // resets it), so only a fresh or suspect buffer is memset
+    bool flags_dirty = true;
+    mmh::DevBuf parts;     // partial tiles
+    unsigned long stamp = 0;
+    bool captured = false; // a captured launch points at flags / parts: retire on growth, never evict
+  };
+  std::vector<StreamWs *> ws;
+  unsigned long ws_stamp = 0;
   int *sk_stats = nullptr;           // device: [0] stream-K hand-overs finished by the head's owner (diagnostic)
-  bool ws_captured = false;          // a captured launch points at flags / parts: retire, never free
   std::vector<void *> retired;       // allocations a captured graph may still point at
   int streamk = 1;         // allow the persistent stream-K launch for ragged tile counts
   int splitk = 0;          // opt-in split-K: 0 off (default), 1 auto, >= 2 that many parts
@@ -118,14 +127,10 @@ struct mmh_context {
     unsigned long stamp = 0;
     bool pinned = false;       // a captured graph points at buf: never evicted
     bool uploaded = false;
+    hipStream_t upload_stream = nullptr;   // the stream whose order the last upload sits in
   };
   std::vector<SkTable *> sk_tables;
   unsigned long sk_stamp = 0;
-  // the hand-off workspaces above are per handle: an eager launch on another stream than the previous
-  // one is ordered behind it with an event (no host block)
-  hipStream_t ws_stream = nullptr;
-  hipEvent_t ws_event = nullptr;
-  bool ws_used = false;
   // resident workgroups per CU of each persistent kernel, per handle (= per device)
   std::vector<std::pair<const void *, int>> per_cu;
   bool warmed = false;
@@ -171,10 +176,9 @@ int check_gemm_args(int m, int n, int k, const void *A, int lda, const void *B, 
 bool known_kernel(int kernel);
 
 // ---- stream-K workspaces (state.hip) ----
-int claim_workspaces(mmh_context *ctx, hipStream_t s);
-void workspaces_launched(mmh_context *ctx, hipStream_t s);
-int prepare_flags(mmh_context *ctx, long tiles, hipStream_t s, int **flags);
-int reserve_parts(mmh_context *ctx, size_t bytes, hipStream_t s, float **parts);
+// the stream's own hand-off words (>= tiles of them, all zero) and partial-tile slots (>= parts_bytes)
+int workspace_for(mmh_context *ctx, hipStream_t s, long tiles, size_t parts_bytes, int **flags, float **parts);
+void workspaces_suspect(mmh_context *ctx);   // a launch may have died half-way: every set is memset before its next use
 bool build_sk_tables(long tiles, int nk, int grid, int *order, int *place);
 int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place);
 

@@ -72,12 +72,10 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB,
     const long rounds = (tiles + cus - 1) / cus;
     if (tiles * 100 >= rounds * cus * 93) return 1;
   }
-  int rc = claim_workspaces(ctx, g.s);
-  if (rc != MMH_OK) return rc;
   int *flags = nullptr;
-  if ((rc = prepare_flags(ctx, tiles, g.s, &flags)) != MMH_OK) return rc;
-  float *parts = nullptr;
-  if ((rc = reserve_parts(ctx, (size_t)grid * BM * BN * sizeof(float), g.s, &parts)) != MMH_OK) return rc;   // one slot per range
+  float *parts = nullptr;   // one partial-tile slot per range
+  int rc = workspace_for(ctx, g.s, tiles, (size_t)grid * BM * BN * sizeof(float), &flags, &parts);
+  if (rc != MMH_OK) return rc;
   // The ranges assume every workgroup owns 1/w of a CU.  When more than w would FIT (a 48 KiB ring three
   // times), nothing obliges the dispatcher to spread grid = w x CUs workgroups evenly -- seen as a bimodal
   // rate (N = 1536: 130 or 100 TFLOP/s from run to run) -- so the launch asks for 160 KiB / w of LDS:
@@ -94,7 +92,6 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB,
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds_launch, g.s, g.m, g.n, g.k, g.A, g.lda, g.B, g.ldb, g.C,
                      g.ldc, g.acc, nbm, nbn, flags, parts, order, place, ctx->sk_stats);
   HIP_TRY(hipGetLastError());
-  workspaces_launched(ctx, g.s);
   {
     char buf[224];
     snprintf(buf, sizeof buf, "%s, %ld tiles on %d persistent workgroups%s", what, tiles, grid,

@@ -89,13 +89,11 @@ int try_launch_splitk(mmh_context *ctx, int S, const GemmArgs &g) {
   const int per_cu = resident_per_cu(ctx, kern, threads, lds);
   while (S >= 2 && tiles * S > (long)per_cu * cus) --S;   // every part resident at once
   if (S < 2) return 1;
-  int rc = claim_workspaces(ctx, g.s);
-  if (rc != MMH_OK) return rc;
   int *flags = nullptr;
-  if ((rc = prepare_flags(ctx, tiles, g.s, &flags)) != MMH_OK) return rc;
   float *parts = nullptr;
-  if ((rc = reserve_parts(ctx, (size_t)tiles * (S - 1) * BM * BN * sizeof(float), g.s, &parts)) != MMH_OK) return rc;
-  if (ctx->fault) ctx->flags_dirty = true;   // a launch whose finishers time out leaves arrival counts behind
+  const int rc = workspace_for(ctx, g.s, tiles, (size_t)tiles * (S - 1) * BM * BN * sizeof(float), &flags, &parts);
+  if (rc != MMH_OK) return rc;
+  if (ctx->fault) workspaces_suspect(ctx);   // a launch whose finishers time out leaves arrival counts behind
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(threads), lds, g.s, g.m, g.n, g.k, g.A, g.lda, g.B, g.ldb, g.C,
                      g.ldc, g.acc, nbm, nbn, S, flags, ctx->sticky_dev, parts, ctx->spin_limit, ctx->fault);
   HIP_TRY(hipGetLastError());

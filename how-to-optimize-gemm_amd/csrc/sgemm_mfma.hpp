@@ -538,19 +538,20 @@ sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 // The hand-over never waits for a workgroup that is not RUNNING (round 3; rounds 1-2 had the tail's owner
 // spin on a flag until a time-out, which is only live while every workgroup of the grid is resident --
 // something HIP never promises and a second stream, a second handle or an RCCL kernel takes away).
-// A shared tile has one word:
-//     0  nothing yet      3  the head's owner has started      1  head published      2  the tail's owner has left
-// The head's owner marks 0 -> 3 as its very first action, computes the head (its first piece of work: it depends
-// on nobody), stores the partial tile, drains, and EXCHANGES 1 into the word.  The tail's owner, when it gets there:
-//   * reads 1 (the normal case: the head was due a whole tile earlier): acquires, continues the chain from the
+// A shared tile has one word of three bits:
+//     RUNNING (4)  the head's owner has started     DONE (1)  head published     LEFT (2)  the tail's owner has left
+// The head's owner ORs RUNNING in as its very first action (no reply awaited), computes the head (its first piece
+// of work: it depends on nobody), stores the partial tile, drains, and ORs DONE in -- the reply, which says whether
+// LEFT was already there, is only looked at after the workgroup's other work.  The tail's owner, when it gets there:
+//   * reads DONE (the normal case: the head was due a whole tile earlier): acquires, continues the chain from the
 //     slot, stores C;
-//   * reads 3: the head's owner is resident and will publish after a bounded amount of its OWN work -- polls
-//     (one lane, relaxed, s_sleep) until it reads 1.  This absorbs timing noise between the two (their margin is
+//   * reads RUNNING: the head's owner is resident and will publish after a bounded amount of its OWN work -- polls
+//     (one lane, relaxed, s_sleep) until it reads DONE.  This absorbs timing noise between the two (their margin is
 //     a tenth of a tile when ranges are ~1.1 tiles long) without ever depending on a workgroup that has not been
 //     dispatched;
-//   * reads 0: the head's owner is not running yet -- it may be queued behind THIS workgroup's slot.  Marks
-//     0 -> 2 and LEAVES; the head's owner will find the mark when it publishes (its exchange returns 2) and run
-//     the tail itself, from its own slot, after its other work.  (Also taken, as a back-stop, after 2^22 polls.)
+//   * reads 0: the head's owner is not running yet -- it may be queued behind THIS workgroup's slot.  Swaps
+//     0 -> LEFT and LEAVES; the head's owner will find LEFT in the reply to its DONE and run the tail itself, from
+//     its own slot, after its other work.  (Also taken, as a back-stop, after 2^22 polls of RUNNING.)
 // Whoever finishes the tile puts the 0 back, so the next launch needs no memset.  So: a launch makes progress
 // with ANY number of resident workgroups, in any dispatch order -- co-residency is a matter of speed (the ranges
 // are sized for it), not of correctness, and there is no time-out to report.
@@ -575,7 +576,7 @@ struct RegSeg {
   }
 };
 
-constexpr int SK_EMPTY = 0, SK_HEAD_DONE = 1, SK_TAIL_LEFT = 2, SK_HEAD_RUNNING = 3;
+constexpr int SK_EMPTY = 0, SK_HEAD_DONE = 1, SK_TAIL_LEFT = 2, SK_HEAD_RUNNING = 4;
 
 template <class Seg>
 __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
@@ -637,23 +638,18 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
     return;
   }
   const bool first_partial = k_first != 0, last_partial = k_last_end != nk;
-  bool tail_of_last_is_mine = false;
+  int head_reply = 0;                                                      // thread 0: what the word held when DONE went in
   if (last_partial) {                                                      // 1. head of the last tile
-    if (threadIdx.x == 0) {                                                //    "I am running": whoever needs it may wait for it
-      int none = SK_EMPTY;
-      __hip_atomic_compare_exchange_strong(&flags[t_last], &none, SK_HEAD_RUNNING, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0)                                                  //    "I am running": whoever needs it may wait for it
+      (void)__hip_atomic_fetch_or(&flags[t_last], SK_HEAD_RUNNING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     segment(t_last, 0, k_last_end, nullptr, my_slot);
     // Publish (cdna guide G16, recipe R1): the partial tile was stored write-through (sc1), so there is
     // nothing for a release fence to write back -- every storing wave drains its stores, the
-    // workgroup meets, ONE lane exchanges the word.
+    // workgroup meets, ONE lane ORs DONE into the word.  Nobody waits for the reply here.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int old = 0;
     __syncthreads();
     if (threadIdx.x == 0)
-      old = __hip_atomic_exchange(&flags[t_last], SK_HEAD_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tail_of_last_is_mine = uniform(old) == SK_TAIL_LEFT;
+      head_reply = __hip_atomic_fetch_or(&flags[t_last], SK_HEAD_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   for (int t = t_first + (first_partial ? 1 : 0); t <= t_last - (last_partial ? 1 : 0); ++t)
     segment(t, 0, nk, nullptr, nullptr);                                   // 2. whole tiles
@@ -663,19 +659,20 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
       long long polls = 0;
       for (;;) {
         seen = __hip_atomic_load(&flags[t_first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen == SK_HEAD_DONE) break;
-        if (seen == SK_HEAD_RUNNING && ++polls < (1ll << 22)) {   // resident and on its way: bounded by ITS OWN work
+        if (seen & SK_HEAD_DONE) break;
+        if ((seen & SK_HEAD_RUNNING) && ++polls < (1ll << 22)) {   // resident and on its way: bounded by ITS OWN work
           __builtin_amdgcn_s_sleep(8);
           continue;
         }
         int expect = seen;                                        // not running (or the back-stop): leave the tail to it
-        if (__hip_atomic_compare_exchange_strong(&flags[t_first], &expect, SK_TAIL_LEFT, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+        if (__hip_atomic_compare_exchange_strong(&flags[t_first], &expect, seen | SK_TAIL_LEFT, __ATOMIC_RELAXED,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           seen = SK_TAIL_LEFT;
           break;
         }
       }
-      if (seen == SK_HEAD_DONE) {
+      if (seen & SK_HEAD_DONE) {
+        seen = SK_HEAD_DONE;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // the part that finishes a tile is the last reader of its word: it puts the 0 back, so that the
         // NEXT launch finds every word zero without a memset dispatch in front of it
@@ -686,7 +683,7 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
       segment(t_first, k_first, nk, parts + (size_t)(q - 1) * BM * BN, nullptr);
     // else: the head's owner is not running -- it will find our mark and finish the tile itself
   }
-  if (tail_of_last_is_mine) {                                              // 4. a tail somebody left to us
+  if (last_partial && (uniform(head_reply) & SK_TAIL_LEFT)) {              // 4. a tail somebody left to us
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // our own write-through stores, read back through L2
       __hip_atomic_store(&flags[t_last], SK_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

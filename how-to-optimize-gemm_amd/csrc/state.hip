@@ -78,65 +78,67 @@ int check_gemm_args(int m, int n, int k, const void *A, int lda, const void *B, 
 bool known_kernel(int kernel) { return mmh_kernel_name(kernel) != nullptr; }
 
 // ---------------------------------------------------------------------------------------------------
-// The hand-off workspaces (flags, partial tiles) belong to the handle.  Launches on ONE stream are
-// ordered by the stream.  An eager launch on ANOTHER stream than the previous workspace-using launch is
-// ordered behind it on the DEVICE: an event recorded on the previous stream, waited for by the new one --
-// no host block, and the handle keeps no claim on a stream the caller may have destroyed meanwhile (if
-// the record fails because the stream is gone, everything in flight on the device is waited for instead,
-// once).  A launch that is being CAPTURED into a hipGraph executes nothing now and may not synchronise
-// anything: it is recorded as it is, and whoever replays the graph orders it against other work on the
-// handle (as for any buffer a graph owns) -- include/mmult_hip.h says so.
+// The hand-off workspaces (flags, partial tiles) exist once PER STREAM the handle has launched on.  Launches on
+// one stream are ordered by the stream; launches on different streams use different sets, so they may overlap and
+// the handle never needs to order one stream behind another -- it keeps no claim on a stream once the call that
+// launched on it has returned, and the caller may destroy the stream.  (Rounds 1-2 had ONE set and synchronised
+// the previous stream by handle; ROCm 7.2 crashes inside hipEventRecord / hipStreamSynchronize on a destroyed
+// stream, it does not return an error.)  Sets are created on first use and kept; beyond eight, the least
+// recently used one that no captured graph points at is released after a device-wide synchronisation (its stream
+// may be gone).  A launch that is being CAPTURED into a hipGraph uses the capture stream's set, which is then never
+// evicted and only ever retires (never frees) a buffer that has to grow.
 // ---------------------------------------------------------------------------------------------------
-int claim_workspaces(mmh_context *ctx, hipStream_t s) {
-  if (capturing(s)) {
-    ctx->ws_captured = true;   // flags / parts are now part of a graph: they may grow, never move
-    return MMH_OK;
-  }
-  if (ctx->ws_used && ctx->ws_stream != s) {
-    if (!ctx->ws_event) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
-    if (hipEventRecord(ctx->ws_event, ctx->ws_stream) == hipSuccess) {
-      HIP_TRY(hipStreamWaitEvent(s, ctx->ws_event, 0));
-    } else {
-      (void)hipGetLastError();             // the previous stream no longer exists
-      HIP_TRY(hipDeviceSynchronize());
-    }
-  }
-  ctx->ws_stream = s;
-  ctx->ws_used = true;
-  return MMH_OK;
-}
-
-void workspaces_launched(mmh_context *, hipStream_t) {}
-
-// The hand-off words of `tiles` tiles, all zero.  The kernels restore the zeros themselves (the part that
-// finishes a tile resets its word), so the fill runs only when the buffer is new, has grown, or a
-// launch may have died half-way (a sticky error was cleared).
-int prepare_flags(mmh_context *ctx, long tiles, hipStream_t s, int **flags) {
-  const size_t need = (size_t)tiles * sizeof(int);
+int workspace_for(mmh_context *ctx, hipStream_t s, long tiles, size_t parts_bytes, int **flags, float **parts) {
   const bool cap = capturing(s);
-  if (need > ctx->flags.bytes) {
-    const int rc = ctx->flags.reserve(std::max(need, (size_t)(256u << 10)), ctx->ws_captured ? &ctx->retired : nullptr);
+  mmh_context::StreamWs *w = nullptr;
+  for (auto *e : ctx->ws)
+    if (e->stream == s) w = e;
+  if (!w) {
+    size_t evictable = 0;
+    for (auto *e : ctx->ws) evictable += e->captured ? 0 : 1;
+    if (evictable >= 8 && !cap) {
+      mmh_context::StreamWs *old = nullptr;
+      for (auto *e : ctx->ws)
+        if (!e->captured && (!old || e->stamp < old->stamp)) old = e;
+      HIP_TRY(hipDeviceSynchronize());   // whatever still uses the set -- on a stream that may no longer exist
+      old->flags.release();
+      old->parts.release();
+      old->flags_dirty = true;
+      w = old;
+    } else {
+      w = new (std::nothrow) mmh_context::StreamWs;
+      if (!w) return MMH_ERR_ALLOC;
+      ctx->ws.push_back(w);
+    }
+    w->stream = s;
+  }
+  w->stamp = ++ctx->ws_stamp;
+  if (cap) w->captured = true;
+  std::vector<void *> *retire = w->captured ? &ctx->retired : nullptr;
+  const size_t need = (size_t)tiles * sizeof(int);
+  if (need > w->flags.bytes) {
+    // (growing a set whose stream still runs a launch: hipFree waits for the device, so freeing is safe eagerly)
+    const int rc = w->flags.reserve(std::max(need, (size_t)(256u << 10)), retire);
     if (rc != MMH_OK) return rc;
-    ctx->flags_dirty = true;
+    w->flags_dirty = true;
   }
-  if (ctx->flags_dirty) {
-    HIP_TRY(hipMemsetAsync(ctx->flags.p, 0, ctx->flags.bytes, s));
-    // a fill recorded into a graph does not clean the buffer NOW: stay dirty until an eager launch
-    if (!cap) ctx->flags_dirty = false;
+  if (w->flags_dirty) {
+    // The kernels restore the zeros themselves (the part that finishes a tile resets its word), so the fill runs
+    // only when the buffer is new, has grown, or a launch may have died half-way (a sticky error was cleared).
+    HIP_TRY(hipMemsetAsync(w->flags.p, 0, w->flags.bytes, s));
+    if (!cap) w->flags_dirty = false;   // a fill recorded into a graph does not clean the buffer NOW
   }
-  *flags = static_cast<int *>(ctx->flags.p);
+  if (parts_bytes > w->parts.bytes) {
+    const int rc = w->parts.reserve(std::max(parts_bytes, (size_t)(16u << 20)), retire);
+    if (rc != MMH_OK) return rc;
+  }
+  *flags = static_cast<int *>(w->flags.p);
+  *parts = static_cast<float *>(w->parts.p);
   return MMH_OK;
 }
 
-int reserve_parts(mmh_context *ctx, size_t bytes, hipStream_t, float **parts) {
-  // (a buffer that has to grow while an eager launch on another stream still uses it: claim_workspaces has
-  // already ordered this stream behind that launch, but hipFree does not wait for streams -- retire it)
-  if (bytes > ctx->parts.bytes) {
-    const int rc = ctx->parts.reserve(std::max(bytes, (size_t)(64u << 20)), &ctx->retired);
-    if (rc != MMH_OK) return rc;
-  }
-  *parts = static_cast<float *>(ctx->parts.p);
-  return MMH_OK;
+void workspaces_suspect(mmh_context *ctx) {
+  for (auto *e : ctx->ws) e->flags_dirty = true;
 }
 
 // The two tables of a stream-K launch (streamk_body's `order` and `place`), per shape, cached in the handle.
@@ -188,11 +190,13 @@ int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s,
   for (auto *t : ctx->sk_tables)
     if (t->tiles == tiles && t->nk == nk && t->grid == grid && t->uploaded) {
       t->stamp = ++ctx->sk_stamp;
-      if (cap) {
-        // the graph must carry its own upload (the eager one is not ordered against the replay) and the
-        // entry must outlive it
-        t->pinned = true;
-        HIP_TRY(hipMemcpyAsync(t->buf.p, t->host, t->host_ints * sizeof(int), hipMemcpyHostToDevice, s));
+      if (cap) t->pinned = true;   // the entry must outlive the graph
+      if (cap || t->upload_stream != s) {
+        // a graph must carry its own upload (the eager one is not ordered against the replay), and a launch on
+        // another stream than the last upload's is not ordered behind that upload either: upload again, in THIS
+        // stream's order (the same bytes to the same place: harmless beside a launch that is reading them)
+        HIP_TRY(hipMemcpyAsync(t->buf.p, t->host, ((size_t)grid + (size_t)tiles) * sizeof(int), hipMemcpyHostToDevice, s));
+        if (!cap) t->upload_stream = s;
       }
       *order = static_cast<const int *>(t->buf.p);
       *place = *order + grid;
@@ -210,13 +214,9 @@ int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s,
   } else {
     for (auto *t : ctx->sk_tables)
       if (!t->pinned && (!slot || t->stamp < slot->stamp)) slot = t;
-    // the evicted tables may still be read by a launch in flight: wait for the streams that can hold one
+    // the evicted tables may still be read by a launch in flight on any stream
     if (!cap) {
-      HIP_TRY(hipStreamSynchronize(s));
-      if (ctx->ws_used && ctx->ws_stream != s && hipStreamSynchronize(ctx->ws_stream) != hipSuccess) {
-        (void)hipGetLastError();
-        HIP_TRY(hipDeviceSynchronize());
-      }
+      HIP_TRY(hipDeviceSynchronize());
     } else {
       // nothing may synchronise during capture: take a fresh entry instead
       slot = new (std::nothrow) mmh_context::SkTable;
@@ -249,6 +249,7 @@ int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s,
   slot->grid = grid;
   slot->stamp = ++ctx->sk_stamp;
   slot->uploaded = true;
+  slot->upload_stream = cap ? nullptr : s;
   slot->pinned = cap;
   *order = static_cast<const int *>(slot->buf.p);
   *place = *order + grid;
@@ -332,8 +333,7 @@ int warm_context(mmh_context *h) {
   if (rc == MMH_OK) {
     int *flags = nullptr;
     float *parts = nullptr;
-    rc = prepare_flags(h, 1 << 16, nullptr, &flags);
-    if (rc == MMH_OK) rc = reserve_parts(h, (size_t)(64u << 20), nullptr, &parts);
+    rc = workspace_for(h, nullptr, 1 << 16, (size_t)(64u << 20), &flags, &parts);   // the null stream's set
   }
   const hipError_t e = hipStreamSynchronize(nullptr);
   scratch.release();
@@ -352,8 +352,11 @@ void destroy_context(mmh_context *h) {
   h->a.release();
   h->b.release();
   h->c.release();
-  h->flags.release();
-  h->parts.release();
+  for (auto *e : h->ws) {
+    e->flags.release();
+    e->parts.release();
+    delete e;
+  }
   h->bt.release();
   h->qa.release();
   h->qb.release();
@@ -375,7 +378,6 @@ void destroy_context(mmh_context *h) {
     if (h->hs_run) (void)hipStreamDestroy(h->hs_run);
     if (h->hs_out) (void)hipStreamDestroy(h->hs_out);
   }
-  if (h->ws_event) (void)hipEventDestroy(h->ws_event);
   if (h->t0) (void)hipEventDestroy(h->t0);
   if (h->t1) (void)hipEventDestroy(h->t1);
   if (h->sticky) (void)hipHostFree(h->sticky);

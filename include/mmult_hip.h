@@ -133,10 +133,13 @@ int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
  * cuda/test_MMult.cpp:43-44).  mmh_warm does the same for a lazily created handle; it is idempotent.
  *
  * Streams.  Calls on ONE stream through one handle are ordered by the stream (as cublasHandle_t with
- * cublasSetStream).  A stream-K / split-K launch on ANOTHER stream than the handle's previous one is ordered
- * behind it on the device (an event, no host block) so that the workspaces are never in use twice -- which
- * costs the overlap: use one handle per stream that should run concurrently.  The handle keeps no claim on a
- * stream after the call returns: destroying a stream the handle has launched on is fine.
+ * cublasSetStream).  The stream-K / split-K workspaces exist once per stream the handle has launched on, so
+ * launches on different streams share nothing, may overlap, and need no ordering between them; the handle
+ * never touches a stream again once the call that launched on it has returned -- destroying a stream the
+ * handle has used is fine.  (More than eight streams per handle: the least recently used stream's set is
+ * released after a device-wide synchronisation.)  The other per-handle scratch (host-flavour staging, int8 /
+ * quantisation buffers) is NOT per stream: use one handle per host thread, and one handle per stream for
+ * mmh_sgemm_host / mmh_igemm_s8 / mmh_qgemm_f32 calls that should overlap.
  *
  * Progress guarantee.  Stream-K launches are persistent grids whose workgroups hand partial tiles to each
  * other, but a workgroup only ever waits for one that is ALREADY RUNNING and whose remaining work before the
@@ -149,11 +152,11 @@ int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
  * kernels wait for workgroups that may not be resident -- bounded, raising the sticky error below.
  *
  * hipGraphs.  After one eager call of a shape, launches capture into a graph: a captured stream-K launch
- * records the upload of its phase-order tables as a node of the graph and pins them, and from the first
- * capture on the handle never frees or moves a workspace a graph may point at (a buffer that must grow is
- * replaced, the old one lives as long as the handle).  A graph that contains stream-K launches owns the
- * handle's workspaces while it RUNS, like any buffer it was captured with: do not run the same handle
- * eagerly on another stream at the same time.  Every entry point runs on the handle's device and restores the
+ * records the upload of its phase-order tables as a node of the graph and pins them, and the capture stream's
+ * workspace set is never released -- a buffer of it that must grow is replaced, the old one lives as long as
+ * the handle.  A graph that contains stream-K launches owns the workspaces of the stream it was captured on
+ * while it RUNS, like any buffer it was captured with: do not launch eagerly on that same stream handle value
+ * from the same mmh handle while a replay may be in flight on another stream.  Every entry point runs on the handle's device and restores the
  * caller's current device before it returns. */
 int mmh_create(mmh_handle_t *handle, int device);
 int mmh_destroy(mmh_handle_t handle);
