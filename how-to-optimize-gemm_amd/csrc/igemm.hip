@@ -27,8 +27,9 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
     return MMH_OK;
   }
   // mode 7 (A/B switch while K3p is being measured): the ping-pong schedule of the 256x256 in-place kernel
-  if (h->igemm_mode == 7 && igemm_s8_inplace_ok(dA, lda, dB, ldb, k)) {
-    HIP_TRY(launch_igemm_s8_pp(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
+  if ((h->igemm_mode == 7 || h->igemm_mode == 8) && igemm_s8_inplace_ok(dA, lda, dB, ldb, k)) {
+    if (h->igemm_mode == 7) HIP_TRY(launch_igemm_s8_pp<4>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
+    else HIP_TRY(launch_igemm_s8_pp<2>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
     return MMH_OK;
   }
   // Default mode: operands the in-place kernel cannot take as they are (an odd leading dimension, a

@@ -37,7 +37,9 @@ __device__ __forceinline__ void ds_read_tr8_pair(uint32_t addr, pp_i32x2 &lo, pp
                : "v"(addr), "n"(OFF_LO), "n"(OFF_HI));
 }
 
-template <bool EDGE, bool DEQ>
+// PPS = phases per slice: 4 (16 MFMAs between barriers: one 64-row half of the wave tile per 64-deep step) or
+// 2 (32 MFMAs: the whole wave tile per step -- half the barriers per MFMA; the request schedule for it is in `phase2`).
+template <bool EDGE, bool DEQ, int PPS>
 __global__ void __launch_bounds__(512, 1)
 igemm_s8_pp_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda, const int8_t *__restrict__ B, int ldb,
                    int32_t *__restrict__ C, int ldc, int accumulate, int nbm, int nbn, const float *__restrict__ deq) {
@@ -134,11 +136,12 @@ igemm_s8_pp_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda, c
       bt_off[c][u] = (uint32_t)(c * STAGE + A_IMG + r * BN + 16 * ((4 * wn + u) ^ btr_swz(r)) + 8 * (li & 1));
   }
   typedef int i32x2 __attribute__((ext_vector_type(2)));
-  i32x4 fa[4], fb[TN];
-  auto read_a = [&](auto c_c, auto st_c, auto h_c) {   // A tiles 4 h .. 4 h + 3 of step st, buffer c
+  i32x4 fa[PPS == 2 ? 8 : 4], fb[TN];
+  auto read_a = [&](auto c_c, auto st_c, auto h_c) {   // A tiles 4 h .. 4 h + 3 of step st, buffer c (PPS 2: all eight)
     constexpr int CB_ = decltype(c_c)::value, ST = decltype(st_c)::value, H = decltype(h_c)::value;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const i32x4 *>(ilds + a_off[CB_][ST] + 16 * (4 * H + t) * IK);
+    for (int t = 0; t < (PPS == 2 ? 8 : 4); ++t)
+      fa[t] = *reinterpret_cast<const i32x4 *>(ilds + a_off[CB_][ST] + 16 * (4 * H + t) * IK);
   };
   // The transposing reads are spelled in inline asm: through the builtin hipcc cannot tell what the read may alias
   // and puts `s_waitcnt vmcnt(0)` in front of it whenever an LDS-DMA is in flight -- which here is always, by design.
@@ -158,6 +161,7 @@ igemm_s8_pp_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda, c
   constexpr std::integral_constant<int, 2> i2{};
   constexpr std::integral_constant<int, 3> i3{};
 
+  if constexpr (PPS == 4) {
   // ---- prologue: slice 0 whole, B0 and A0 of slice 1 -- six request groups, the two oldest landed ----
   request(i2, ilds, 0);
   request(i0, ilds, 0);
@@ -211,6 +215,56 @@ igemm_s8_pp_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda, c
     phase(kt + 1, i1, i2);
     phase(kt + 1, i1, i3);
   }
+  } else {
+  // ---- PPS == 2.  Request schedule, four pieces per wave and phase, issued at the TOP of the phase's R section:
+  //   phase 0 of slice t: A0 and A1 of slice t+1 (other buffer; its A regions were last read in slice t-1)
+  //   phase 1 of slice t: B1 of slice t+1 (other buffer), B0 of slice t+2 (this buffer, last read in phase 0)
+  // every region two or three phases ahead of its first reader; the wait, after the phase's own reads, is
+  // `vmcnt(4)`: everything but the four pieces just requested -- which is what the NEXT phase's reads need.
+  request(i2, ilds, 0);
+  request(i0, ilds, 0);
+  request(i1, ilds, 0);
+  request(i3, ilds, 0);
+  request(i2, ilds + STAGE, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+  auto phase2 = [&](int kt, auto cur_c, auto s_c) {
+    constexpr int CUR = decltype(cur_c)::value, S = decltype(s_c)::value;
+    constexpr std::integral_constant<int, CUR> cur{};
+    int8_t *mine = ilds + CUR * STAGE, *other = ilds + (CUR ^ 1) * STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S == 0) {
+      request(i0, other, kt + 1);
+      request(i1, other, kt + 1);
+    } else {
+      request(i3, other, kt + 1);
+      request(i2, mine, kt + 2);
+    }
+    read_a(cur, std::integral_constant<int, S>{}, i0);
+    read_b(cur, std::integral_constant<int, S>{});
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < TN; ++u) fb[u] = i32x4{fb_lo[u][0], fb_lo[u][1], fb_hi[u][0], fb_hi[u][1]};
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[u], fa[t], acc[t][u], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    phase2(kt, i0, i0);
+    phase2(kt, i0, i1);
+    phase2(kt + 1, i1, i0);
+    phase2(kt + 1, i1, i1);
+  }
+  }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // the older group's matching barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-length tail requests
 
@@ -236,6 +290,7 @@ igemm_s8_pp_kernel(int m, int n, int k, const int8_t *__restrict__ A, int lda, c
     }
 }
 
+template <int PPS>
 inline hipError_t launch_igemm_s8_pp(int m, int n, int k, const int8_t *A, int lda, const int8_t *B, int ldb, int32_t *C,
                                      int ldc, int acc, hipStream_t s, const float *deq = nullptr) {
   constexpr int BM = 256, BN = 256;
@@ -244,9 +299,9 @@ inline hipError_t launch_igemm_s8_pp(int m, int n, int k, const int8_t *A, int l
   const bool c_fast = (m % BM == 0) && (n % BN == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #define MMH_PP_LAUNCH(E, D)                                                                                           \
   do {                                                                                                                \
-    const hipError_t e = opt_in_big_lds(reinterpret_cast<const void *>(&igemm_s8_pp_kernel<E, D>), lds);              \
+    const hipError_t e = opt_in_big_lds(reinterpret_cast<const void *>(&igemm_s8_pp_kernel<E, D, PPS>), lds);              \
     if (e != hipSuccess) return e;                                                                                    \
-    hipLaunchKernelGGL((igemm_s8_pp_kernel<E, D>), dim3((unsigned)(nbm * nbn)), dim3(512), lds, s, m, n, k, A, lda, B, \
+    hipLaunchKernelGGL((igemm_s8_pp_kernel<E, D, PPS>), dim3((unsigned)(nbm * nbn)), dim3(512), lds, s, m, n, k, A, lda, B, \
                        ldb, C, ldc, acc, nbm, nbn, deq);                                                              \
   } while (0)
   if (deq) {

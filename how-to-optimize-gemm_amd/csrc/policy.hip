@@ -59,15 +59,35 @@ int auto_kernel(mmh_context *ctx, const GemmArgs &g) {
   // edge tiles pad the shape noticeably more than 128x128 tiles would (ragged tile COUNTS are balanced
   // by stream-K for either size).
   if (tiles256 >= cus && fill(tiles256, 65536.0) >= fill(tiles128, 16384.0) - 0.015) return MMH_KERNEL_MFMA_256X256;
-  // Below one 256x256 tile per CU (N < 4096 on the reference sweep) the LDS-DMA tiles (sgemm_dma.hpp), the
-  // choice measured on the sweep (profiles/r02_ablation.md): 128x128 from 1.15 tiles per CU (N >= 2304),
-  // 128x64 from 1.25 of those per CU (N >= 1664), 64x64 below -- each as a chained stream-K launch when
-  // worthwhile.
-  // two co-resident 128x64 workgroups per CU beat one 128x128 workgroup by 1-1.5 % once the launch
-  // is a phase-ordered stream-K (>= 1.8 tiles per workgroup of a 2-per-CU grid: N >= 2816)
+  // Below one 256x256 tile per CU (N < 4096 on the reference sweep) the LDS-DMA tiles (sgemm_dma.hpp).  Two
+  // co-resident 128x64 workgroups per CU under a phase-ordered stream-K launch (>= 1.8 tiles per workgroup of the
+  // 2-per-CU grid: N >= 2816) are the best form there is for these sizes (145-147 TFLOP/s, 1-1.5 % ahead of one
+  // 128x128 workgroup per CU).
   if (dma128x64 && tiles128x64 * 10 >= 2 * cus * 18) return MMH_KERNEL_MFMA_128X64_DMA;
-  if (dma128 && tiles128 * 100 >= cus * 115) return MMH_KERNEL_MFMA_128X128_DMA;
-  if (dma128x64 && tiles128x64 * 100 >= cus * 125) return MMH_KERNEL_MFMA_128X64_DMA;
+  // In between, the candidates are scored: (share of the tiles' area that is matrix -- an edge tile costs a whole
+  // tile's time) x (what the tile's loop sustains in the launch form it would get), the latter measured on the
+  // square sweep and on the off-grid sweep (profiles/r03_offgrid_vs_vendor.md; TFLOP/s):
+  //   128x128, stream-K or plain, one workgroup per CU, >= 1 tile per CU ................ 139
+  //   128x64, two workgroups per CU (>= 2 tiles per CU) .................................. 138 (whole rounds: 142)
+  //   128x64, ONE workgroup per CU (1 .. 2 tiles per CU: nobody to hide its stalls) ...... 124
+  //   64x64 with two workgroups per CU (2 .. 3 tiles per CU, stream-K or plain) .......... 130
+  // (64x64 with three workgroups per CU under a plain-order stream-K launch is erratic -- 97 .. 133 between
+  // N = 1800 and 2200, its ranges start at unrelated K phases and thrash L2 -- and is not a candidate here; with
+  // about one tile per CU it sustains ~104-117, which only the smallest shapes, below, settle for.)
+  // This is what keeps a shape one element past a tile boundary of the big tiles (N = 2049, 2177, 2433, 2561: 9-11 %
+  // of a 128x128 grid would be padding) on the tile that pads it least.
+  {
+    int best = -1;
+    double best_score = 0.0;
+    auto consider = [&](int kernel, bool ok, double score) {
+      if (ok && score > best_score) { best_score = score; best = kernel; }
+    };
+    consider(MMH_KERNEL_MFMA_128X128_DMA, dma128 && tiles128 >= cus, fill(tiles128, 16384.0) * 139.0);
+    consider(MMH_KERNEL_MFMA_128X64_DMA, dma128x64 && tiles128x64 * 100 >= cus * 125,
+             fill(tiles128x64, 8192.0) * (tiles128x64 >= 2 * cus ? (tiles128x64 % (2 * cus) == 0 ? 142.0 : 138.0) : 124.0));
+    consider(MMH_KERNEL_MFMA_64X64_DMA, dma64 && tiles64 >= 2 * cus && tiles64 < 3 * cus, fill(tiles64, 4096.0) * 130.0);
+    if (best >= 0) return best;
+  }
   if (dma64) return MMH_KERNEL_MFMA_64X64_DMA;
   // operands the descriptors cannot window (beyond 2 GiB), or the guarded LDS-DMA form switched off:
   // the register-staged tiles

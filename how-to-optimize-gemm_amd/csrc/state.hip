@@ -93,6 +93,25 @@ int workspace_for(mmh_context *ctx, hipStream_t s, long tiles, size_t parts_byte
   mmh_context::StreamWs *w = nullptr;
   for (auto *e : ctx->ws)
     if (e->stream == s) w = e;
+  const size_t need_flags = (size_t)tiles * sizeof(int);
+  if (cap && (!w || need_flags > w->flags.bytes || parts_bytes > w->parts.bytes)) {
+    // Nothing may be allocated while a stream is capturing.  A capture stream without a (large enough) set of its
+    // own BORROWS the most recently used set that is large enough -- normally the one the shape's eager warm-up
+    // call used -- which from now on belongs to the graph as well (see include/mmult_hip.h, hipGraphs).
+    w = nullptr;
+    for (auto *e : ctx->ws)
+      if (need_flags <= e->flags.bytes && parts_bytes <= e->parts.bytes && !e->flags_dirty && (!w || e->stamp > w->stamp)) w = e;
+    if (!w) {
+      set_last_error("a stream-K launch cannot allocate its workspaces while the stream is capturing: run the shape once "
+                     "eagerly (any stream) before capturing it");
+      return MMH_ERR_UNSUPPORTED;
+    }
+    w->captured = true;
+    w->stamp = ++ctx->ws_stamp;
+    *flags = static_cast<int *>(w->flags.p);
+    *parts = static_cast<float *>(w->parts.p);
+    return MMH_OK;
+  }
   if (!w) {
     size_t evictable = 0;
     for (auto *e : ctx->ws) evictable += e->captured ? 0 : 1;
@@ -202,6 +221,9 @@ int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s,
       *place = *order + grid;
       return MMH_OK;
     }
+  // nothing may be allocated while a stream is capturing: a shape that was never launched eagerly is captured
+  // with ranges in plain order (the identity tables are always right)
+  if (cap) return MMH_OK;
   // a new shape: a free entry, else the least recently used one that no graph points at; beyond 32 live
   // entries pinned ones only make the cache grow
   mmh_context::SkTable *slot = nullptr;

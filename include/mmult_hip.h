@@ -151,12 +151,14 @@ int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
  * (MMH_OPT_STREAMK_DELEGATIONS counts the hand-overs that took the slow path).  Only the OPT-IN split-K
  * kernels wait for workgroups that may not be resident -- bounded, raising the sticky error below.
  *
- * hipGraphs.  After one eager call of a shape, launches capture into a graph: a captured stream-K launch
- * records the upload of its phase-order tables as a node of the graph and pins them, and the capture stream's
- * workspace set is never released -- a buffer of it that must grow is replaced, the old one lives as long as
- * the handle.  A graph that contains stream-K launches owns the workspaces of the stream it was captured on
- * while it RUNS, like any buffer it was captured with: do not launch eagerly on that same stream handle value
- * from the same mmh handle while a replay may be in flight on another stream.  Every entry point runs on the handle's device and restores the
+ * hipGraphs.  After one eager call of a shape (on any stream), launches capture into a graph.  Nothing can be
+ * allocated while a stream is capturing, so a captured stream-K launch uses the workspace set of the capture
+ * stream if it has one that is large enough, and otherwise BORROWS the most recently used set that is --
+ * normally the one the eager call just used; it records the upload of its phase-order tables as a node of the
+ * graph and pins them (a shape that was never launched eagerly is captured with plain-order ranges).  A set a
+ * graph points at is never released; a buffer of it that must grow is replaced and the old one lives as long
+ * as the handle.  While a graph with stream-K launches RUNS it owns that set, like any buffer it was captured
+ * with: do not launch the same handle eagerly on the set's stream at the same time.  Every entry point runs on the handle's device and restores the
  * caller's current device before it returns. */
 int mmh_create(mmh_handle_t *handle, int device);
 int mmh_destroy(mmh_handle_t handle);
