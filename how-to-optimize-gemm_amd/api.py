@@ -283,9 +283,10 @@ class MMult:
         _check(lib().mmh_set_option(self._h, OPT_STREAMK, int(on)), "mmh_set_option")
 
     def set_igemm_mode(self, mode: int) -> None:
-        """0 B read in place (default; packed B for unaligned operands), tile picked by size; 1 in-kernel
-        transpose; 2 correctness-first kernel; 3 / 4 packed-B + LDS-DMA with 128x128 / 256x256 tiles;
-        5 / 6 in-place B likewise.  (10..13, timing-only ablations with wrong results, exist only in
+        """0 B read in place (default; packed B for unaligned operands): the ping-pong 256x256 kernel from one tile
+        per CU up, 128x128 tiles below; 1 in-kernel transpose; 2 correctness-first kernel; 3 / 4 packed-B + LDS-DMA
+        with 128x128 / 256x256 tiles; 5 / 6 the lockstep in-place kernel likewise; 7 / 8 the ping-pong kernel with
+        16 / 32 MFMAs per phase.  (10..13, timing-only ablations with wrong results, exist only in
         the tools build libmmult_hip_ab.so; the product library rejects them.)"""
         _check(lib().mmh_set_option(self._h, OPT_IGEMM_MODE, int(mode)), "mmh_set_option")
 

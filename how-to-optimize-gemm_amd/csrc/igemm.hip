@@ -27,7 +27,11 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
     return MMH_OK;
   }
   // mode 7 (A/B switch while K3p is being measured): the ping-pong schedule of the 256x256 in-place kernel
-  if ((h->igemm_mode == 7 || h->igemm_mode == 8) && igemm_s8_inplace_ok(dA, lda, dB, ldb, k)) {
+  // K3p (igemm_s8_pp.hpp): the 256x256 in-place tile with its wave groups in ping-pong -- what mode 0 runs from one
+  // tile per CU up (mode 8 forces it, 7 is its 16-MFMA-per-phase form; 6 stays the lockstep K3t kernel for A/B)
+  const int cus_ = h->cu_count > 0 ? h->cu_count : 256;
+  if (igemm_s8_inplace_ok(dA, lda, dB, ldb, k) &&
+      (h->igemm_mode == 7 || h->igemm_mode == 8 || (h->igemm_mode == 0 && igemm_s8_big_tile(m, n, cus_)))) {
     if (h->igemm_mode == 7) HIP_TRY(launch_igemm_s8_pp<4>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
     else HIP_TRY(launch_igemm_s8_pp<2>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
     return MMH_OK;
@@ -122,7 +126,10 @@ int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
   const int cus = h->cu_count > 0 ? h->cu_count : 256;
   if (h->igemm_mode == 0 && igemm_s8_inplace_ok(qa, ka, qb, nb, k)) {
     // the int8 GEMM dequantises in its epilogue: no int32 image of C at all
-    HIP_TRY(launch_igemm_s8_dequant(m, n, k, qa, ka, qb, nb, dC, ldc, scales, s, cus));
+    if (igemm_s8_big_tile(m, n, cus))
+      HIP_TRY(launch_igemm_s8_pp<2>(m, n, k, qa, ka, qb, nb, reinterpret_cast<int32_t *>(dC), ldc, 0, s, scales));
+    else
+      HIP_TRY(launch_igemm_s8_dequant(m, n, k, qa, ka, qb, nb, dC, ldc, scales, s, cus));
     return MMH_OK;
   }
   // two-pass form (A/B modes of the int8 kernel): int32 C, then the dequantisation pass

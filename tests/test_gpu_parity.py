@@ -483,7 +483,7 @@ def test_invalid_arguments_return_codes(mm):
     for kid in list(range(16, 20)) + list(range(21, 25)) + list(range(32, 45)):
         assert L.mmh_set_kernel(h, kid) == H.ERR_INVALID_ARG, kid
         assert H.kernel_name(kid) is None
-    for mode in (7, 10, 11, 12, 13, -1):
+    for mode in (9, 10, 11, 12, 13, -1):
         assert L.mmh_set_option(h, H.OPT_IGEMM_MODE, mode) == H.ERR_INVALID_ARG, mode
     assert L.mmh_set_option(h, H.OPT_SPLITK, 17) == H.ERR_INVALID_ARG
     assert L.mmh_set_option(h, H.OPT_HOST_PANELS, 99) == H.ERR_INVALID_ARG
@@ -618,10 +618,11 @@ def test_int8_bit_exact(mm, oracle):
     assert np.array_equal(out.cpu().numpy(), oracle.ref_igemm_s8(a, b, c0.copy()))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_int8_every_kernel_bit_exact(mm, oracle, mode):
     """Each int8 kernel forced in turn (MMH_OPT_IGEMM_MODE: 1 in-kernel transpose, 2 simple,
-    3 / 4 packed-B LDS-DMA with 128x128 / 256x256 tiles, 5 / 6 B read in place likewise) on whole, ragged and tiny shapes, odd and
+    3 / 4 packed-B LDS-DMA with 128x128 / 256x256 tiles, 5 / 6 B read in place likewise, 7 / 8 the ping-pong
+    schedule of the in-place 256x256 tile with 16 / 32 MFMAs per phase) on whole, ragged and tiny shapes, odd and
     even slice counts (k around multiples of 128 and 256)."""
     rng = np.random.default_rng(900 + mode)
     mm.set_igemm_mode(mode)
