@@ -9,9 +9,10 @@ already resident in HBM (the reference excludes H2D/D2H from its timed region
 too: cuda/test_MMult.cpp:85-98,121).
 
   N = 1  workload = BASELINE.json configs[2]: fp32 N=4096 square SGEMM on the
-         MFMA kernel (MMH_KERNEL_AUTO picks the 256x256-tile configuration of it
-         at this size) -- the configuration the headline metric ("% of MI355X
-         fp32 MFMA peak at N=4096") is quoted on.
+         MFMA kernel (MMH_KERNEL_AUTO picks the 64x64 LDS-DMA tile of it at this
+         size: sixteen tiles per CU, three workgroups co-resident) -- the
+         configuration the headline metric ("% of MI355X fp32 MFMA peak at
+         N=4096") is quoted on.
   N > 1  workload = configs[3]: fp32 N=16384, C row panels sharded over the N
          ranks (mmh_shard_rows), B replicated by one RCCL broadcast from rank 0
          BEFORE the timed region (it is data placement, the multi-GPU analogue
@@ -197,7 +198,7 @@ def live_traffic(n: int, kernel: str):
                 per_dispatch = {}
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     for r in csv.DictReader(open(f)):
-                        if "sgemm_" in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
+                        if "sgemm_" in r.get("Kernel_Name", "") and "naive" not in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
                             per_dispatch[r["Dispatch_Id"]] = per_dispatch.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
                 vals = [v for _, v in sorted(per_dispatch.items(), key=lambda kv: int(kv[0]))][2:]   # skip the cold ones
                 if not vals:

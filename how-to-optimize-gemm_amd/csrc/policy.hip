@@ -27,25 +27,23 @@ int auto_kernel(mmh_context *ctx, const GemmArgs &g) {
   // how much of the tiles' area is matrix (an edge tile costs a whole tile's time)
   auto fill = [&](long tiles, double area) { return (double)m * (double)n / ((double)tiles * area); };
   // The 64x64 LDS-DMA tile with three workgroups co-resident per CU has the most efficient loop of
-  // all (148.5-150 TFLOP/s at N = 3072, where 2304 tiles are exactly nine per CU; 151.6-152.9 at 5120 ..
-  // 8192 against 148.5-150.4 for the 256x256 tile) -- on a PLAIN launch: under the chained stream-K
-  // launch its workgroups run at different K phases and stop sharing operand slices in L2 (hit rate
-  // 81 % -> 22 %, 2.4 GB of fabric traffic per launch, profiles/r02_ablation.md section 9).  So it is
-  // chosen for shapes with many tiles (>= 6 per CU) that fill their last round of CUs to
-  // >= 97.5 % (N = 2688, 3072, 3200 on the reference sweep; 5120, 6144, 8192).
-  // One exception: whole rounds of 256x256 tiles in a SHORT launch (N = 4096: one tile per CU, 0.93 ms).
-  // Sustained the two are level there (148.5-149.4 vs 148.7-150.5), but from an idle clock the big
-  // tile is within 1 % of its rate after 18 launches and the small one after 40 -- and 20 launches
-  // from idle is what the reference's timing convention measures (137 vs 129 TFLOP/s,
-  // profiles/r02_cold_start.txt).
+  // all (148.5-150 TFLOP/s at N = 3072, where 2304 tiles are exactly nine per CU; 150.4-150.8 at 4096 and
+  // 151.6-152.9 at 5120 .. 8192 against 147.8-148.1 and 148.5-150.4 for the 256x256 tile) -- on a PLAIN launch:
+  // under the chained stream-K launch its workgroups run at different K phases and stop sharing operand slices
+  // in L2 (hit rate 81 % -> 22 %, 2.4 GB of fabric traffic per launch, profiles/r02_ablation.md section 9).  So it
+  // is chosen for shapes with many tiles (>= 6 per CU) that fill their last round of CUs to >= 97.5 %
+  // (N = 2688, 3072, 3200 and 4096 on the reference sweep; 5120, 6144, 8192).
+  // (Round 2 kept N = 4096 on the 256x256 tile because that tile follows the chip's clock ramp faster -- within
+  // 1 % of its sustained rate after 18 launches against 40, 137 vs 129 TFLOP/s over the first 20 launches from an
+  // idle clock, profiles/r02_cold_start.txt.  With launch #1 of a process no longer carrying 2 ms of one-offs
+  // (mmh_create warms the handle) either tile clears the 80 % target under the reference's no-warm-up convention,
+  // and the sustained rate -- what the headline metric quotes -- is the small tile's by 1.5 %.)
   {
     const long rounds64 = (tiles64 + cus - 1) / cus;
-    const double est_ms = 2.0 * (double)m * (double)n * (double)k / 150e9;
-    const bool whole_rounds_256 = tiles256 >= cus && tiles256 % cus == 0 && m % 256 == 0 && n % 256 == 0;
     // ... and only up to N = 8192-sized problems: with K = 16384 and B beyond the Infinity Cache the
     // small tile's two slices of look-ahead no longer cover its misses (2048 .. 16384 x 16384 x 16384:
     // 147.8 .. 140.0 against 150.9-151.1 for the 256x256 tile, which those shapes keep)
-    if (dma64 && !(whole_rounds_256 && est_ms < 2.0) && k <= 8192 && tiles64 <= 64 * cus && tiles64 >= 6 * cus &&
+    if (dma64 && k <= 8192 && tiles64 <= 64 * cus && tiles64 >= 6 * cus &&
         tiles64 * 1000 >= rounds64 * cus * 975 && fill(tiles64, 4096.0) >= 0.97)
       return MMH_KERNEL_MFMA_64X64_DMA;
   }
