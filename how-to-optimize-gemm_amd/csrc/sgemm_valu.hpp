@@ -52,6 +52,15 @@ sgemm_valu_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                       ? C[(size_t)row * ldc + col] : 0.0f;
     }
 
+  // Make the accumulators' initial values ARRIVE before the K loop starts.  Without this hipcc's wait-count pass
+  // carries "these registers may still be in flight" into the rolled k loop and puts `s_waitcnt vmcnt(0)` in
+  // front of the first FMA of EVERY slice -- where it also waits for the next slice's global loads, issued a few
+  // instructions earlier, to come back from L2 (seen in the round-2 build's ISA; 86 -> ~100 TFLOP/s at N = 4096).
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; j += 4) asm volatile("" : "+v"(acc[i][j]), "+v"(acc[i][j + 1]), "+v"(acc[i][j + 2]), "+v"(acc[i][j + 3]));
+
   Stage<BM, BN, THREADS, false, false, KB> st;
   const int nk = (k + KB - 1) / KB;
   if (nk > 0) {

@@ -24,13 +24,14 @@ declare -A CTRS
 CTRS[pmc1]="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 CTRS[pmc2]="SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
 CTRS[pmc3]="FETCH_SIZE"
+CTRS[pmc5]="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"   # VALU rung only (ask for it in PASSES)
 CTRS[pmc4]="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
 for p in $PASSES; do
   if [ "$p" = trace ]; then
     timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
     echo "trace rc=$?"
   else
-    timeout 180 rocprofv3 --kernel-trace --pmc ${CTRS[$p]} --output-format csv -d "$OUT/$p" -o pmc -- $BENCH --steps 3 --warmup 1 > "$OUT/$p.log" 2>&1
+    timeout ${PMC_TIMEOUT:-180} rocprofv3 --kernel-trace --pmc ${CTRS[$p]} --output-format csv -d "$OUT/$p" -o pmc -- $BENCH --steps 3 --warmup 1 > "$OUT/$p.log" 2>&1
     echo "$p rc=$? (${CTRS[$p]})"
   fi
 done
