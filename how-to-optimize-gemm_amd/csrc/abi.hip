@@ -133,6 +133,10 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       h->dma_edge = value ? 1 : 0;     //    for rows that are 16-byte aligned; 2 (default): for any 4-byte aligned rows
       h->dma_dword_rows = value >= 2 ? 1 : 0;
       return MMH_OK;
+    case MMH_OPT_RIM:
+      if (value < 0 || value > 16) return MMH_ERR_INVALID_ARG;
+      h->rim = value;
+      return MMH_OK;
 #ifdef MMH_AB_BUILD
     case 100:   // A/B: pin the residency of persistent launches by their LDS request (default on)
       h->pin = value ? 1 : 0;
@@ -163,6 +167,7 @@ int mmh_get_option(mmh_handle_t h, int option, int *value) {
       return MMH_OK;
     }
     case MMH_OPT_DMA_EDGE: *value = h->dma_edge ? (h->dma_dword_rows ? 2 : 1) : 0; return MMH_OK;
+    case MMH_OPT_RIM: *value = h->rim; return MMH_OK;
     case MMH_OPT_STREAMK_TIMEOUTS: {
       // synchronises, then reads the sticky word: how many hand-off waits have timed out on this
       // handle since it was last cleared

@@ -74,6 +74,9 @@ struct GemmArgs {
   int ldc;
   int acc;          // 0: C = A*B, 1: C = A*B + C
   hipStream_t s;
+  // "rim" launches (sgemm_dma.hpp): m x n above is the TRIMMED problem the tiles cover, rim_m x rim_n the whole
+  // one -- the strips in between run on the vector ALU in extra workgroups of the same launch.  0: no rim.
+  int rim_m = 0, rim_n = 0;
 };
 
 }  // namespace mmh
@@ -117,6 +120,7 @@ struct mmh_context {
   int sk_order = 1;            // stream-K launches get the phase-ordered range / tile tables
   int dma_edge = 1;            // ragged / 4-byte-aligned shapes may run the guarded LDS-DMA tiles (MMH_OPT_DMA_EDGE)
   int dma_dword_rows = 1;      // ... including operands whose rows are only 4-byte aligned (odd lda / ldb / base)
+  int rim = 8;                 // MMH_KERNEL_AUTO trims up to this many rows / columns past a 64-boundary off the tiles (MMH_OPT_RIM)
   // stream-K tables per launch shape (tiles, K-slices, grid): [order: grid ints][place: tiles ints]
   struct SkTable {
     long tiles = 0;

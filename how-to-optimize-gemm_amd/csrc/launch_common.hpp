@@ -42,6 +42,28 @@ inline int streamk_grid(long tiles, int cus, int per_cu) {
   return 0;
 }
 
+// Whether (and on how many persistent workgroups) a count of BM x BN tiles runs as a stream-K launch: 0 = the
+// plain one-workgroup-per-tile launch serves it.
+inline int streamk_wanted(const mmh_context *ctx, long tiles, int BM, int BN, int per_cu) {
+  const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+  const int grid = streamk_grid(tiles, cus, per_cu);
+  if (grid == 0 || tiles % grid == 0) return 0;   // too few tiles, or already balanced
+  if (tiles > (1L << 24)) return 0;
+  // Small tiles in nearly full rounds: the plain launch idles less than the hand-overs cost (measured,
+  // N = 1408 on 64x64 tiles: 484 tiles for 512 slots run 119 TFLOP/s plain, 109 under stream-K).  From
+  // 128x128 tiles up a hand-over is small beside a tile's work and stream-K wins whenever the count is
+  // ragged (N = 2816 / 3456 / 3968: 143 / 145 / 146.5 against 138 / 139 / 138 plain).
+  // (Balance is a matter of CUs, not of workgroup slots: co-resident workgroups share their CU's matrix pipe.)
+  // (The 128x64 tile counts as a big one once the launch is phase-ordered -- >= 1.8 tiles per workgroup,
+  // sk_tables_for -- N = 3968: 147.7 under stream-K, 141.9 plain.)
+  const bool ordered = ctx->sk_order && tiles * 10 >= (long)grid * 18;
+  if (ctx->streamk != 2 && BM * BN < 128 * 128 && !(ordered && BM * BN >= 128 * 64)) {   // MMH_OPT_STREAMK = 2: whenever ragged
+    const long rounds = (tiles + cus - 1) / cus;
+    if (tiles * 100 >= rounds * cus * 93) return 0;
+  }
+  return grid;
+}
+
 // Persistent chained stream-K launch: what is common to every tile code.  `kern` is the instantiation
 // to launch (`occ_kern` the one whose residency bounds the grid).  Returns MMH_OK if it launched, 1 if
 // the shape does not qualify (caller then uses the plain one-tile-per-workgroup launch).  `force`: launch
@@ -57,21 +79,8 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB,
     if (ok != MMH_OK) return ok;
   }
   const int per_cu = resident_per_cu(ctx, occ_kern, threads, lds);
-  const int grid = streamk_grid(tiles, cus, per_cu);
-  if (grid == 0 || tiles % grid == 0) return 1;   // too few tiles, or already balanced
-  if (tiles > (1L << 24)) return 1;
-  // Small tiles in nearly full rounds: the plain launch idles less than the hand-overs cost (measured,
-  // N = 1408 on 64x64 tiles: 484 tiles for 512 slots run 119 TFLOP/s plain, 109 under stream-K).  From
-  // 128x128 tiles up a hand-over is small beside a tile's work and stream-K wins whenever the count is
-  // ragged (N = 2816 / 3456 / 3968: 143 / 145 / 146.5 against 138 / 139 / 138 plain).
-  // (Balance is a matter of CUs, not of workgroup slots: co-resident workgroups share their CU's matrix pipe.)
-  // (The 128x64 tile counts as a big one once the launch is phase-ordered -- >= 1.8 tiles per workgroup,
-  // sk_tables_for -- N = 3968: 147.7 under stream-K, 141.9 plain.)
-  const bool ordered = ctx->sk_order && tiles * 10 >= (long)grid * 18;
-  if (ctx->streamk != 2 && BM * BN < 128 * 128 && !(ordered && BM * BN >= 128 * 64)) {   // MMH_OPT_STREAMK = 2: whenever ragged
-    const long rounds = (tiles + cus - 1) / cus;
-    if (tiles * 100 >= rounds * cus * 93) return 1;
-  }
+  const int grid = streamk_wanted(ctx, tiles, BM, BN, per_cu);
+  if (grid == 0) return 1;
   int *flags = nullptr;
   float *parts = nullptr;   // one partial-tile slot per range
   int rc = workspace_for(ctx, g.s, tiles, (size_t)grid * BM * BN * sizeof(float), &flags, &parts);

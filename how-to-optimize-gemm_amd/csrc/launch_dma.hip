@@ -25,7 +25,35 @@ int launch_dma_tile(mmh_context *ctx, const GemmArgs &g) {
   const int form = dma_form<BM, BN, KB>(ctx, g);
   if (form < 0) return 1;
   const bool edge = form == 1;
-  char what[192];
+  char what[224];
+  constexpr bool RIM_TILE = BN == 64 && ((BM == 64 && WTM == 2) || (BM == 128 && WTM == 4)) && WTN == 2;
+  if (g.rim_m && !RIM_TILE) return 1;
+  if constexpr (RIM_TILE) if (g.rim_m) {
+    // tiles of the trimmed shape + the rim's workgroups in ONE plain launch.  Only where the trimmed shape would
+    // be a plain launch anyway (the persistent stream-K grid owns every workgroup slot: nowhere for a rim to run)
+    const int nbm = (g.m + BM - 1) / BM, nbn = (g.n + BN - 1) / BN;
+    const long tiles = (long)nbm * nbn;
+    if (ctx && ctx->streamk) {
+      auto occ = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true>;
+      if (streamk_wanted(ctx, tiles, BM, BN, resident_per_cu(ctx, occ, T::THREADS, T::LDS_BYTES)) > 0) return 1;
+    }
+    const int rn = g.rim_n - g.n, rm = g.rim_m - g.m;
+    const long rim_elems = (((long)g.rim_m * rn + 63) / 64) * 64 + (long)rm * (((g.n + 63) / 64) * 64);
+    const long rim_blocks = (rim_elems + T::THREADS - 1) / T::THREADS;
+    if (tiles + rim_blocks > (1L << 30)) return 1;
+    auto kern = edge ? sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, true> : sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, false>;
+    const int ok = allow_big_lds(kern, T::LDS_BYTES);
+    if (ok != MMH_OK) return ok;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles + rim_blocks)), dim3(T::THREADS), T::LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda,
+                       g.B, g.ldb, g.C, g.ldc, g.acc, nbm, nbn, g.rim_m, g.rim_n);
+    HIP_TRY(hipGetLastError());
+    snprintf(what, sizeof what,
+             "sgemm_mfma_dma_rim_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by LDS-DMA, %s%ld workgroups of %d "
+             "threads on %d x %d + %ld on the rim (%d rows, %d columns, vector ALU)",
+             BM, BN, 16 * WTM, 16 * WTN, KB, NBUF, edge ? "guarded, " : "", tiles, T::THREADS, g.m, g.n, rim_blocks, rm, rn);
+    set_last_launch(what);
+    return MMH_OK;
+  }
   if (ctx && ctx->streamk) {
     auto kern = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false>;
     auto kern_edge = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true>;
@@ -62,6 +90,18 @@ int warm_dma_tile(mmh_context *ctx, float *scratch, hipStream_t s) {
   };
   if ((rc = plain(sgemm_mfma_dma_kernel<BM, BN, KB, WTM, WTN, NBUF, false>)) != MMH_OK) return rc;
   if ((rc = plain(sgemm_mfma_dma_kernel<BM, BN, KB, WTM, WTN, NBUF, true>)) != MMH_OK) return rc;
+  if constexpr (BN == 64) {   // the rim forms (AUTO only trims onto the 64-wide tiles)
+    auto rim = [&](auto kern) {
+      const int ok = allow_big_lds(kern, T::LDS_BYTES);
+      if (ok != MMH_OK) return ok;
+      hipLaunchKernelGGL(kern, dim3(2), dim3(T::THREADS), T::LDS_BYTES, s, BM, BN, KB, scratch, KB, scratch, BN + 1, scratch + 65536,
+                         BN + 1, 0, 1, 1, BM, BN + 1);
+      HIP_TRY(hipGetLastError());
+      return (int)MMH_OK;
+    };
+    if ((rc = rim(sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, false>)) != MMH_OK) return rc;
+    if ((rc = rim(sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, true>)) != MMH_OK) return rc;
+  }
   auto sk = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false>;
   auto ske = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true>;
   (void)resident_per_cu(ctx, ske, T::THREADS, T::LDS_BYTES);

@@ -431,6 +431,81 @@ sgemm_mfma_dma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   dma_stamp_after_stores(3);
 }
 
+// ---- the rim ------------------------------------------------------------------------------------------------
+// A shape a few elements past a tile boundary (N = 1025, 2049, 4097: `m % 64`, `n % 64` <= 8) would pay a whole
+// extra row AND column of tiles for one element each way -- 13 % more tile work at N = 1025 and, worse, a second
+// round of CUs for 33 of 289 tiles (80 TFLOP/s against 117 at N = 1024, profiles/r03_offgrid_vs_vendor.md).
+// sgemm_mfma_dma_rim_kernel runs the TRIMMED problem (m0 = m - m % 64, n0 = n - n % 64) on the MFMA tiles and
+// the rim -- the strip of columns n0 .. n-1 (all rows, corner included) and the strip of rows m0 .. m-1 (columns
+// below n0) -- on the vector ALU in a few extra workgroups of the same launch: one thread per C element, one
+// `v_fma_f32` chain over ascending k.  Same chain as the MFMA (which is what makes K1 and K2 agree bit for
+// bit), so the same bits.  Rim workgroups come last in dispatch order: wherever a CU has a workgroup slot free
+// (64x64 tiles: three slots per CU) they run beside the tiles; their chains are k dependent FMAs long, a
+// quarter of what a tile's K loop takes.
+//   bottom strip: a wave is 64 neighbouring columns of one row -- B's k-rows are read coalesced, A's row is
+//                 the same address for every lane;
+//   right strip:  a wave is 64 / rn rows x rn columns -- A rows are read 16 bytes per lane (k-contiguous;
+//                 the lines stay in L1 for the next eight reads), B's rim columns are a few addresses per wave.
+struct f32x4_any { float v[4]; } __attribute__((aligned(4)));   // 16 bytes at any dword address
+
+template <int THREADS>
+__device__ __forceinline__ void rim_body(int rim_block, int m, int n, int k, const float *__restrict__ A, int lda,
+                                         const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                                         bool accumulate, int m0, int n0) {
+  const int rn = n - n0, rm = m - m0;
+  const long right = (((long)m * rn + 63) / 64) * 64;          // the bottom strip starts on a wave boundary
+  const int n0r = ((n0 + 63) / 64) * 64;                        // ... and so does each of its rows
+  long e = (long)rim_block * THREADS + threadIdx.x;
+  int i, j;
+  if (e < right) {
+    if (rn == 0 || e >= (long)m * rn) return;
+    i = (int)(e / rn);
+    j = n0 + (int)(e % rn);
+  } else {
+    e -= right;
+    if (rm == 0 || e >= (long)rm * n0r) return;
+    i = m0 + (int)(e / n0r);
+    j = (int)(e % n0r);
+    if (j >= n0) return;
+  }
+  const float *__restrict__ a = A + (size_t)i * lda;
+  const float *__restrict__ b = B + j;
+  float *c = C + (size_t)i * ldc + j;
+  float acc = accumulate ? *c : 0.0f;
+  int kk = 0;
+  for (; kk + 8 <= k; kk += 8) {   // two 16-byte pieces of the A row and eight B values in flight per trip
+    const f32x4_any a0 = *reinterpret_cast<const f32x4_any *>(a + kk);
+    const f32x4_any a1 = *reinterpret_cast<const f32x4_any *>(a + kk + 4);
+    float bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bv[u] = b[(size_t)(kk + u) * ldb];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(a0.v[u], bv[u], acc);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(a1.v[u], bv[4 + u], acc);
+  }
+  for (; kk < k; ++kk) acc = __builtin_fmaf(a[kk], b[(size_t)kk * ldb], acc);
+  *c = acc;
+}
+
+// workgroups 0 .. nbm*nbn-1: the tiles of the trimmed problem (m0 x n0, as sgemm_mfma_dma_kernel); the rest: the rim
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false>
+__global__ void __launch_bounds__((BM / (16 * WTM)) * (BN / (16 * WTN)) * 64)
+sgemm_mfma_dma_rim_kernel(int m0, int n0, int k, const float *__restrict__ A, int lda, const float *__restrict__ B,
+                          int ldb, float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn, int m, int n) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tiles = nbm * nbn;
+  if ((int)blockIdx.x >= tiles) {
+    rim_body<(BM / (16 * WTM)) * (BN / (16 * WTN)) * 64>((int)blockIdx.x - tiles, m, n, k, A, lda, B, ldb, C, ldc,
+                                                         accumulate != 0, m0, n0);
+    return;
+  }
+  int tm, tn;
+  block_to_tile(blockIdx.x, tiles, nbm, nbn, tm, tn);
+  DmaSegment<BM, BN, KB, WTM, WTN, NBUF, false, EDGE>::run(lds, m0, n0, k, A, lda, B, ldb, C, ldc, tm, tn, 0,
+                                                           (k + KB - 1) / KB, accumulate != 0);
+}
+
 // Segment policy of this tile for the chained stream-K control flow (streamk_body in sgemm_mfma.hpp,
 // K2p) -- tile counts that do not divide the chip run as one persistent workgroup per CU over ranges
 // of (tile, K-slice) units, partial tiles handed over through the workspace: sgemm_dma_streamk_kernel.

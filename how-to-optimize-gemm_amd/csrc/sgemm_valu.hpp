@@ -23,7 +23,12 @@ namespace mmh {
 // BASELINE config 2 names) and <64,64,64> (4x4 per thread, 64-deep K-slices) for shapes with fewer
 // 128x128 tiles than CUs -- N = 1024 has 64 of them for 256 CUs; the small tile fills the chip at
 // the price of twice the LDS reads per FMA.  Same chain per element, same bits.
-template <int BM, int BN, int KB, bool EDGE>
+//
+// NBUF = 2: two LDS slices, one barrier per slice (64 KiB for either tile: two workgroups per CU = two waves
+// per SIMD).  NBUF = 1: one slice, the next one parked in registers across "barrier, store, barrier" (32 KiB:
+// the register file becomes the limit -- three waves per SIMD at 160 registers, five for the 64x64 tile); a
+// workgroup's barrier gap is filled by the CU's other workgroups.
+template <int BM, int BN, int KB, bool EDGE, int NBUF>
 __global__ void __launch_bounds__(256)
 sgemm_valu_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
                   const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
@@ -55,7 +60,8 @@ sgemm_valu_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   // Make the accumulators' initial values ARRIVE before the K loop starts.  Without this hipcc's wait-count pass
   // carries "these registers may still be in flight" into the rolled k loop and puts `s_waitcnt vmcnt(0)` in
   // front of the first FMA of EVERY slice -- where it also waits for the next slice's global loads, issued a few
-  // instructions earlier, to come back from L2 (seen in the round-2 build's ISA; 86 -> ~100 TFLOP/s at N = 4096).
+  // instructions earlier, to come back from L2 (seen in the round-2 build's ISA, tools/valu_isa.sh; N = 2048: 68.8 -> 76.4
+  // TFLOP/s, N = 4096 with two workgroups per CU to hide it: 88.1 -> 89.4).
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -77,7 +83,7 @@ sgemm_valu_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
       if (EDGE) st.load_edge(A, lda, B, ldb, row0, col0, (kt + 1) * KB, m, n, k, tid);
       else      st.load(A, lda, B, ldb, row0, col0, (kt + 1) * KB, tid);
     }
-    const float *As = lds + cur * (A_FLOATS + B_FLOATS);
+    const float *As = lds + (NBUF == 2 ? cur : 0) * (A_FLOATS + B_FLOATS);
     const float *Bs = As + A_FLOATS;
 #pragma unroll 4
     for (int kk = 0; kk < KB; ++kk) {
@@ -98,8 +104,9 @@ sgemm_valu_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_fmaf(a[i], b[j], acc[i][j]);
     }
+    if (NBUF == 1 && more) __syncthreads();   // everybody is done reading the one slice
     if (more) {
-      float *nxt = lds + (cur ^ 1) * (A_FLOATS + B_FLOATS);
+      float *nxt = lds + (NBUF == 2 ? (cur ^ 1) : 0) * (A_FLOATS + B_FLOATS);
       st.store(nxt, nxt + A_FLOATS, tid);
     }
     __syncthreads();
