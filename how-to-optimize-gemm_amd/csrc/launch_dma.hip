@@ -38,8 +38,8 @@ int launch_dma_tile(mmh_context *ctx, const GemmArgs &g) {
       if (streamk_wanted(ctx, tiles, BM, BN, resident_per_cu(ctx, occ, T::THREADS, T::LDS_BYTES)) > 0) return 1;
     }
     const int rn = g.rim_n - g.n, rm = g.rim_m - g.m;
-    const long rim_elems = (((long)g.rim_m * rn + 63) / 64) * 64 + (long)rm * (((g.n + 63) / 64) * 64);
-    const long rim_blocks = (rim_elems + T::THREADS - 1) / T::THREADS;
+    // one rim workgroup per 64 elements: a column's 64 rows / a row's 64 columns
+    const long rim_blocks = (long)rn * ((g.rim_m + 63) / 64) + (long)rm * ((g.n + 63) / 64);
     if (tiles + rim_blocks > (1L << 30)) return 1;
     auto kern = edge ? sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, true> : sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, false>;
     const int ok = allow_big_lds(kern, T::LDS_BYTES);

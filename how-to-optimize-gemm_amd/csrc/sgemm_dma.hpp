@@ -437,55 +437,116 @@ sgemm_mfma_dma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
 // round of CUs for 33 of 289 tiles (80 TFLOP/s against 117 at N = 1024, profiles/r03_offgrid_vs_vendor.md).
 // sgemm_mfma_dma_rim_kernel runs the TRIMMED problem (m0 = m - m % 64, n0 = n - n % 64) on the MFMA tiles and
 // the rim -- the strip of columns n0 .. n-1 (all rows, corner included) and the strip of rows m0 .. m-1 (columns
-// below n0) -- on the vector ALU in a few extra workgroups of the same launch: one thread per C element, one
-// `v_fma_f32` chain over ascending k.  Same chain as the MFMA (which is what makes K1 and K2 agree bit for
-// bit), so the same bits.  Rim workgroups come last in dispatch order: wherever a CU has a workgroup slot free
-// (64x64 tiles: three slots per CU) they run beside the tiles; their chains are k dependent FMAs long, a
-// quarter of what a tile's K loop takes.
-//   bottom strip: a wave is 64 neighbouring columns of one row -- B's k-rows are read coalesced, A's row is
-//                 the same address for every lane;
-//   right strip:  a wave is 64 / rn rows x rn columns -- A rows are read 16 bytes per lane (k-contiguous;
-//                 the lines stay in L1 for the next eight reads), B's rim columns are a few addresses per wave.
-struct f32x4_any { float v[4]; } __attribute__((aligned(4)));   // 16 bytes at any dword address
-
-template <int THREADS>
-__device__ __forceinline__ void rim_body(int rim_block, int m, int n, int k, const float *__restrict__ A, int lda,
-                                         const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+// below n0) -- on the vector ALU in extra workgroups of the same launch: one lane per C element, one `v_fma_f32`
+// chain over ascending k.  Same chain as the MFMA (which is what makes K1 and K2 agree bit for bit), so the same
+// bits.  Rim workgroups come last in dispatch order: wherever a CU has a workgroup slot free (64x64 tiles: three
+// slots per CU) they run beside the tiles.
+//
+// A chain is k dependent FMAs -- 4 cycles each, a quarter of what a tile's K loop takes -- but every link needs two
+// operands from memory, and one memory round trip (0.5-1 us under the tiles' traffic) per handful of links is
+// what a plain per-thread loop gets: the first version of this, eight k per trip from registers, made N = 1025
+// run at 28 TFLOP/s.  So the rim is ONE WAVE per workgroup (64 elements; the other waves leave at once) and the
+// workgroup's whole LDS allocation -- it is there anyway, the launch is sized for the tiles -- is that wave's
+// prefetch ring: five slots of 32 k, filled by LDS-DMA (no registers), 128 k in flight under a counted
+// `s_waitcnt vmcnt`, exactly the tiles' own scheme.  Per element and k the lane needs one value of its own
+// (x) and one the whole wave shares (u):
+//   right strip, unit (column c, 64 rows):  x = A[row][k]  (16-byte pieces along k, lane-linear: one
+//                                           ds_read_b128 per 4 k),  u = B[k][n0 + c]  (a dword per lane = 64 k);
+//   bottom strip, unit (row r, 64 columns): x = B[k][col]  (four k-rows of 64 columns per DMA instruction;
+//                                           ds_read_b32 per k),       u = A[m0 + r][k].
+// Descriptor extents turn rows past the end into zeros; links past k in the last slot are computed and dropped.
+template <int LDS_FLOATS>
+__device__ __forceinline__ void rim_body(float *lds, int unit, int m, int n, int k, const float *__restrict__ A,
+                                         int lda, const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                          bool accumulate, int m0, int n0) {
-  const int rn = n - n0, rm = m - m0;
-  const long right = (((long)m * rn + 63) / 64) * 64;          // the bottom strip starts on a wave boundary
-  const int n0r = ((n0 + 63) / 64) * 64;                        // ... and so does each of its rows
-  long e = (long)rim_block * THREADS + threadIdx.x;
+  if (threadIdx.x >= 64) return;
+  constexpr int KC = 32, SLOT = 64 * KC + 64;   // floats per slot: x image (KC x 64) + u (one dword per lane)
+  constexpr int R = 5, PER = KC / 4 + 1;        // ring slots; DMA instructions per slot
+  static_assert(R * SLOT <= LDS_FLOATS, "the rim's ring lives in the tile's LDS allocation");
+  static_assert((R - 1) * PER <= 63, "vmcnt is a 6-bit counter");
+  const int lane = threadIdx.x;
+  const int rn = n - n0;
+  const int row_blocks = (m + 63) / 64, col_blocks = (n0 + 63) / 64;
+  const bool right = unit < rn * row_blocks;
   int i, j;
-  if (e < right) {
-    if (rn == 0 || e >= (long)m * rn) return;
-    i = (int)(e / rn);
-    j = n0 + (int)(e % rn);
+  bool valid;
+  const float *xbase, *ubase;
+  uint32_t ext_x, ext_u, voff_x, voff_u, sx, su;
+  if (right) {
+    const int c = unit / row_blocks, row0 = (unit % row_blocks) * 64;
+    i = row0 + lane;
+    j = n0 + c;
+    valid = i < m;
+    xbase = A + (size_t)row0 * lda;
+    ext_x = (uint32_t)(((min(64, m - row0) - 1) * lda + k) * 4);
+    voff_x = (uint32_t)(lane * lda) * 4u;
+    sx = 4u;
+    ubase = B + j;
+    ext_u = (uint32_t)(((k - 1) * ldb + 1) * 4);
+    voff_u = (uint32_t)(lane * ldb) * 4u;
+    su = (uint32_t)ldb * 4u;
   } else {
-    e -= right;
-    if (rm == 0 || e >= (long)rm * n0r) return;
-    i = m0 + (int)(e / n0r);
-    j = (int)(e % n0r);
-    if (j >= n0) return;
+    const int u2 = unit - rn * row_blocks, col0 = (u2 % col_blocks) * 64;
+    i = m0 + u2 / col_blocks;
+    j = col0 + lane;
+    valid = j < n0;
+    xbase = B + col0;
+    ext_x = (uint32_t)(((k - 1) * ldb + min(64, n0 - col0)) * 4);
+    voff_x = (uint32_t)((lane >> 4) * ldb + 4 * (lane & 15)) * 4u;
+    sx = (uint32_t)ldb * 4u;
+    ubase = A + (size_t)i * lda;
+    ext_u = (uint32_t)(k * 4);
+    voff_u = (uint32_t)lane * 4u;
+    su = 4u;
   }
-  const float *__restrict__ a = A + (size_t)i * lda;
-  const float *__restrict__ b = B + j;
-  float *c = C + (size_t)i * ldc + j;
-  float acc = accumulate ? *c : 0.0f;
-  int kk = 0;
-  for (; kk + 8 <= k; kk += 8) {   // two 16-byte pieces of the A row and eight B values in flight per trip
-    const f32x4_any a0 = *reinterpret_cast<const f32x4_any *>(a + kk);
-    const f32x4_any a1 = *reinterpret_cast<const f32x4_any *>(a + kk + 4);
-    float bv[8];
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xbase), 0, ext_x, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ubase), 0, ext_u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t null_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xbase), 0, 0, 0x00020000);
+  float *c_ptr = C + (size_t)i * ldc + j;
+  float acc = (accumulate && valid) ? *c_ptr : 0.0f;
+  const int nchunks = (k + KC - 1) / KC;
+  auto issue = [&](int c) {   // chunk c into slot c % R (past the end: the same instructions against an empty descriptor)
+    float *slot = lds + (c % R) * SLOT;
+    const bool live = c < nchunks;
+    const uint32_t kc = (uint32_t)(c * KC);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) bv[u] = b[(size_t)(kk + u) * ldb];
+    for (int g = 0; g < KC / 4; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? rsrc_x : null_x, (__attribute__((address_space(3))) void *)(slot + 256 * g),
+                                               16, voff_x, (kc + 4u * g) * sx, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? rsrc_u : null_x, (__attribute__((address_space(3))) void *)(slot + 64 * KC), 4,
+                                             voff_u, kc * su, 0, 0);
+  };
+  for (int c = 0; c < R - 1; ++c) issue(c);
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot about to be refilled has been read
+    issue(c + R - 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * PER) : "memory");   // chunk c has landed
+    const float *slot = lds + (c % R) * SLOT;
+    const int kend = k - c * KC;   // links of this chunk that exist (>= KC: all)
+    float x[KC], u[KC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(a0.v[u], bv[u], acc);
+    for (int g = 0; g < KC / 4; ++g) {
+      const f32x4 uv = *reinterpret_cast<const f32x4 *>(slot + 64 * KC + 4 * g);
+      u[4 * g] = uv[0]; u[4 * g + 1] = uv[1]; u[4 * g + 2] = uv[2]; u[4 * g + 3] = uv[3];
+    }
+    if (right) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(a1.v[u], bv[4 + u], acc);
+      for (int g = 0; g < KC / 4; ++g) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(slot + 256 * g + 4 * lane);
+        x[4 * g] = xv[0]; x[4 * g + 1] = xv[1]; x[4 * g + 2] = xv[2]; x[4 * g + 3] = xv[3];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < KC; ++q) x[q] = slot[64 * q + lane];
+    }
+    // fmaf(a, b, acc) with a from A and b from B either way (the product is commutative bit for bit)
+#pragma unroll
+    for (int q = 0; q < KC; ++q) {
+      const float next = __builtin_fmaf(x[q], u[q], acc);
+      acc = q < kend ? next : acc;
+    }
   }
-  for (; kk < k; ++kk) acc = __builtin_fmaf(a[kk], b[(size_t)kk * ldb], acc);
-  *c = acc;
+  if (valid) *c_ptr = acc;
 }
 
 // workgroups 0 .. nbm*nbn-1: the tiles of the trimmed problem (m0 x n0, as sgemm_mfma_dma_kernel); the rest: the rim
@@ -496,8 +557,8 @@ sgemm_mfma_dma_rim_kernel(int m0, int n0, int k, const float *__restrict__ A, in
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tiles = nbm * nbn;
   if ((int)blockIdx.x >= tiles) {
-    rim_body<(BM / (16 * WTM)) * (BN / (16 * WTN)) * 64>((int)blockIdx.x - tiles, m, n, k, A, lda, B, ldb, C, ldc,
-                                                         accumulate != 0, m0, n0);
+    rim_body<DmaTile<BM, BN, KB, WTM, WTN, NBUF>::LDS_BYTES / 4>(lds, (int)blockIdx.x - tiles, m, n, k, A, lda, B, ldb, C, ldc,
+                                                                 accumulate != 0, m0, n0);
     return;
   }
   int tm, tn;
