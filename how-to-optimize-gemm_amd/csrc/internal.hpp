@@ -120,7 +120,7 @@ struct mmh_context {
   int sk_order = 1;            // stream-K launches get the phase-ordered range / tile tables
   int dma_edge = 1;            // ragged / 4-byte-aligned shapes may run the guarded LDS-DMA tiles (MMH_OPT_DMA_EDGE)
   int dma_dword_rows = 1;      // ... including operands whose rows are only 4-byte aligned (odd lda / ldb / base)
-  int rim = 8;                 // MMH_KERNEL_AUTO trims up to this many rows / columns past a 64-boundary off the tiles (MMH_OPT_RIM)
+  int rim = 0;                 // MMH_KERNEL_AUTO trims up to this many rows / columns past a 64-boundary off the tiles (MMH_OPT_RIM; off: measured, it does not pay)
   // stream-K tables per launch shape (tiles, K-slices, grid): [order: grid ints][place: tiles ints]
   struct SkTable {
     long tiles = 0;

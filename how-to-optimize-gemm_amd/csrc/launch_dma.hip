@@ -31,21 +31,27 @@ int launch_dma_tile(mmh_context *ctx, const GemmArgs &g) {
   if constexpr (RIM_TILE) if (g.rim_m) {
     // tiles of the trimmed shape + the rim's workgroups in ONE plain launch.  Only where the trimmed shape would
     // be a plain launch anyway (the persistent stream-K grid owns every workgroup slot: nowhere for a rim to run)
+    // and where every tile and every rim unit is resident from the start (see the kernel).
     const int nbm = (g.m + BM - 1) / BM, nbn = (g.n + BN - 1) / BN;
     const long tiles = (long)nbm * nbn;
-    if (ctx && ctx->streamk) {
-      auto occ = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true>;
-      if (streamk_wanted(ctx, tiles, BM, BN, resident_per_cu(ctx, occ, T::THREADS, T::LDS_BYTES)) > 0) return 1;
-    }
+    if (!ctx) return 1;
+    auto occ = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true>;
+    if (ctx->streamk && streamk_wanted(ctx, tiles, BM, BN, resident_per_cu(ctx, occ, T::THREADS, T::LDS_BYTES)) > 0) return 1;
+    auto occ_rim = sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, true>;
+    const int per_cu = resident_per_cu(ctx, occ_rim, T::THREADS, T::LDS_BYTES);
     const int rn = g.rim_n - g.n, rm = g.rim_m - g.m;
-    // one rim workgroup per 64 elements: a column's 64 rows / a row's 64 columns
-    const long rim_blocks = (long)rn * ((g.rim_m + 63) / 64) + (long)rm * ((g.n + 63) / 64);
-    if (tiles + rim_blocks > (1L << 30)) return 1;
+    // one rim workgroup per 16 elements: a column's 16 rows / a row's 16 columns
+    const long rim_blocks = (long)rn * ((g.rim_m + 15) / 16) + (long)rm * (g.n / 16);
+    if (tiles + rim_blocks > (long)per_cu * (ctx->cu_count > 0 ? ctx->cu_count : 256)) return 1;
     auto kern = edge ? sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, true> : sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, false>;
     const int ok = allow_big_lds(kern, T::LDS_BYTES);
     if (ok != MMH_OK) return ok;
+    int acc_word = g.acc;
+#ifdef MMH_AB_BUILD
+    if (const char *ab = getenv("MMH_AB_RIM")) acc_word |= !strcmp(ab, "only") ? 2 : !strcmp(ab, "none") ? 4 : 0;
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles + rim_blocks)), dim3(T::THREADS), T::LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda,
-                       g.B, g.ldb, g.C, g.ldc, g.acc, nbm, nbn, g.rim_m, g.rim_n);
+                       g.B, g.ldb, g.C, g.ldc, acc_word, nbm, nbn, g.rim_m, g.rim_n);
     HIP_TRY(hipGetLastError());
     snprintf(what, sizeof what,
              "sgemm_mfma_dma_rim_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by LDS-DMA, %s%ld workgroups of %d "

@@ -127,9 +127,9 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
         if (sk <= 0) return sk;
       }
     }
-    // A few rows / columns past a 64-boundary (N = 1025, 2049, 4097): the tiles take the trimmed shape, the rim runs on
-    // the vector ALU in the same launch (sgemm_dma.hpp, "the rim") -- where the trimmed shape is a plain launch of the
-    // 64-wide LDS-DMA tiles; otherwise the whole shape goes the usual way, edge tiles and all.
+    // MMH_OPT_RIM (off by default): a few rows / columns past a 64-boundary (N = 1025): the tiles take the trimmed shape,
+    // the rim runs on the vector ALU in the same launch (sgemm_dma.hpp, "the rim") -- where the trimmed shape is a
+    // one-round plain launch of the 64-wide LDS-DMA tiles; otherwise the whole shape goes the usual way, edge tiles and all.
     if (ctx && ctx->rim > 0) {
       const int rm = m % 64, rn = n % 64;
       if ((rm || rn) && rm <= ctx->rim && rn <= ctx->rim && m - rm >= 256 && n - rn >= 256 && k >= 64) {

@@ -221,11 +221,14 @@ int mmh_kernel_id(const char *short_name);
  * persistent grids are co-resident; > 0 says a launch ran with part of its grid queued -- correct, only slower.
  * get synchronises the device. */
 #define MMH_OPT_STREAMK_DELEGATIONS 10
-/* MMH_OPT_RIM (default 8, 0 = off, at most 16): MMH_KERNEL_AUTO runs a shape whose m and n are at most this many rows /
- * columns past a multiple of 64 (N = 1025, 2049, 4097) as the tiles of the TRIMMED shape plus "the rim" -- the thin
- * strips of C beyond it, computed on the vector ALU by extra workgroups of the same launch (one fused-multiply-add
- * chain over ascending k per element: the same bits as the tiles) -- instead of paying a whole extra row and column of
- * edge tiles.  Applies where the trimmed shape is a plain launch of the 64-wide LDS-DMA tiles (sgemm_dma.hpp). */
+/* MMH_OPT_RIM (default 0 = off, at most 16; an experiment that is kept for its measurements, profiles/r03_notes.md
+ * section 6): MMH_KERNEL_AUTO runs a shape whose m and n are at most this many rows / columns past a multiple of 64
+ * (N = 1025) as the tiles of the TRIMMED shape plus "the rim" -- the thin strips of C beyond it, computed on the vector
+ * ALU by extra workgroups of the same launch (one fused-multiply-add chain over ascending k per element: the same bits
+ * as the tiles) -- instead of paying a whole extra row and column of edge tiles.  Applies where the trimmed shape is a
+ * plain launch of the 64-wide LDS-DMA tiles (sgemm_dma.hpp) and tiles and rim units are all resident at once.  Off by
+ * default because it does not pay: alone the tiles of 1024 x 1024 x 1025 take 20 us and the rim 13 us, together 28-29 us
+ * -- against 27 us for the plain launch of 17 x 17 edge tiles. */
 #define MMH_OPT_RIM 11
 int mmh_set_option(mmh_handle_t handle, int option, int value);
 /* The two tables of a phase-ordered stream-K launch (MMH_OPT_STREAMK_ORDER) for `tiles` tile slots of `nk`
