@@ -43,8 +43,13 @@ int auto_kernel(mmh_context *ctx, const GemmArgs &g) {
     // ... and only up to N = 8192-sized problems: with K = 16384 and B beyond the Infinity Cache the
     // small tile's two slices of look-ahead no longer cover its misses (2048 .. 16384 x 16384 x 16384:
     // 147.8 .. 140.0 against 150.9-151.1 for the 256x256 tile, which those shapes keep)
-    if (dma64 && k <= 8192 && tiles64 <= 64 * cus && tiles64 >= 6 * cus &&
-        tiles64 * 1000 >= rounds64 * cus * 975 && fill(tiles64, 4096.0) >= 0.97)
+    // (Ragged shapes: what counts is padding no worse than the alternative's -- one element past a 64-boundary pads
+    // a 64x64 grid by 4-5 % and a 128x64 grid by 6-7 %: N = 2817, 3329, 3457, 3585 read 137.5 / 141.3 / 140.2 / 140.4 here
+    // against 133.1 / 135.8 / 137.4 / 138.1 under the 128x64 stream-K launch, profiles/r03_offgrid_vs_vendor.md; 39 x 39
+    // tiles at N = 2433 are 5.94 per CU: 134.3 against 126.8.)
+    if (dma64 && k <= 8192 && tiles64 <= 64 * cus && tiles64 * 100 >= 590 * cus &&
+        tiles64 * 1000 >= rounds64 * cus * 975 &&
+        (fill(tiles64, 4096.0) >= 0.97 || fill(tiles64, 4096.0) >= fill(tiles128x64, 8192.0) + 0.015))
       return MMH_KERNEL_MFMA_64X64_DMA;
   }
   // a ragged count of 256x256 tiles would run as stream-K with ~1.1-1.2 tiles per workgroup; the 128x64
