@@ -20,7 +20,7 @@
 // (0,0) (0,1) (1,0) (1,1), B fragments read in the half-0 phases and kept for half 1.  Request schedule --
 // phase 0: A1 of slice t+1, 1: B1 of t+1, 2: B0 of t+2, 3: A0 of t+2 -- each into the buffer region whose
 // readers finished >= 1 phase (and one lgkmcnt(0) + barrier) earlier.
-// Measured (profiles/r03_igemm_s8.md; M = N = 4096, K swept, us per launch = fixed + slope x K): K3t 16.8 us + 3.05 POPS
+// Measured (profiles/r03_igemm_s8_ksweep.txt, r03_notes.md section 4; M = N = 4096, K swept, us per launch = fixed + slope x K): K3t 16.8 us + 3.05 POPS
 // in the loop; this kernel with 16 MFMAs per phase 3.1, with 32 MFMAs per phase (PPS = 2, what ships) 17.1 us +
 // 3.18 POPS = 0.83 of what the matrix pipe sustains on random operands at the power-managed clock (3.84 POPS).  The
 // fixed part -- launch, prologue and above all the 64 MB C store, which nothing can overlap with one tile per CU

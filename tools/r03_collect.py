@@ -45,12 +45,12 @@ cp(os.path.join("i8prof", "summary.json"), "r03_igemm_s8_rocprofv3.json")
 cp(os.path.join("qprof", "summary.json"), "r03_qgemm_rocprofv3.json")
 cp("i8_ksweep.txt", "r03_igemm_s8_ksweep.txt")
 cp("i8_ab.txt", "r03_igemm_s8_ab.txt")
-# pieces of the earlier calls of the round that the notes cite
-cp(os.path.join("r03a", "probe_align.txt"), "r03_lds_dma_align_probe.txt", OUT)
-cp(os.path.join("r03d", "offgrid_steps.md"), "r03_offgrid_steps_recheck.md", OUT)
-cp(os.path.join("r03c", "ab_r02.txt"), "r03_streamk_ab_vs_r02.txt", OUT)
-cp(os.path.join("r03e", "i8_ld_probe.txt"), "r03_igemm_s8_ld_probe.txt", OUT)
-cp(os.path.join("r03f", "i8_ksweep.txt"), "r03_igemm_s8_ksweep_with_nt_stores.txt", OUT)
+# pieces of the other calls of the round that the notes cite
+cp(os.path.join("r03o", "probe_align.txt"), "r03_lds_dma_align_probe.txt", OUT)
+cp(os.path.join("r03o", "ab_r02.txt"), "r03_streamk_ab_vs_r02.txt", OUT)
+cp(os.path.join("r03o", "i8_ld_probe.txt"), "r03_igemm_s8_ld_probe.txt", OUT)
+cp(os.path.join("r03n", "rim_ab.md"), "r03_rim_ab.md", OUT)
+cp(os.path.join("r03k", "harness_2944_context.txt"), "r03_harness_2944_context.txt", OUT)
 
 # roofline.traffic: FETCH_SIZE (KiB, x2 on gfx950 for 16 B/lane coalesced reads) + WRITE_SIZE (KiB)
 traffic = {}
