@@ -51,6 +51,7 @@ cp(os.path.join("r03o", "ab_r02.txt"), "r03_streamk_ab_vs_r02.txt", OUT)
 cp(os.path.join("r03o", "i8_ld_probe.txt"), "r03_igemm_s8_ld_probe.txt", OUT)
 cp(os.path.join("r03n", "rim_ab.md"), "r03_rim_ab.md", OUT)
 cp(os.path.join("r03k", "harness_2944_context.txt"), "r03_harness_2944_context.txt", OUT)
+cp(os.path.join("r03p", "eight_sweeps.txt"), "r03_eight_sweeps_ref_skip.txt", OUT)
 
 # roofline.traffic: FETCH_SIZE (KiB, x2 on gfx950 for 16 B/lane coalesced reads) + WRITE_SIZE (KiB)
 traffic = {}
