@@ -49,7 +49,7 @@ EXPORTS = [
     "mmh_shard_unpin",
     "mmh_rccl_version",
     "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_time_comparator", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
-    "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy", "mmh_probe_hbm_read", "mmh_probe_lds_read", "mmh_streamk_plan",
+    "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy", "mmh_probe_hbm_read", "mmh_probe_lds_read", "mmh_streamk_plan", "mmh_auto_plan",
 ]
 
 
@@ -83,6 +83,16 @@ def streamk_plan(tiles: int, nk: int, grid: int):
     _check(lib().mmh_streamk_plan(tiles, nk, grid, order.ctypes.data_as(C.POINTER(C.c_int)),
                                   place.ctypes.data_as(C.POINTER(C.c_int))), "mmh_streamk_plan")
     return order, place
+
+
+def auto_plan(m: int, n: int, k: int, lda: int = 0, ldb: int = 0, ldc: int = 0, base_align: int = 16, cu_count: int = 256):
+    """What MMH_KERNEL_AUTO would run for a shape (host arithmetic only, no device): (short kernel name, tiles,
+    stream-K grid) -- grid 0 = one workgroup per tile, -1 = needs the device's occupancy query."""
+    kern, grid, tiles = C.c_int(), C.c_int(), C.c_long()
+    _check(lib().mmh_auto_plan(m, n, k, lda or k, ldb or n, ldc or n, base_align, cu_count, C.byref(kern), C.byref(tiles),
+                               C.byref(grid)), "mmh_auto_plan")
+    names = {v: name for name, v in KERNELS.items() if name != "mfma256"}
+    return names.get(kern.value, str(kern.value)), tiles.value, grid.value
 
 
 def use_timeline_library() -> str:
@@ -176,6 +186,7 @@ def lib() -> C.CDLL:
     L.mmh_probe_hbm_read.argtypes = [vp, C.c_size_t, fp]
     L.mmh_probe_lds_read.argtypes = [vp, C.c_int, fp]
     L.mmh_streamk_plan.argtypes = [C.c_long, C.c_int, C.c_int, ip, ip]
+    L.mmh_auto_plan.argtypes = [C.c_int] * 8 + [ip, C.POINTER(C.c_long), ip]
     L.mmh_probe_mfma_f32.argtypes = [vp, fp]
     L.mmh_probe_mfma_i8.argtypes = [vp, fp]
     L.mmh_probe_mfma_i8_sustained.argtypes = [vp, C.c_int, C.c_float, fp]
@@ -645,7 +656,7 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
 
 
 __all__ = ["MMult", "ShardedMMult", "MMultError", "lib", "use_ab_library", "device_count", "rccl_version", "shard_rows",
-           "kernel_name", "last_launch", "use_timeline_library", "streamk_plan", "sgemm_sharded", "KERNELS", "CHAIN_KERNELS", "AB_LIB_PATH",
+           "kernel_name", "last_launch", "use_timeline_library", "streamk_plan", "auto_plan", "sgemm_sharded", "KERNELS", "CHAIN_KERNELS", "AB_LIB_PATH",
            "OPT_SPLITK", "OPT_HOST_PANELS", "OPT_STREAMK_SPIN_LIMIT", "OPT_FAULT_INJECT", "OPT_STREAMK_ORDER", "OPT_DMA_EDGE", "OPT_STREAMK_DELEGATIONS", "OPT_RIM", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
            "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OPT_IGEMM_MODE", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

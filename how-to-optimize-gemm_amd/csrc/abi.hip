@@ -317,4 +317,9 @@ int mmh_streamk_plan(long tiles, int nk, int grid, int *order, int *place) {
   return build_sk_tables(tiles, nk, grid, order, place) ? MMH_OK : MMH_ERR_INVALID_ARG;
 }
 
+int mmh_auto_plan(int m, int n, int k, int lda, int ldb, int ldc, int base_align, int cu_count, int *kernel, long *tiles,
+                  int *streamk_grid) {
+  return mmh::auto_plan(m, n, k, lda, ldb, ldc, base_align, cu_count, kernel, tiles, streamk_grid);
+}
+
 }  // extern "C"

@@ -187,6 +187,8 @@ bool build_sk_tables(long tiles, int nk, int grid, int *order, int *place);
 int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place);
 
 // ---- the kernel families (each returns MMH_OK, an error, or 1 = "this shape does not qualify") ----
+int auto_plan(int m, int n, int k, int lda, int ldb, int ldc, int base_align, int cu_count, int *kernel, long *tiles,
+              int *streamk_grid);   // policy.hip: mmh_auto_plan
 int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA, int lda, const float *dB, int ldb,
              float *dC, int ldc, int accumulate, hipStream_t s);
 // launch_reg.hip: `kernel` is one of the register-staged ids (MFMA, MFMA_TILES, MFMA_256, MFMA_256X256, MFMA_128X64,

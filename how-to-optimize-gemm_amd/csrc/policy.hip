@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "internal.hpp"
+#include "launch_common.hpp"   // streamk_wanted
 
 namespace mmh {
 
@@ -198,6 +199,37 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
     default:
       return launch_reg(ctx, kernel, g);
   }
+}
+
+// What MMH_KERNEL_AUTO would do with a shape, as host arithmetic (mmh_auto_plan: no device, no launch): the tile it
+// picks and, for the tiles whose residency the LDS alone decides, whether the launch would be the persistent
+// stream-K form.  Uses the very functions the launch path uses (auto_kernel, streamk_wanted) on a default handle.
+int auto_plan(int m, int n, int k, int lda, int ldb, int ldc, int base_align, int cu_count, int *kernel, long *tiles,
+              int *streamk_grid) {
+  if (m <= 0 || n <= 0 || k <= 0 || lda < k || ldb < n || ldc < n) return MMH_ERR_INVALID_ARG;
+  mmh_context ctx;
+  ctx.cu_count = cu_count > 0 ? cu_count : 256;
+  // addresses that are never dereferenced: a 16-byte (or only 4-byte) aligned base for each operand
+  const uintptr_t base = (uintptr_t)1 << 32, off = base_align >= 16 ? 0 : 4;
+  const GemmArgs g{m, n, k, reinterpret_cast<const float *>(base + off), lda,
+                   reinterpret_cast<const float *>(2 * base + off), ldb, reinterpret_cast<float *>(3 * base + off), ldc, 0, nullptr};
+  const int kern = auto_kernel(&ctx, g);
+  int bm = 0, bn = 0, per_cu = 0;
+  switch (kern) {
+    case MMH_KERNEL_MFMA_64X64_DMA: bm = 64; bn = 64; per_cu = 3; break;     // 48 KiB ring
+    case MMH_KERNEL_MFMA_128X64_DMA: bm = 128; bn = 64; per_cu = 2; break;   // 72 KiB
+    case MMH_KERNEL_MFMA_128X128_DMA: bm = 128; bn = 128; per_cu = 1; break; // 96 KiB
+    case MMH_KERNEL_MFMA_256X256: bm = 256; bn = 256; per_cu = 1; break;     // 128 KiB
+    case MMH_KERNEL_MFMA: bm = 128; bn = 128; break;
+    case MMH_KERNEL_MFMA_128X64: bm = 128; bn = 64; break;
+    case MMH_KERNEL_MFMA_64X64: bm = 64; bn = 64; break;
+    default: break;
+  }
+  if (kernel) *kernel = kern;
+  const long t = bm ? (long)((m + bm - 1) / bm) * ((n + bn - 1) / bn) : 0;
+  if (tiles) *tiles = t;
+  if (streamk_grid) *streamk_grid = per_cu ? streamk_wanted(&ctx, t, bm, bn, per_cu) : -1;
+  return MMH_OK;
 }
 
 }  // namespace mmh

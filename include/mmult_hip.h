@@ -235,6 +235,15 @@ int mmh_set_option(mmh_handle_t handle, int option, int value);
  * K-slices on `grid` persistent workgroups, computed on the host (no device needed): order[grid] = the range
  * each chip position takes, place[tiles] = the tile computed in each slot.  For tests and tools. */
 int mmh_streamk_plan(long tiles, int nk, int grid, int *order, int *place);
+/* What MMH_KERNEL_AUTO would run for a shape -- the reference's `NEW := MMult_xxx` makefile choice (cuda/makefile:1-3)
+ * made per call -- computed on the host by the launch path's own functions (no device needed, nothing launched):
+ * *kernel = the MMH_KERNEL_* id of the tile, *tiles = how many of them the shape takes (edge tiles included),
+ * *streamk_grid = the persistent workgroups of a stream-K launch, 0 for one workgroup per tile, -1 where the answer
+ * needs the device's occupancy query (the register-staged 128x128 / 128x64 / 64x64 tiles).  base_align: 16 or 4, the
+ * alignment of the operands' base addresses; cu_count <= 0: 256.  Handle options at their defaults.  For tests,
+ * tools and callers that want to know before they launch. */
+int mmh_auto_plan(int m, int n, int k, int lda, int ldb, int ldc, int base_align, int cu_count, int *kernel, long *tiles,
+                  int *streamk_grid);
 int mmh_get_option(mmh_handle_t handle, int option, int *value);
 
 /* The hot path ------------------------------------------------------------ */

@@ -403,3 +403,29 @@ def test_the_rim_runs_on_the_vector_alu_with_the_tiles_bits(oracle):
             mm.set_option(H.OPT_RIM, 17)
     finally:
         mm.close()
+
+
+def test_the_host_plan_is_what_the_device_launches(mm):
+    """mmh_auto_plan (host arithmetic, tests/test_auto_plan.py) against mmh_last_launch after a real launch, on the
+    device's own CU count: tile, tile count and launch form."""
+    import re
+    import torch
+    import how_to_optimize_gemm_amd as H
+    fam = {("mfma_dma", "64,64"): "mfma_64x64_dma", ("dma_streamk", "64,64"): "mfma_64x64_dma",
+           ("mfma_dma", "128,64"): "mfma_128x64_dma", ("dma_streamk", "128,64"): "mfma_128x64_dma",
+           ("mfma_dma", "128,128"): "mfma_128x128_dma", ("dma_streamk", "128,128"): "mfma_128x128_dma",
+           ("mfma", "256,256"): "mfma_256x256", ("mfma_streamk", "256,256"): "mfma_256x256"}
+    mm.set_kernel("auto")
+    cus = mm.device_info()["cu_count"]
+    for (m, n, k) in [(1024, 1024, 64), (1152, 1152, 96), (2048, 2048, 64), (2304, 2304, 64), (2817, 2817, 40), (3584, 3584, 64),
+                      (4096, 4096, 64), (4000, 4000, 40), (300, 5000, 70), (8192, 1024, 64), (1023, 1025, 33)]:
+        a = torch.rand((m, k), device="cuda")
+        b = torch.rand((k, n), device="cuda")
+        mm.matmul(a, b)
+        text = H.last_launch()
+        g = re.match(r"sgemm_(\w+)_kernel<(\d+,\d+)>", text)
+        sk = re.search(r"(\d+) tiles on (\d+) persistent", text)
+        got = (fam[(g.group(1), g.group(2))],) + ((int(sk.group(1)), int(sk.group(2))) if sk else
+                                                   (int(re.search(r"(\d+) workgroups", text).group(1)), 0))
+        assert H.auto_plan(m, n, k, cu_count=cus) == got, (m, n, k, text)
+    mm.set_kernel("mfma")
