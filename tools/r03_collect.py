@@ -52,6 +52,10 @@ cp(os.path.join("r03o", "i8_ld_probe.txt"), "r03_igemm_s8_ld_probe.txt", OUT)
 cp(os.path.join("r03n", "rim_ab.md"), "r03_rim_ab.md", OUT)
 cp(os.path.join("r03k", "harness_2944_context.txt"), "r03_harness_2944_context.txt", OUT)
 cp(os.path.join("r03p", "eight_sweeps.txt"), "r03_eight_sweeps_ref_skip.txt", OUT)
+cp(os.path.join("r03s", "prof2304_summary.json"), "r03_sgemm2304_dma_streamk128x128_rocprofv3.json", OUT)
+cp(os.path.join("r03s", "prof1152_summary.json"), "r03_sgemm1152_dma_streamk64x64_rocprofv3.json", OUT)
+cp(os.path.join("r03s", "prof1024_summary.json"), "r03_sgemm1024_dma64x64_rocprofv3.json", OUT)
+cp(os.path.join("r03s", "prof4096_valu_summary.json"), "r03_sgemm4096_valu128x128_rocprofv3.json", OUT)
 
 # roofline.traffic: FETCH_SIZE (KiB, x2 on gfx950 for 16 B/lane coalesced reads) + WRITE_SIZE (KiB)
 traffic = {}
