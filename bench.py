@@ -9,8 +9,8 @@ already resident in HBM (the reference excludes H2D/D2H from its timed region
 too: cuda/test_MMult.cpp:85-98,121).
 
   N = 1  workload = BASELINE.json configs[2]: fp32 N=4096 square SGEMM on the
-         MFMA kernel (MMH_KERNEL_AUTO picks the 64x64 LDS-DMA tile of it at this
-         size: sixteen tiles per CU, three workgroups co-resident) -- the
+         MFMA kernel (MMH_KERNEL_AUTO picks the 128x64 LDS-DMA tile of it at this
+         size: 2048 tiles = four whole rounds of two workgroups per CU) -- the
          configuration the headline metric ("% of MI355X fp32 MFMA peak at
          N=4096") is quoted on.
   N > 1  workload = configs[3]: fp32 N=16384, C row panels sharded over the N

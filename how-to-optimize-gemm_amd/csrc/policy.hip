@@ -39,6 +39,16 @@ int auto_kernel(mmh_context *ctx, const GemmArgs &g) {
   // idle clock, profiles/r02_cold_start.txt.  With launch #1 of a process no longer carrying 2 ms of one-offs
   // (mmh_create warms the handle) either tile clears the 80 % target under the reference's no-warm-up convention,
   // and the sustained rate -- what the headline metric quotes -- is the small tile's by 1.5 %.)
+  // Whole rounds of the 128x64 tile (two workgroups per CU) on problems with K loops long enough to amortise its
+  // larger prologue: N = 4096 (2048 tiles = four rounds), 6144, 8192, 4096 x 8192 x 4096.  Measured level with the
+  // 64x64 tile there (4096: 150.5 vs 150.3; 6144: 151.4 vs 151.5; 8192: 152.0 vs 152.3, tools/tile_ab.py) with 20 % less
+  // fabric traffic (1.32 vs 1.65 GB per launch at 4096), a faster start from an idle clock (133 vs 130 TFLOP/s over a
+  // process's launches 2 .. 21) -- and on the one box of four that ran the 64x64 tile 3 % slow at every many-tile size
+  // (profiles/r03_notes.md section 7) the 128x64 sizes of the sweep lost 0-1 %: the smaller the tile, the more a launch
+  // leans on the fabric.  (K = 1024: 145.1 vs 146.1 for the small tile, which keeps those.)
+  if (dma128x64 && k >= 2048 && k <= 8192 && tiles128x64 >= 4 * cus && tiles128x64 % (2 * cus) == 0 &&
+      tiles128x64 <= 32 * cus && fill(tiles128x64, 8192.0) >= 0.97)
+    return MMH_KERNEL_MFMA_128X64_DMA;
   {
     const long rounds64 = (tiles64 + cus - 1) / cus;
     // ... and only up to N = 8192-sized problems: with K = 16384 and B beyond the Infinity Cache the

@@ -95,7 +95,9 @@ def test_one_row_and_column_less_keeps_the_tile():
 
 def test_named_decisions():
     import how_to_optimize_gemm_amd as H
-    assert H.auto_plan(4096, 4096, 4096) == ("mfma_64x64_dma", 4096, 0)            # the headline: sixteen tiles per CU, plain
+    assert H.auto_plan(4096, 4096, 4096) == ("mfma_128x64_dma", 2048, 0)           # the headline: four whole rounds of two per CU, plain
+    assert H.auto_plan(4096, 4096, 1024) == ("mfma_64x64_dma", 4096, 0)            # a short K loop keeps the small tile
+    assert H.auto_plan(3072, 3072, 3072) == ("mfma_64x64_dma", 2304, 0)            # nine tiles per CU; 1152 of 128x64 are not whole rounds
     for rows in (16384, 8192, 4096, 2048):                                         # the config-4 panels: B beyond the Infinity Cache
         assert H.auto_plan(rows, 16384, 16384)[0] == "mfma_256x256", rows
     assert H.auto_plan(2817, 2817, 2817) == ("mfma_64x64_dma", 45 * 45, 0)          # pads less than the 128x64 grid

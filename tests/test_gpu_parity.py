@@ -190,17 +190,20 @@ def test_headline_size_4096(mm, oracle):
     c64 = oracle.ref_mmult_f64(a, b)
     assert np.abs(got - c64).max() <= 1.05 * np.abs(unfused - c64).max() + 1e-6
     # every kernel variant is the same chain -> identical bits.  "auto" is what bench.py and the
-    # harness run at this size: it launches the 64x64 LDS-DMA tile on a plain launch (sixteen tiles per
-    # CU; round 2 ran the 256x256 tile here), and that launch -- like the 256x256 tile -- is checked
-    # here against the oracle on the FULL matrix, not on sampled rows.
+    # harness run at this size: it launches the 128x64 LDS-DMA tile on a plain launch (2048 tiles = four whole
+    # rounds of two workgroups per CU; round 2 ran the 256x256 tile here), and that launch -- like the 64x64
+    # LDS-DMA and the 256x256 tile -- is checked here against the oracle on the FULL matrix, not on sampled rows.
     import how_to_optimize_gemm_amd as H
-    for kern in ("auto", "mfma_256x256", "mfma_64x64_dma", "mfma256", "mfma_tiles", "mfma_128x64", "valu", "valu_128x128"):
+    for kern in ("auto", "mfma_256x256", "mfma_64x64_dma", "mfma_128x64_dma", "mfma256", "mfma_tiles", "mfma_128x64", "valu",
+                 "valu_128x128"):
         mm.set_kernel(kern)
         out = mm.matmul(dev(a), dev(b)).cpu().numpy()
         if kern == "mfma_256x256":
             assert "sgemm_mfma_kernel<256,256>" in H.last_launch(), (kern, H.last_launch())
-        if kern in ("auto", "mfma_64x64_dma"):
+        if kern == "mfma_64x64_dma":
             assert "sgemm_mfma_dma_kernel<64,64>" in H.last_launch() and "4096 workgroups" in H.last_launch(), (kern, H.last_launch())
+        if kern in ("auto", "mfma_128x64_dma"):
+            assert "sgemm_mfma_dma_kernel<128,64>" in H.last_launch() and "2048 workgroups" in H.last_launch(), (kern, H.last_launch())
         assert np.array_equal(out, fused), kern
     # accumulate mode at the headline size, through the headline kernel: C's value starts each chain
     mm.set_kernel("auto")

@@ -35,7 +35,8 @@ cp("offgrid.json", "r03_offgrid_vs_vendor.json")
 cp("shard_dryrun.md", "r03_shard_dryrun.md")
 cp("harness_sharded_1gpu.txt", "r03_harness_sharded_shared_device.txt")
 cp("prof4096_kernel_stats.csv", "r03_sgemm4096_kernel_stats.csv")
-cp("prof4096_summary.json", "r03_sgemm4096_auto_dma64x64_rocprofv3.json")
+cp("prof4096_summary.json", "r03_sgemm4096_auto_dma128x64_rocprofv3.json")
+cp("prof4096_64_summary.json", "r03_sgemm4096_dma64x64_rocprofv3.json")
 cp("prof4096_mfma128_summary.json", "r03_sgemm4096_mfma128x128_rocprofv3.json")
 cp("prof4096_256_summary.json", "r03_sgemm4096_mfma256x256_rocprofv3.json")
 cp("prof3584_summary.json", "r03_sgemm3584_dma_streamk128x64_rocprofv3.json")

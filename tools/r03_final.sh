@@ -37,7 +37,7 @@ if has bench; then
   timeout 300 python bench.py --gpus 1 --force-shard --n 8192 --steps 5 --warmup 2 --sweep > $OUT/bench_forceshard.json 2> $OUT/bench_forceshard.err
   timeout 120 python bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/bench_gpus2.out 2> $OUT/bench_gpus2.err; echo "bench --gpus 2 rc=$?" >> $OUT/bench_gpus2.err
   for i in 1 2; do
-    for kk in auto mfma_256x256; do
+    for kk in auto mfma_64x64_dma mfma_256x256; do
       timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --kernel $kk 2> /dev/null | \
         python -c "import json,sys; d=json.load(sys.stdin); c=d['cold']; print('$kk', 'sustained', d['value'], 'launch1_ms', c['launch_1_ms'], 'first20', c['reference_convention_20_launches_no_warmup_tflops'], 'launches2to21', c['launches_2_to_21_tflops'], 'within1pct_after', c['launches_until_within_1pct_of_sustained'])" >> $OUT/cold_start.txt
       sleep 2
@@ -56,11 +56,13 @@ if has shard; then
 fi
 if has prof; then
   TAG=r03z/prof4096 KERNEL=auto bash tools/gpu_profile.sh > $OUT/prof4096.log 2>&1
+  TAG=r03z/prof4096_64 KERNEL=mfma_64x64_dma PASSES="trace pmc1 pmc3 pmc4" bash tools/gpu_profile.sh > $OUT/prof4096_64.log 2>&1
   TAG=r03z/prof4096_mfma128 KERNEL=mfma bash tools/gpu_profile.sh > $OUT/prof4096_mfma128.log 2>&1
   TAG=r03z/prof4096_256 KERNEL=mfma_256x256 PASSES="trace pmc1 pmc3 pmc4" bash tools/gpu_profile.sh > $OUT/prof4096_256.log 2>&1
   TAG=r03z/prof3584 KERNEL=auto BENCH_ARGS="--n 3584" bash tools/gpu_profile.sh > $OUT/prof3584.log 2>&1
   TAG=r03z/prof1023 KERNEL=auto BENCH_ARGS="--n 1023" PASSES="trace pmc1 pmc3 pmc4" bash tools/gpu_profile.sh > $OUT/prof1023.log 2>&1
   python tools/summarize_profile.py $OUT/prof4096 "sgemm_mfma_dma_kernel" > $OUT/prof4096_summary.json 2>> $OUT/prof4096.log
+  python tools/summarize_profile.py $OUT/prof4096_64 "sgemm_mfma_dma_kernel" > $OUT/prof4096_64_summary.json 2>> $OUT/prof4096_64.log
   python tools/summarize_profile.py $OUT/prof4096_mfma128 "sgemm_mfma_kernel" > $OUT/prof4096_mfma128_summary.json 2>> $OUT/prof4096_mfma128.log
   python tools/summarize_profile.py $OUT/prof4096_256 "sgemm_mfma_kernel" > $OUT/prof4096_256_summary.json 2>> $OUT/prof4096_256.log
   python tools/summarize_profile.py $OUT/prof3584 "sgemm_dma_streamk_kernel" > $OUT/prof3584_summary.json 2>> $OUT/prof3584.log
