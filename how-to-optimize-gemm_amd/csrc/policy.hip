@@ -27,28 +27,28 @@ int auto_kernel(mmh_context *ctx, const GemmArgs &g) {
   const bool dma128 = dma_shape_ok(ctx, MMH_KERNEL_MFMA_128X128_DMA, g);
   // how much of the tiles' area is matrix (an edge tile costs a whole tile's time)
   auto fill = [&](long tiles, double area) { return (double)m * (double)n / ((double)tiles * area); };
-  // The 64x64 LDS-DMA tile with three workgroups co-resident per CU has the most efficient loop of
-  // all (148.5-150 TFLOP/s at N = 3072, where 2304 tiles are exactly nine per CU; 150.4-150.8 at 4096 and
-  // 151.6-152.9 at 5120 .. 8192 against 147.8-148.1 and 148.5-150.4 for the 256x256 tile) -- on a PLAIN launch:
-  // under the chained stream-K launch its workgroups run at different K phases and stop sharing operand slices
-  // in L2 (hit rate 81 % -> 22 %, 2.4 GB of fabric traffic per launch, profiles/r02_ablation.md section 9).  So it
-  // is chosen for shapes with many tiles (>= 6 per CU) that fill their last round of CUs to >= 97.5 %
-  // (N = 2688, 3072, 3200 and 4096 on the reference sweep; 5120, 6144, 8192).
-  // (Round 2 kept N = 4096 on the 256x256 tile because that tile follows the chip's clock ramp faster -- within
-  // 1 % of its sustained rate after 18 launches against 40, 137 vs 129 TFLOP/s over the first 20 launches from an
-  // idle clock, profiles/r02_cold_start.txt.  With launch #1 of a process no longer carrying 2 ms of one-offs
-  // (mmh_create warms the handle) either tile clears the 80 % target under the reference's no-warm-up convention,
-  // and the sustained rate -- what the headline metric quotes -- is the small tile's by 1.5 %.)
   // Whole rounds of the 128x64 tile (two workgroups per CU) on problems with K loops long enough to amortise its
   // larger prologue: N = 4096 (2048 tiles = four rounds), 6144, 8192, 4096 x 8192 x 4096.  Measured level with the
   // 64x64 tile there (4096: 150.5 vs 150.3; 6144: 151.4 vs 151.5; 8192: 152.0 vs 152.3, tools/tile_ab.py) with 20 % less
-  // fabric traffic (1.32 vs 1.65 GB per launch at 4096), a faster start from an idle clock (133 vs 130 TFLOP/s over a
+  // fabric traffic (1.38 vs 1.65 GB per launch at 4096), a faster start from an idle clock (133 vs 130 TFLOP/s over a
   // process's launches 2 .. 21) -- and on the one box of four that ran the 64x64 tile 3 % slow at every many-tile size
   // (profiles/r03_notes.md section 7) the 128x64 sizes of the sweep lost 0-1 %: the smaller the tile, the more a launch
   // leans on the fabric.  (K = 1024: 145.1 vs 146.1 for the small tile, which keeps those.)
   if (dma128x64 && k >= 2048 && k <= 8192 && tiles128x64 >= 4 * cus && tiles128x64 % (2 * cus) == 0 &&
       tiles128x64 <= 32 * cus && fill(tiles128x64, 8192.0) >= 0.97)
     return MMH_KERNEL_MFMA_128X64_DMA;
+  // The 64x64 LDS-DMA tile with three workgroups co-resident per CU shares the most efficient loop of all with the
+  // 128x64 tile (148.5-150 TFLOP/s at N = 3072, where 2304 tiles are exactly nine per CU; 151.6-152.9 at 5120 .. 8192
+  // against 148.5-150.4 for the 256x256 tile) -- on a PLAIN launch: under the chained stream-K launch its workgroups
+  // run at different K phases and stop sharing operand slices in L2 (hit rate 81 % -> 22 %, 2.4 GB of fabric traffic
+  // per launch, profiles/r02_ablation.md section 9).  So it is chosen for shapes with many tiles (>= 5.9 per CU) that
+  // fill their last round of CUs to >= 97.5 % and that the rule above did not take (N = 2688, 3072, 3200 on the
+  // reference sweep; 5120; the short-K shapes).
+  // (Round 2 kept N = 4096 on the 256x256 tile because that tile follows the chip's clock ramp faster -- 137-139
+  // TFLOP/s over the first 20 launches from an idle clock against 130-134 for the small tiles,
+  // profiles/r03_cold_start.txt.  With launch #1 of a process no longer carrying 2 ms of one-offs (mmh_create warms
+  // the handle) every tile clears the 80 % target under the reference's no-warm-up convention, and the sustained
+  // rate -- what the headline metric quotes -- is the small tiles' by 1.5 %.)
   {
     const long rounds64 = (tiles64 + cus - 1) / cus;
     // ... and only up to N = 8192-sized problems: with K = 16384 and B beyond the Infinity Cache the
