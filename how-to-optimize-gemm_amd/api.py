@@ -33,7 +33,8 @@ KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
            "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11, "mfma_256x256": 12,
            "valu_128x128": 13, "valu_64x64": 14, "mfma_splitk": 15, "mfma_splitk_128x64": 20,
-           "mfma_64x64_dma": 25, "mfma_128x64_dma": 27, "mfma_128x128_dma": 28}
+           "mfma_64x64_dma": 25, "mfma_128x64_dma": 27, "mfma_128x128_dma": 28,
+           "mfma32_64x64_dma": 48, "mfma32_128x64_dma": 49, "mfma32_128x128_dma": 50, "mfma32_64x128_dma": 51}
 # kernels that keep the one-chain-per-element contract (bit-identical results); the split-K ids do not
 CHAIN_KERNELS = [k for k in KERNELS if "splitk" not in k]
 

@@ -207,6 +207,10 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_64X64_DMA: return "MMult_hip_mfma_64x64_dma";
     case MMH_KERNEL_MFMA_128X64_DMA: return "MMult_hip_mfma_128x64_dma";
     case MMH_KERNEL_MFMA_128X128_DMA: return "MMult_hip_mfma_128x128_dma";
+    case MMH_KERNEL_MFMA32_64X64_DMA: return "MMult_hip_mfma32_64x64_dma";
+    case MMH_KERNEL_MFMA32_128X64_DMA: return "MMult_hip_mfma32_128x64_dma";
+    case MMH_KERNEL_MFMA32_64X128_DMA: return "MMult_hip_mfma32_64x128_dma";
+    case MMH_KERNEL_MFMA32_128X128_DMA: return "MMult_hip_mfma32_128x128_dma";
     case MMH_KERNEL_MFMA_SPLITK: return "MMult_hip_mfma_splitk";
     case MMH_KERNEL_MFMA_SPLITK_128X64: return "MMult_hip_mfma_splitk_128x64";
 #ifdef MMH_AB_BUILD

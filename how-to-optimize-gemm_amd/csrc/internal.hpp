@@ -8,6 +8,7 @@
 //                    makefile switch (cuda/makefile:1-3) made a run-time choice.  Pure host code.
 //   launch_reg.hip   register-staged MFMA tiles (sgemm_mfma.hpp): plain, stream-K, split-K
 //   launch_dma.hip   LDS-DMA tiles (sgemm_dma.hpp): plain, stream-K; whole and guarded shapes
+//   launch_dma32.hip LDS-DMA tiles on the 32x32x2 MFMA (sgemm_dma32.hpp): plain, chained stream-K
 //   launch_valu.hip  K1 / K0 (sgemm_valu.hpp)
 //   host_flavour.hip mmh_sgemm_host(_timed): the host-pointer MY_MMult, row-panel pipeline
 //   shard.hip        mmh_shard_*: single-process row-panel shard over RCCL
@@ -200,6 +201,10 @@ int warm_reg(mmh_context *ctx, float *scratch, hipStream_t s);
 int launch_dma(mmh_context *ctx, int kernel, const GemmArgs &g);
 bool dma_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g);
 int warm_dma(mmh_context *ctx, float *scratch, hipStream_t s);
+// launch_dma32.hip: tile = MMH_KERNEL_MFMA32_*_DMA (sgemm_dma32.hpp); returns 1 when the shape does not qualify
+int launch_dma32(mmh_context *ctx, int kernel, const GemmArgs &g);
+bool dma32_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g);
+int warm_dma32(mmh_context *ctx, float *scratch, hipStream_t s);
 // launch_valu.hip
 int launch_valu(mmh_context *ctx, int kernel, const GemmArgs &g);
 int warm_valu(mmh_context *ctx, float *scratch, hipStream_t s);

@@ -181,6 +181,19 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       const int d = launch_dma(ctx, kernel, g);
       return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA, g);
     }
+    case MMH_KERNEL_MFMA32_64X64_DMA: {   // K2M; shapes it does not take run the register-staged tile of the same size
+      const int d = launch_dma32(ctx, kernel, g);
+      return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA_64X64, g);
+    }
+    case MMH_KERNEL_MFMA32_128X64_DMA:
+    case MMH_KERNEL_MFMA32_64X128_DMA: {
+      const int d = launch_dma32(ctx, kernel, g);
+      return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA_128X64, g);
+    }
+    case MMH_KERNEL_MFMA32_128X128_DMA: {
+      const int d = launch_dma32(ctx, kernel, g);
+      return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA, g);
+    }
     case MMH_KERNEL_MFMA_SPLITK: {   // K2s forced: 128x128 tiles, ctx->splitk parts (auto when <= 1)
       int S = ctx ? ctx->splitk : 0;
       if (S <= 1) {

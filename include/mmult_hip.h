@@ -97,6 +97,13 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_64X64_DMA 25
 #define MMH_KERNEL_MFMA_128X64_DMA 27
 #define MMH_KERNEL_MFMA_128X128_DMA 28
+/* K2M (sgemm_dma32.hpp, round 4): the same LDS-DMA ring feeding v_mfma_f32_32x32x2_f32 -- 64-cycle matrix
+ * instructions, one conflict-free ds_read_b128 + two v_permlane32_swap per eight k's of A -- and, under stream-K,
+ * CHAINED segments (a segment's tail fetches the next segment's first slices).  Same chain, same bits. */
+#define MMH_KERNEL_MFMA32_64X64_DMA 48
+#define MMH_KERNEL_MFMA32_128X64_DMA 49
+#define MMH_KERNEL_MFMA32_128X128_DMA 50
+#define MMH_KERNEL_MFMA32_64X128_DMA 51
 /* OPT-IN split-K (sgemm_mfma.hpp K2s): the K range of every tile runs as S concurrent parts whose
  * partial tiles are summed in part order.  Deterministic, inside the reference harness's tolerance,
  * but NOT the one-chain-per-element bits every other variant returns; never chosen unless asked for

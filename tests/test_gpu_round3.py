@@ -20,7 +20,8 @@ def dev(x):
     return torch.from_numpy(np.ascontiguousarray(x)).cuda()
 
 
-DMA_KERNELS = ["mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma"]
+DMA_KERNELS = ["mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma",
+               "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma"]
 
 
 @pytest.mark.parametrize("kernel", DMA_KERNELS)
