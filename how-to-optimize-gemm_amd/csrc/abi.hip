@@ -137,6 +137,9 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       if (value < 0 || value > 16) return MMH_ERR_INVALID_ARG;
       h->rim = value;
       return MMH_OK;
+    case MMH_OPT_STREAMK_CHAIN:
+      h->sk_chain = value ? 1 : 0;
+      return MMH_OK;
 #ifdef MMH_AB_BUILD
     case 100:   // A/B: pin the residency of persistent launches by their LDS request (default on)
       h->pin = value ? 1 : 0;
@@ -168,6 +171,7 @@ int mmh_get_option(mmh_handle_t h, int option, int *value) {
     }
     case MMH_OPT_DMA_EDGE: *value = h->dma_edge ? (h->dma_dword_rows ? 2 : 1) : 0; return MMH_OK;
     case MMH_OPT_RIM: *value = h->rim; return MMH_OK;
+    case MMH_OPT_STREAMK_CHAIN: *value = h->sk_chain; return MMH_OK;
     case MMH_OPT_STREAMK_TIMEOUTS: {
       // synchronises, then reads the sticky word: how many hand-off waits have timed out on this
       // handle since it was last cleared
@@ -207,10 +211,16 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_64X64_DMA: return "MMult_hip_mfma_64x64_dma";
     case MMH_KERNEL_MFMA_128X64_DMA: return "MMult_hip_mfma_128x64_dma";
     case MMH_KERNEL_MFMA_128X128_DMA: return "MMult_hip_mfma_128x128_dma";
+    case MMH_KERNEL_MFMA_64X64_DMA5: return "MMult_hip_mfma_64x64_dma5";
+    case MMH_KERNEL_MFMA_128X64_DMA5: return "MMult_hip_mfma_128x64_dma5";
+    case MMH_KERNEL_MFMA_128X128_DMA5: return "MMult_hip_mfma_128x128_dma5";
     case MMH_KERNEL_MFMA32_64X64_DMA: return "MMult_hip_mfma32_64x64_dma";
     case MMH_KERNEL_MFMA32_128X64_DMA: return "MMult_hip_mfma32_128x64_dma";
     case MMH_KERNEL_MFMA32_64X128_DMA: return "MMult_hip_mfma32_64x128_dma";
     case MMH_KERNEL_MFMA32_128X128_DMA: return "MMult_hip_mfma32_128x128_dma";
+    case MMH_KERNEL_MFMA32B_128X64_DMA: return "MMult_hip_mfma32b_128x64_dma";
+    case MMH_KERNEL_MFMA32B_64X128_DMA: return "MMult_hip_mfma32b_64x128_dma";
+    case MMH_KERNEL_MFMA32B_128X128_DMA: return "MMult_hip_mfma32b_128x128_dma";
     case MMH_KERNEL_MFMA_SPLITK: return "MMult_hip_mfma_splitk";
     case MMH_KERNEL_MFMA_SPLITK_128X64: return "MMult_hip_mfma_splitk_128x64";
 #ifdef MMH_AB_BUILD
@@ -238,6 +248,14 @@ const char *mmh_kernel_name(int kernel) {
     case 45: return "exp_dma_64x64_8waves";
     case 46: return "exp_dma_128x64_8waves";
     case 47: return "exp_dma_128x128_8waves";
+    case 52: return "abl32_128x64_no_swap";
+    case 53: return "abl32_128x64_no_dma";
+    case 54: return "abl32_128x64_no_a_reads";
+    case 55: return "abl32_128x64_mfma_only";
+    case 56: return "abl32_64x64_no_swap";
+    case 57: return "abl32_64x64_no_dma";
+    case 58: return "abl32_64x64_no_a_reads";
+    case 59: return "abl32_64x64_mfma_only";
 #endif
     default: return nullptr;
   }

@@ -8,6 +8,7 @@
 //                    makefile switch (cuda/makefile:1-3) made a run-time choice.  Pure host code.
 //   launch_reg.hip   register-staged MFMA tiles (sgemm_mfma.hpp): plain, stream-K, split-K
 //   launch_dma.hip   LDS-DMA tiles (sgemm_dma.hpp): plain, stream-K; whole and guarded shapes
+//   launch_dma5.hip  LDS-DMA tiles with a loader wave (sgemm_dma5.hpp): plain, chained stream-K
 //   launch_dma32.hip LDS-DMA tiles on the 32x32x2 MFMA (sgemm_dma32.hpp): plain, chained stream-K
 //   launch_valu.hip  K1 / K0 (sgemm_valu.hpp)
 //   host_flavour.hip mmh_sgemm_host(_timed): the host-pointer MY_MMult, row-panel pipeline
@@ -121,6 +122,7 @@ struct mmh_context {
   int sk_order = 1;            // stream-K launches get the phase-ordered range / tile tables
   int dma_edge = 1;            // ragged / 4-byte-aligned shapes may run the guarded LDS-DMA tiles (MMH_OPT_DMA_EDGE)
   int dma_dword_rows = 1;      // ... including operands whose rows are only 4-byte aligned (odd lda / ldb / base)
+  int sk_chain = 1;            // stream-K launches of the K2M tiles run a range's parts as one stream of slices (MMH_OPT_STREAMK_CHAIN)
   int rim = 0;                 // MMH_KERNEL_AUTO trims up to this many rows / columns past a 64-boundary off the tiles (MMH_OPT_RIM; off: measured, it does not pay)
   // stream-K tables per launch shape (tiles, K-slices, grid): [order: grid ints][place: tiles ints]
   struct SkTable {
@@ -205,6 +207,10 @@ int warm_dma(mmh_context *ctx, float *scratch, hipStream_t s);
 int launch_dma32(mmh_context *ctx, int kernel, const GemmArgs &g);
 bool dma32_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g);
 int warm_dma32(mmh_context *ctx, float *scratch, hipStream_t s);
+// launch_dma5.hip: tile = MMH_KERNEL_MFMA_*_DMA5 (sgemm_dma5.hpp); returns 1 when the shape does not qualify
+int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g);
+bool dma5_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g);
+int warm_dma5(mmh_context *ctx, float *scratch, hipStream_t s);
 // launch_valu.hip
 int launch_valu(mmh_context *ctx, int kernel, const GemmArgs &g);
 int warm_valu(mmh_context *ctx, float *scratch, hipStream_t s);

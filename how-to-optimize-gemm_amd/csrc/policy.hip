@@ -181,15 +181,30 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       const int d = launch_dma(ctx, kernel, g);
       return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA, g);
     }
+    case MMH_KERNEL_MFMA_64X64_DMA5: {   // K2W; shapes it does not take run the register-staged tile of the same size
+      const int d = launch_dma5(ctx, kernel, g);
+      return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA_64X64, g);
+    }
+    case MMH_KERNEL_MFMA_128X64_DMA5: {
+      const int d = launch_dma5(ctx, kernel, g);
+      return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA_128X64, g);
+    }
+    case MMH_KERNEL_MFMA_128X128_DMA5: {
+      const int d = launch_dma5(ctx, kernel, g);
+      return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA, g);
+    }
     case MMH_KERNEL_MFMA32_64X64_DMA: {   // K2M; shapes it does not take run the register-staged tile of the same size
       const int d = launch_dma32(ctx, kernel, g);
       return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA_64X64, g);
     }
     case MMH_KERNEL_MFMA32_128X64_DMA:
+    case MMH_KERNEL_MFMA32B_128X64_DMA:
+    case MMH_KERNEL_MFMA32B_64X128_DMA:
     case MMH_KERNEL_MFMA32_64X128_DMA: {
       const int d = launch_dma32(ctx, kernel, g);
       return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA_128X64, g);
     }
+    case MMH_KERNEL_MFMA32B_128X128_DMA:
     case MMH_KERNEL_MFMA32_128X128_DMA: {
       const int d = launch_dma32(ctx, kernel, g);
       return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA, g);
@@ -218,6 +233,8 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
     case 46:
     case 47:
       return launch_dma(ctx, kernel, g);
+    case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59:
+      return launch_dma32(ctx, kernel, g);
 #endif
     default:
       return launch_reg(ctx, kernel, g);

@@ -40,21 +40,30 @@
 #include <type_traits>
 
 #include "sgemm_dma.hpp"
+#include "sgemm_mfma.hpp"   // the stream-K hand-over protocol (SK_* words), streamk_body
 
 namespace mmh {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
 
-template <int BM, int BN, int KB, int WM, int WN, int NBUF>
+// MB = row blocks per matrix instruction: 1 = v_mfma_f32_32x32x2_f32 (one 32x32 block, two k's), 2 =
+// v_mfma_f32_32x32x1_2b_f32 (two 32x32 blocks -- 64 rows -- one k: lanes 0-31 carry block 0's A rows, lanes 32-63
+// block 1's, BOTH at the same k, so the four registers of a lane's ds_read_b128 are the A operands of four consecutive
+// instructions as they stand: no v_permlane32_swap, which measured 9 % of the MB = 1 loop, profiles/r04_notes.md).
+template <int BM, int BN, int KB, int WM, int WN, int NBUF, int MB = 1>
 struct Dma32Tile {
   static_assert(KB == 32, "a K-slice row of A is 128 bytes: eight 16-byte chunks");
-  static_assert(WM >= 1 && WM <= 4 && (WN == 1 || WN == 2 || WN == 4), "wave tile is 32 WM x 32 WN");
+  static_assert(MB == 1 || MB == 2, "one or two 32-row blocks per matrix instruction");
+  static_assert(WM >= 1 && WM <= 4 && (WN == 1 || WN == 2 || WN == 4), "wave tile is 32 MB WM x 32 WN");
   static_assert(NBUF == 3, "a ring of three K-slice buffers");
-  static constexpr int WAVES_M = BM / (32 * WM), WAVES_N = BN / (32 * WN), WAVES = WAVES_M * WAVES_N;
-  static_assert(WAVES_M * 32 * WM == BM && WAVES_N * 32 * WN == BN && WAVES == 4, "four waves, one per SIMD");
+  static constexpr int RB = 32 * MB;                                          // rows per matrix instruction
+  static constexpr int WAVES_M = BM / (RB * WM), WAVES_N = BN / (32 * WN), WAVES = WAVES_M * WAVES_N;
+  static_assert(WAVES_M * RB * WM == BM && WAVES_N * 32 * WN == BN && WAVES == 4, "four waves, one per SIMD");
   static constexpr int THREADS = 64 * WAVES;
   static constexpr int A_FLOATS = BM * KB, B_FLOATS = KB * BN, STAGE = A_FLOATS + B_FLOATS;
-  static constexpr int KG = KB / 8;                                           // k-groups (eight k's) per slice
+  static constexpr int KSTEP = 8 / MB;                                        // k's per k-group: four matrix instructions deep
+  static constexpr int KG = KB / KSTEP;                                       // k-groups per slice
   static constexpr int CHA = A_FLOATS / 256, CHB = B_FLOATS / 256;            // 1 KiB pieces per image
   static constexpr int CA = CHA / WAVES, CB = CHB / WAVES, ND = CA + CB;      // pieces per wave and slice
   static constexpr int RPC_A = 256 / KB, LPR_A = KB / 4;                      // rows per piece, lanes per row
@@ -81,9 +90,14 @@ struct Dma32Link {
   bool primed = false;
 };
 
-template <int BM, int BN, int KB, int WM, int WN, int NBUF, bool PART_WT = false, bool EDGE = false, bool CHAIN = false>
+// ABL (tools build only, timing-only: WRONG results): 1 no swaps, 2 no LDS-DMA inside the loop, 4 no A fragment
+// reads, 8 no B fragment reads -- what each part of the loop costs (profiles/r04_notes.md).
+template <int BM, int BN, int KB, int WM, int WN, int NBUF, bool PART_WT = false, bool EDGE = false, bool CHAIN = false, int ABL = 0,
+          int MB = 1>
 struct Dma32Segment {
-  using T = Dma32Tile<BM, BN, KB, WM, WN, NBUF>;
+  using T = Dma32Tile<BM, BN, KB, WM, WN, NBUF, MB>;
+  static constexpr int RB = T::RB, KSTEP = T::KSTEP;
+  using acc_t = std::conditional_t<MB == 2, f32x32, f32x16>;
   typedef float bvec_t __attribute__((ext_vector_type(WN)));
   typedef float c_vec_u __attribute__((ext_vector_type(WN), aligned(4)));
   using c_vec = std::conditional_t<EDGE, c_vec_u, bvec_t>;
@@ -110,8 +124,10 @@ struct Dma32Segment {
       h = lane >> 5;
       const int sw = (i >> 1) & 7;
 #pragma unroll
-      for (int g = 0; g < T::KG; ++g) a_off[g] = (wm * 32 * WM + i) * KB + 4 * ((2 * g + h) ^ sw);
-      b_off = T::A_FLOATS + h * BN + wn * 32 * WN + WN * i;
+      for (int g = 0; g < T::KG; ++g)
+        a_off[g] = MB == 1 ? (wm * RB * WM + i) * KB + 4 * ((2 * g + h) ^ sw)       // lower / upper half-wave: chunks 2g / 2g+1
+                           : (wm * RB * WM + 32 * h + i) * KB + 4 * (g ^ sw);       // ... rows i / 32 + i of the same chunk
+      b_off = T::A_FLOATS + (MB == 1 ? h * BN : 0) + wn * 32 * WN + WN * i;
       // wave w moves pieces CA w .. CA w + CA - 1 of the A image and likewise of the B image; the 16-byte chunk a
       // lane fetches is the one that belongs at its (swizzled) position
 #pragma unroll
@@ -130,19 +146,19 @@ struct Dma32Segment {
   template <int g>
   static __device__ __forceinline__ void read_frag(Frag &f, const float *buf, const Lane &L) {
 #pragma unroll
-    for (int bm = 0; bm < WM; ++bm) {
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + L.a_off[g] + bm * 32 * KB);
+    for (int bm = 0; bm < ((ABL & 4) ? 0 : WM); ++bm) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + L.a_off[g] + bm * RB * KB);
 #pragma unroll
       for (int q = 0; q < 4; ++q) f.a[bm][q] = v[q];
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) f.b[p] = *reinterpret_cast<const bvec_t *>(buf + L.b_off + (8 * g + 2 * p) * BN);
+    for (int p = 0; p < ((ABL & 8) ? 0 : 4); ++p) f.b[p] = *reinterpret_cast<const bvec_t *>(buf + L.b_off + (KSTEP * g + (2 / MB) * p) * BN);
   }
   // {k0|k4} {k1|k5} {k2|k6} {k3|k7}  ->  a[0] = {k0|k1}, a[1] = {k2|k3}, a[2] = {k4|k5}, a[3] = {k6|k7}
   static __device__ __forceinline__ void swap_frag(Frag &f) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int bm = 0; bm < WM; ++bm) {
+    for (int bm = 0; bm < ((ABL & 1) || MB == 2 ? 0 : WM); ++bm) {
       const u32x2 s01 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, f.a[bm][0]),
                                                          __builtin_bit_cast(unsigned, f.a[bm][1]), false, false);
       const u32x2 s23 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, f.a[bm][2]),
@@ -167,7 +183,7 @@ struct Dma32Segment {
     constexpr int KG = T::KG, STAGE = T::STAGE, A_FLOATS = T::A_FLOATS, CA = T::CA, CB = T::CB, ND = T::ND, LA = T::LA;
     const int row0 = tm * BM, col0 = tn * BN;
     // C rows / columns of this lane: row(bm, r) = crow + 32 bm + (r & 3) + 8 (r >> 2), columns ccol .. ccol + WN - 1
-    const int crow = row0 + L.wm * 32 * WM + 4 * L.h;
+    const int crow = row0 + L.wm * RB * WM + 4 * L.h;
     const int ccol = col0 + L.wn * 32 * WN + WN * L.i;
     const int rows_valid = EDGE ? min(BM, m - row0) : BM;
     const int cols_valid = EDGE ? min(BN, n - col0) : BN;
@@ -218,11 +234,14 @@ struct Dma32Segment {
         DmaPiece::one(s.b, buf + A_FLOATS + 256 * (CB * L.wave + (I - CA)), L.voff_b[I - CA], s.off_b);
     };
 
-    f32x16 acc[WM][WN];
+    acc_t acc[WM][WN];
+    constexpr int NR = 16 * MB;   // accumulator registers per instruction: register r = row 32 (r >> 4) + (r & 3) + 8 ((r & 15) >> 2) + 4 h
+    auto c_row = [&](int bm, int r) { return crow + RB * bm + 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2); };
     // ---- prologue: LA slices in flight, the first one landed, its first fragments read (unless the previous
     // segment of the chain has done all that) ----
-    int pos = CHAIN ? link.pos : 0;
-    if (!CHAIN || !link.primed) {
+    int pos = CHAIN ? __builtin_amdgcn_readfirstlane(link.pos) : 0;
+    const bool primed = CHAIN && __builtin_amdgcn_readfirstlane((int)link.primed) != 0;
+    if (!primed) {
       if constexpr (CHAIN) __syncthreads();   // every wave is past its last fragment read of whatever ran before
       pos = 0;
       static_for<LA>([&](auto s_c) {
@@ -236,8 +255,8 @@ struct Dma32Segment {
 #pragma unroll
       for (int bm = 0; bm < WM; ++bm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = crow + 32 * bm + (r & 3) + 8 * (r >> 2) - row0;
+        for (int r = 0; r < NR; ++r) {
+          const int rr = c_row(bm, r) - row0;
           const bvec_t v = *reinterpret_cast<const bvec_t *>(part_in + (size_t)rr * BN + (ccol - col0));
 #pragma unroll
           for (int u = 0; u < WN; ++u) acc[bm][u][r] = v[u];
@@ -246,8 +265,8 @@ struct Dma32Segment {
 #pragma unroll
       for (int bm = 0; bm < WM; ++bm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = crow + 32 * bm + (r & 3) + 8 * (r >> 2);
+        for (int r = 0; r < NR; ++r) {
+          const int row = c_row(bm, r);
           bvec_t v = {};
           if (whole_c) {
             v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
@@ -265,9 +284,9 @@ struct Dma32Segment {
 #pragma unroll
         for (int u = 0; u < WN; ++u)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[bm][u][r] = 0.0f;
+          for (int r = 0; r < NR; ++r) acc[bm][u][r] = 0.0f;
     }
-    if (!CHAIN || !link.primed) {
+    if (!primed) {
       if (part_in || init_from_c) {
         // the accumulators' loads were issued AFTER the DMAs: waiting for the first slice means waiting for them too
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -297,7 +316,7 @@ struct Dma32Segment {
         Frag &nxf = fr[(g + 1) & 1];
         if constexpr (g == KG - 1) {
           // everything but the pieces of slice kt + LA issued so far in this slice has landed: slice kt + 1 is whole
-          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((KG - 1) * ND / KG) : "memory");
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((ABL & 2) ? 0 : (KG - 1) * ND / KG) : "memory");
           __builtin_amdgcn_s_barrier();
           read_frag<0>(nxf, nxt, L);
         } else {
@@ -309,7 +328,7 @@ struct Dma32Segment {
           // operands of the k's that do not exist (B's rows there are zeros by descriptor; belt and braces)
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
-            const bool live = 8 * g + 2 * p + L.h < krem;
+            const bool live = KSTEP * g + (MB == 1 ? 2 * p + L.h : p) < krem;
 #pragma unroll
             for (int bm = 0; bm < WM; ++bm) cur.a[bm][p] = live ? cur.a[bm][p] : 0.0f;
 #pragma unroll
@@ -324,11 +343,12 @@ struct Dma32Segment {
           }
           static_for<WM * WN>([&](auto q_c) {
             constexpr int q = decltype(q_c)::value, bm = q / WN, u = q % WN;
-            acc[bm][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[bm][p], cur.b[p][u], acc[bm][u], 0, 0, 0);
+            if constexpr (MB == 1) acc[bm][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[bm][p], cur.b[p][u], acc[bm][u], 0, 0, 0);
+            else acc[bm][u] = __builtin_amdgcn_mfma_f32_32x32x1f32(cur.a[bm][p], cur.b[p][u], acc[bm][u], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             // one DMA piece behind each of the group's first MFMAs
             constexpr int idx = p * WM * WN + q;
-            if constexpr (idx < P1 - P0) {
+            if constexpr (idx < P1 - P0 && !(ABL & 2)) {
               dma_piece(dst, src, std::integral_constant<int, P0 + idx>{});
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -397,17 +417,23 @@ struct Dma32Segment {
     }
     dma_stamp(2);
 
-    __amdgpu_buffer_rsrc_t rsrc_p;
-    if (PART_WT && part_out) rsrc_p = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, BM * BN * 4, 0x00020000);
+    // the tile goes out: a partial tile into the workspace (dense BM x BN, write-through), or C (whole tiles as
+    // vectors, edge tiles element by element).  (One branch around each store loop, not one inside per store.)
+    auto out_vec = [&](int bm, int r) {
+      bvec_t v;
 #pragma unroll
-    for (int bm = 0; bm < WM; ++bm)
+      for (int u = 0; u < WN; ++u) v[u] = acc[bm][u][r];
+      return v;
+    };
+    if (part_out) {
+      __amdgpu_buffer_rsrc_t rsrc_p;
+      if constexpr (PART_WT) rsrc_p = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, BM * BN * 4, 0x00020000);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = crow + 32 * bm + (r & 3) + 8 * (r >> 2);
-        bvec_t v;
+      for (int bm = 0; bm < WM; ++bm)
 #pragma unroll
-        for (int u = 0; u < WN; ++u) v[u] = acc[bm][u][r];
-        if (part_out) {
+        for (int r = 0; r < NR; ++r) {
+          const int row = c_row(bm, r);
+          const bvec_t v = out_vec(bm, r);
           if constexpr (PART_WT) {
             const uint32_t off = (uint32_t)(((row - row0) * BN + (ccol - col0)) * 4);
             if constexpr (WN == 4) {
@@ -417,29 +443,42 @@ struct Dma32Segment {
               typedef int i32x2_t __attribute__((ext_vector_type(2)));
               __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, v), rsrc_p, off, 0, 16);
             } else {
-              { const float v0 = v[0]; __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v0), rsrc_p, off, 0, 16); }
+              const float v0 = v[0];
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v0), rsrc_p, off, 0, 16);
             }
           } else {
             *reinterpret_cast<bvec_t *>(part_out + (size_t)(row - row0) * BN + (ccol - col0)) = v;
           }
-        } else if (whole_c) {
-          *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + ccol) = v;
-        } else if (row < m) {
-#pragma unroll
-          for (int u = 0; u < WN; ++u)
-            if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
         }
-      }
+    } else if (whole_c) {
+#pragma unroll
+      for (int bm = 0; bm < WM; ++bm)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) *reinterpret_cast<c_vec *>(C + (size_t)c_row(bm, r) * ldc + ccol) = out_vec(bm, r);
+    } else {
+#pragma unroll
+      for (int bm = 0; bm < WM; ++bm)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int row = c_row(bm, r);
+          const bvec_t v = out_vec(bm, r);
+          if (row < m) {
+#pragma unroll
+            for (int u = 0; u < WN; ++u)
+              if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
+          }
+        }
+    }
   }
 };
 
 // One workgroup per C tile (XCD-aware block -> tile map), whole K range.
-template <int BM, int BN, int KB, int WM, int WN, int NBUF, bool EDGE = false>
+template <int BM, int BN, int KB, int WM, int WN, int NBUF, bool EDGE = false, int ABL = 0, int MB = 1>
 __global__ void __launch_bounds__(256)
 sgemm_mfma32_dma_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
                         float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  using S = Dma32Segment<BM, BN, KB, WM, WN, NBUF, false, EDGE, false>;
+  using S = Dma32Segment<BM, BN, KB, WM, WN, NBUF, false, EDGE, false, ABL, MB>;
   int tm, tn;
   dma_stamp(0);
   block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
@@ -452,7 +491,7 @@ sgemm_mfma32_dma_kernel(int m, int n, int k, const float *__restrict__ A, int ld
 }
 
 // Segment policy for streamk_body (sgemm_mfma.hpp): the UNCHAINED form, every segment with its own prologue.
-template <int BM_, int BN_, int KB_, int WM, int WN, int NBUF, bool EDGE = false>
+template <int BM_, int BN_, int KB_, int WM, int WN, int NBUF, bool EDGE = false, int MB = 1>
 struct Dma32Seg {
   static constexpr int BM = BM_, BN = BN_, KB = KB_;
   static constexpr int THREADS = 256;
@@ -460,7 +499,7 @@ struct Dma32Seg {
                                              const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                              int tm, int tn, int kb, int ke, bool init_from_c, const float *part_in,
                                              float *part_out) {
-    using S = Dma32Segment<BM, BN, KB, WM, WN, NBUF, true, EDGE, false>;
+    using S = Dma32Segment<BM, BN, KB, WM, WN, NBUF, true, EDGE, false, 0, MB>;
     typename S::Lane L;
     L.init(lda, ldb);
     typename S::Frag fr[2];
@@ -468,5 +507,174 @@ struct Dma32Seg {
     S::run(lds, L, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, kb, ke, init_from_c, part_in, part_out, fr, link);
   }
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2Mp: the chained stream-K body.  The ranges, the order of a range's parts (head of the last tile FIRST, whole tiles,
+// tail of the first tile LAST), the hand-over protocol and its words are streamk_body's (sgemm_mfma.hpp, K2p) -- a
+// launch of either body interoperates with the same workspace and tables.  What differs is how the parts run: as ONE
+// stream of K-slices through the ring (Dma32Segment, CHAIN): each part's tail fetches the next part's first two
+// slices, so that only the workgroup's first part pays a pipeline fill, and the stores of a part's C tile (or of the
+// partial tile, and the wait for them that precedes the publish) run under loads already in flight.  A tail's first
+// slices are fetched BEFORE its hand-over word is looked at: they depend on nobody; should the word say the head's
+// owner is not running (the wait-free path: leave), they are simply dropped.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int KB, int WM, int WN, int NBUF, bool EDGE, int MB>
+__device__ __forceinline__ void streamk32_body(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
+                                               const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
+                                               int accumulate, int nbm, int nbn, int *__restrict__ flags,
+                                               float *__restrict__ parts, const int *__restrict__ order,
+                                               const int *__restrict__ place, int *__restrict__ stats) {
+  using S = Dma32Segment<BM, BN, KB, WM, WN, NBUF, true, EDGE, true, 0, MB>;
+  using T = Dma32Tile<BM, BN, KB, WM, WN, NBUF, MB>;
+  const int nk = (k + KB - 1) / KB;
+  const int Tn = nbm * nbn, G = gridDim.x;
+  const int xcd = blockIdx.x % NXCD, local = blockIdx.x / NXCD;
+  const int gq = G / NXCD, gr = G % NXCD;
+  const int rho = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + local;
+  // (readfirstlane: what is loaded from memory or passed through LDS is workgroup-uniform, but hipcc cannot know -- and a
+  // descriptor, LDS address or slice offset it takes for lane-dependent puts every LDS-DMA instruction of the loop into
+  // a waterfall loop)
+  const int q = __builtin_amdgcn_readfirstlane(order ? order[rho] : rho);
+  const long long total = (long long)Tn * nk;
+  const long long u0 = total * q / G, u1 = total * (q + 1) / G;
+  if (u1 <= u0) return;
+  const int t_first = (int)(u0 / nk), k_first = (int)(u0 % nk);
+  const int t_last = (int)((u1 - 1) / nk), k_last_end = (int)(u1 - (long long)t_last * nk);
+  auto tile_of = [&](int t, int &tm, int &tn) {   // grouped raster, no XCD remap (the ranges are XCD-contiguous)
+    const int tt = __builtin_amdgcn_readfirstlane(place ? place[t] : t);
+    const int per_group = GROUP_M * nbn;
+    const int group = tt / per_group, first_m = group * GROUP_M;
+    const int gsize = min(nbm - first_m, GROUP_M);
+    const int in_group = tt - group * per_group;
+    tm = first_m + in_group % gsize;
+    tn = in_group / gsize;
+  };
+  // one lane's word made workgroup-uniform through the line of LDS behind the ring (the ring itself is never idle here)
+  volatile int *word = reinterpret_cast<volatile int *>(lds + T::RING_BYTES / sizeof(float));
+  auto uniform = [&](int v) {
+    __syncthreads();
+    if (threadIdx.x == 0) *word = v;
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(*word);
+  };
+  const bool whole_only = t_first == t_last && k_first == 0 && k_last_end == nk;
+  const bool first_partial = !whole_only && k_first != 0, last_partial = !whole_only && k_last_end != nk;
+  const int n_whole = t_last - t_first + 1 - (first_partial ? 1 : 0) - (last_partial ? 1 : 0);
+  const int n_parts = (last_partial ? 1 : 0) + n_whole + (first_partial ? 1 : 0);
+  enum { HEAD = 0, WHOLE = 1, TAIL = 2, LEFT_TO_US = 3 };
+  struct Part { int t, kb, ke, kind; };
+  auto part_at = [&](int s) {
+    Part p;
+    const int w = s - (last_partial ? 1 : 0);
+    if (s == 0 && last_partial) p = Part{t_last, 0, k_last_end, HEAD};
+    else if (w < n_whole) p = Part{t_first + (first_partial ? 1 : 0) + w, 0, nk, WHOLE};
+    else p = Part{t_first, k_first, nk, TAIL};
+    return p;
+  };
+  float *my_slot = parts + (size_t)q * BM * BN;
+  typename S::Lane L;
+  L.init(lda, ldb);
+  typename S::Frag fr[2];
+  Dma32Link link;
+  int head_reply = 0;   // thread 0: what the word held when DONE went in
+  if (last_partial && threadIdx.x == 0)   // "I am running": whoever needs the head may wait for it
+    (void)__hip_atomic_fetch_or(&flags[t_last], SK_HEAD_RUNNING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int s = 0;; ++s) {
+    Part p;
+    if (s < n_parts) {
+      p = part_at(s);
+    } else {
+      // after the range: a tail somebody left to us?  (head_reply is only looked at now: nobody stalls on an atomic's
+      // round trip)
+      if (s > n_parts || !last_partial || !(uniform(head_reply) & SK_TAIL_LEFT)) break;
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // our own write-through stores, read back through L2
+        __hip_atomic_store(&flags[t_last], SK_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (stats) __hip_atomic_fetch_add(stats, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      p = Part{t_last, k_last_end, nk, LEFT_TO_US};
+    }
+    Dma32Next nx;
+    if (s + 1 < n_parts) {
+      const Part f = part_at(s + 1);
+      tile_of(f.t, nx.tm, nx.tn);
+      nx.kb = f.kb;
+      nx.len = f.ke - f.kb;
+    }
+    const float *part_in = nullptr;
+    if (p.kind == TAIL) {
+      int seen = SK_EMPTY;
+      if (threadIdx.x == 0) {
+        long long polls = 0;
+        for (;;) {
+          seen = __hip_atomic_load(&flags[t_first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (seen & SK_HEAD_DONE) break;
+          if ((seen & SK_HEAD_RUNNING) && ++polls < (1ll << 22)) {   // resident and on its way: bounded by ITS OWN work
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+          }
+          int expect = seen;                                        // not running (or the back-stop): leave the tail to it
+          if (__hip_atomic_compare_exchange_strong(&flags[t_first], &expect, seen | SK_TAIL_LEFT, __ATOMIC_RELAXED,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            seen = SK_TAIL_LEFT;
+            break;
+          }
+        }
+        if (seen & SK_HEAD_DONE) {
+          seen = SK_HEAD_DONE;
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          // the part that finishes a tile is the last reader of its word: it puts the 0 back
+          __hip_atomic_store(&flags[t_first], SK_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (uniform(seen) != SK_HEAD_DONE) {
+        // the head's owner is not running: it will find our mark and finish the tile itself.  The slices fetched
+        // ahead for this tail are dropped -- once they have landed.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        link.primed = false;
+        continue;
+      }
+      part_in = parts + (size_t)(q - 1) * BM * BN;
+    } else if (p.kind == LEFT_TO_US) {
+      part_in = my_slot;
+    }
+    int tm, tn;
+    tile_of(p.t, tm, tn);
+    S::run(lds, L, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, p.kb, p.ke, p.kb == 0 && accumulate != 0, part_in,
+           p.kind == HEAD ? my_slot : nullptr, fr, link, nx);
+    if (p.kind == HEAD) {
+      // Publish (cdna guide G16, recipe R1): the partial tile went out write-through (sc1) -- every storing wave
+      // drains its stores (the stream's loads in flight land with them), the workgroup meets, ONE lane ORs DONE in.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0)
+        head_reply = __hip_atomic_fetch_or(&flags[t_last], SK_HEAD_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int BM, int BN, int KB, int WM, int WN, int NBUF, bool EDGE = false, int MB = 1>
+__global__ void __launch_bounds__(256)
+sgemm_dma32_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B,
+                           int ldb, float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn,
+                           int *__restrict__ flags, float *__restrict__ parts, const int *__restrict__ order,
+                           const int *__restrict__ place, int *__restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  streamk32_body<BM, BN, KB, WM, WN, NBUF, EDGE, MB>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn, flags, parts,
+                                                  order, place, stats);
+}
+
+// the UNCHAINED persistent form (streamk_body over Dma32Seg: every part its own prologue) -- the A/B baseline
+template <int BM, int BN, int KB, int WM, int WN, int NBUF, bool EDGE = false, int MB = 1>
+__global__ void __launch_bounds__(256)
+sgemm_dma32_streamk_unchained_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                     int ldb, float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn,
+                                     int *__restrict__ flags, float *__restrict__ parts, const int *__restrict__ order,
+                                     const int *__restrict__ place, int *__restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  streamk_body<Dma32Seg<BM, BN, KB, WM, WN, NBUF, EDGE, MB>>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn,
+                                                          flags, parts, order, place, stats);
+}
 
 }  // namespace mmh

@@ -351,7 +351,7 @@ int warm_context(mmh_context *h) {
   HIP_TRY(hipMemsetAsync(scratch.p, 0, scratch.bytes, nullptr));
   float *p = static_cast<float *>(scratch.p);
   if ((rc = warm_reg(h, p, nullptr)) == MMH_OK && (rc = warm_dma(h, p, nullptr)) == MMH_OK &&
-      (rc = warm_dma32(h, p, nullptr)) == MMH_OK) rc = warm_valu(h, p, nullptr);
+      (rc = warm_dma32(h, p, nullptr)) == MMH_OK && (rc = warm_dma5(h, p, nullptr)) == MMH_OK) rc = warm_valu(h, p, nullptr);
   // the hand-off workspaces at the size the largest stream-K launch of a square sweep needs
   if (rc == MMH_OK) {
     int *flags = nullptr;

@@ -97,6 +97,12 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_64X64_DMA 25
 #define MMH_KERNEL_MFMA_128X64_DMA 27
 #define MMH_KERNEL_MFMA_128X128_DMA 28
+/* K2W (sgemm_dma5.hpp, round 4): K2L's tiles with a FIFTH wave that does nothing but the LDS-DMA (all pieces of a
+ * K-slice, two slices ahead), so that the four MFMA waves never stall on a vector-memory issue; under stream-K the
+ * loader walks the parts of a range as ONE stream of slices (MMH_OPT_STREAMK_CHAIN).  Same chain, same bits. */
+#define MMH_KERNEL_MFMA_64X64_DMA5 29
+#define MMH_KERNEL_MFMA_128X64_DMA5 30
+#define MMH_KERNEL_MFMA_128X128_DMA5 31
 /* K2M (sgemm_dma32.hpp, round 4): the same LDS-DMA ring feeding v_mfma_f32_32x32x2_f32 -- 64-cycle matrix
  * instructions, one conflict-free ds_read_b128 + two v_permlane32_swap per eight k's of A -- and, under stream-K,
  * CHAINED segments (a segment's tail fetches the next segment's first slices).  Same chain, same bits. */
@@ -104,6 +110,11 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA32_128X64_DMA 49
 #define MMH_KERNEL_MFMA32_128X128_DMA 50
 #define MMH_KERNEL_MFMA32_64X128_DMA 51
+/* ... and on the two-block form v_mfma_f32_32x32x1_2b_f32 (64-row wave tiles; the A operands of four consecutive k's
+ * are the four registers of one ds_read_b128 as they stand) */
+#define MMH_KERNEL_MFMA32B_128X64_DMA 60
+#define MMH_KERNEL_MFMA32B_64X128_DMA 61
+#define MMH_KERNEL_MFMA32B_128X128_DMA 62
 /* OPT-IN split-K (sgemm_mfma.hpp K2s): the K range of every tile runs as S concurrent parts whose
  * partial tiles are summed in part order.  Deterministic, inside the reference harness's tolerance,
  * but NOT the one-chain-per-element bits every other variant returns; never chosen unless asked for
@@ -237,6 +248,10 @@ int mmh_kernel_id(const char *short_name);
  * default because it does not pay: alone the tiles of 1024 x 1024 x 1025 take 20 us and the rim 13 us, together 28-29 us
  * -- against 27 us for the plain launch of 17 x 17 edge tiles. */
 #define MMH_OPT_RIM 11
+/* MMH_OPT_STREAMK_CHAIN (default 1): stream-K launches of the K2M tiles (sgemm_dma32.hpp) run the parts of a workgroup's
+ * range as ONE stream of K-slices -- a part's last slices fetch the next part's first ones -- instead of starting every
+ * part with an empty pipeline.  Same bits; 0 = the unchained form (the A/B baseline). */
+#define MMH_OPT_STREAMK_CHAIN 12
 int mmh_set_option(mmh_handle_t handle, int option, int value);
 /* The two tables of a phase-ordered stream-K launch (MMH_OPT_STREAMK_ORDER) for `tiles` tile slots of `nk`
  * K-slices on `grid` persistent workgroups, computed on the host (no device needed): order[grid] = the range

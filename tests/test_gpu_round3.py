@@ -21,7 +21,9 @@ def dev(x):
 
 
 DMA_KERNELS = ["mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma",
-               "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma"]
+               "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma",
+    "mfma32b_128x64_dma", "mfma32b_64x128_dma", "mfma32b_128x128_dma",
+    "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5"]
 
 
 @pytest.mark.parametrize("kernel", DMA_KERNELS)

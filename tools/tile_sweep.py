@@ -7,7 +7,7 @@ rules are read off (round 4; the reference's `NEW := MMult_xxx` switch, cuda/mak
 
 A variant is a kernel's short name (mmh_kernel_id) optionally followed by /sk0 (MMH_OPT_STREAMK = 0: one
 workgroup per tile), /sk1 (the library's own policy, the default) or /sk2 (stream-K whenever the tile count is
-ragged); `rocblas` / `hipblaslt` are the vendor comparators.  Protocol as tools/offgrid_sweep.py: every burst
+ragged), and /nc (MMH_OPT_STREAMK_CHAIN = 0: the K2M tiles' stream-K parts unchained); `rocblas` / `hipblaslt` are the vendor comparators.  Protocol as tools/offgrid_sweep.py: every burst
 through the C ABI after ~--warm-ms of untimed launches of its own variant, --rounds interleaved rounds, medians.
 --check compares every variant's C with the first variant's, bit for bit.  Needs a GPU."""
 from __future__ import annotations
@@ -54,9 +54,11 @@ def main():
     rows = []
 
     def select(v):
-        name, _, sk = v.partition("/")
-        mm.set_kernel(name)
-        mm.set_streamk(int(sk[2:]) if sk else 1)
+        parts = v.split("/")
+        mm.set_kernel(parts[0])
+        sk = [x for x in parts[1:] if x.startswith("sk")]
+        mm.set_streamk(int(sk[0][2:]) if sk else 1)
+        mm.set_option(H.OPT_STREAMK_CHAIN, 0 if "nc" in parts[1:] else 1)
 
     for (m, n, k) in parse_shapes(args):
         need = m * k + k * n + m * n
