@@ -140,9 +140,17 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
     case MMH_OPT_STREAMK_CHAIN:
       h->sk_chain = value ? 1 : 0;
       return MMH_OK;
+    case MMH_OPT_PERSIST:
+      if (value < 0 || value > 1) return MMH_ERR_INVALID_ARG;
+      h->persist = value;
+      return MMH_OK;
 #ifdef MMH_AB_BUILD
     case 100:   // A/B: pin the residency of persistent launches by their LDS request (default on)
       h->pin = value ? 1 : 0;
+      return MMH_OK;
+    case 101:   // A/B: raster group height of the plain K2W launch (0 = the product's GROUP_M)
+      if (value < 0 || value > 1024) return MMH_ERR_INVALID_ARG;
+      h->ab_group_m = value;
       return MMH_OK;
 #endif
     default:
@@ -172,6 +180,7 @@ int mmh_get_option(mmh_handle_t h, int option, int *value) {
     case MMH_OPT_DMA_EDGE: *value = h->dma_edge ? (h->dma_dword_rows ? 2 : 1) : 0; return MMH_OK;
     case MMH_OPT_RIM: *value = h->rim; return MMH_OK;
     case MMH_OPT_STREAMK_CHAIN: *value = h->sk_chain; return MMH_OK;
+    case MMH_OPT_PERSIST: *value = h->persist; return MMH_OK;
     case MMH_OPT_STREAMK_TIMEOUTS: {
       // synchronises, then reads the sticky word: how many hand-off waits have timed out on this
       // handle since it was last cleared
@@ -214,6 +223,7 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_64X64_DMA5: return "MMult_hip_mfma_64x64_dma5";
     case MMH_KERNEL_MFMA_128X64_DMA5: return "MMult_hip_mfma_128x64_dma5";
     case MMH_KERNEL_MFMA_128X128_DMA5: return "MMult_hip_mfma_128x128_dma5";
+    case MMH_KERNEL_MFMA_96X96_DMA5: return "MMult_hip_mfma_96x96_dma5";
     case MMH_KERNEL_MFMA32_64X64_DMA: return "MMult_hip_mfma32_64x64_dma";
     case MMH_KERNEL_MFMA32_128X64_DMA: return "MMult_hip_mfma32_128x64_dma";
     case MMH_KERNEL_MFMA32_64X128_DMA: return "MMult_hip_mfma32_64x128_dma";
@@ -256,6 +266,23 @@ const char *mmh_kernel_name(int kernel) {
     case 57: return "abl32_64x64_no_dma";
     case 58: return "abl32_64x64_no_a_reads";
     case 59: return "abl32_64x64_mfma_only";
+    case 64: return "exp5_64x64_l1d2";
+    case 65: return "exp5_64x64_l4d2";
+    case 66: return "exp5_64x64_l2d3";
+    case 67: return "exp5_64x64_l4d3";
+    case 68: return "exp5_128x64_l1d2";
+    case 69: return "exp5_128x64_l4d2";
+    case 70: return "exp5_128x64_l2d3";
+    case 71: return "exp5_128x64_l4d3";
+    case 72: return "exp5_128x128_l1d2";
+    case 73: return "exp5_128x128_l4d2";
+    case 74: return "exp5_128x128_l2d3";
+    case 75: return "exp5_128x128_l4d3";
+    case 76: return "exp5_96x96_l2d2";
+    case 77: return "exp5_96x96_l4d2";
+    case 78: return "exp5_96x96_l2d3";
+    case 79: return "exp5_160x96_l1d2";
+    case 80: return "exp5_160x160_l1d2";
 #endif
     default: return nullptr;
   }
@@ -265,9 +292,9 @@ const char *mmh_kernel_name(int kernel) {
 int mmh_kernel_id(const char *name) {
   if (!name) return -1;
   const std::string want = std::string("MMult_hip_") + name;
-  for (int id = 0; id < 64; ++id) {
+  for (int id = 0; id < 128; ++id) {
     const char *s = mmh_kernel_name(id);
-    if (s && want == s) return id;
+    if (s && (want == s || strcmp(name, s) == 0)) return id;   // (the A/B ids of the tools build carry bare names)
   }
   return -1;
 }
@@ -291,21 +318,24 @@ int mmh_time_sgemm(mmh_handle_t h, int m, int n, int k, const float *dA, int lda
   if (!h || reps <= 0 || warmup < 0 || !ms_per_call) return MMH_ERR_INVALID_ARG;
   ENTER(h);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int rc;
-  for (int i = 0; i < warmup; ++i)
-    if ((rc = sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s)) != MMH_OK) return rc;
-  hipEvent_t t0, t1;
-  HIP_TRY(hipEventCreate(&t0));
-  HIP_TRY(hipEventCreate(&t1));
-  HIP_TRY(hipEventRecord(t0, s));
-  for (int i = 0; i < reps; ++i)
-    if ((rc = sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s)) != MMH_OK) return rc;
-  HIP_TRY(hipEventRecord(t1, s));
-  HIP_TRY(hipEventSynchronize(t1));
+  int rc = MMH_OK;
+  for (int i = 0; i < warmup && rc == MMH_OK; ++i) rc = sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s);
+  if (rc != MMH_OK) return rc;
+  // (every exit below destroys what was created: a sticky error or a failed launch inside the loop must not leak events)
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipError_t e = hipEventCreate(&t0);
+  if (e == hipSuccess) e = hipEventCreate(&t1);
+  if (e == hipSuccess) e = hipEventRecord(t0, s);
+  for (int i = 0; i < reps && rc == MMH_OK && e == hipSuccess; ++i)
+    rc = sgemm_on(h, h->kernel, m, n, k, dA, lda, dB, ldb, dC, ldc, 0, s);
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
-  (void)hipEventDestroy(t0);
-  (void)hipEventDestroy(t1);
+  if (rc == MMH_OK && e == hipSuccess) e = hipEventRecord(t1, s);
+  if (rc == MMH_OK && e == hipSuccess) e = hipEventSynchronize(t1);
+  if (rc == MMH_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, t0, t1);
+  if (t0) (void)hipEventDestroy(t0);
+  if (t1) (void)hipEventDestroy(t1);
+  if (rc != MMH_OK) return rc;
+  if (e != hipSuccess) return hip_fail(e, "mmh_time_sgemm");
   *ms_per_call = ms / reps;
   return check_sticky(h);
 }

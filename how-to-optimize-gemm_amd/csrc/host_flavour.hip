@@ -24,14 +24,26 @@ namespace {
 // single launch.  What is left is the H2D time of A, B (and C): PCIe is the floor of this flavour.
 int ensure_pipeline(mmh_context *h) {
   if (h->pipeline_ready) return MMH_OK;
-  HIP_TRY(hipStreamCreateWithFlags(&h->hs_in, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&h->hs_run, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&h->hs_out, hipStreamNonBlocking));
-  for (int i = 0; i < kMaxHostPanels; ++i) {
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_run[i], hipEventDisableTiming));
+  hipError_t e = hipStreamCreateWithFlags(&h->hs_in, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->hs_run, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->hs_out, hipStreamNonBlocking);
+  for (int i = 0; i < kMaxHostPanels && e == hipSuccess; ++i) {
+    e = hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_run[i], hipEventDisableTiming);
   }
-  HIP_TRY(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    // a partial set is of no use and would be created again (and leaked) by the next call: give back what exists
+    for (int i = 0; i < kMaxHostPanels; ++i) {
+      if (h->ev_in[i]) { (void)hipEventDestroy(h->ev_in[i]); h->ev_in[i] = nullptr; }
+      if (h->ev_run[i]) { (void)hipEventDestroy(h->ev_run[i]); h->ev_run[i] = nullptr; }
+    }
+    if (h->ev_b) { (void)hipEventDestroy(h->ev_b); h->ev_b = nullptr; }
+    if (h->hs_in) { (void)hipStreamDestroy(h->hs_in); h->hs_in = nullptr; }
+    if (h->hs_run) { (void)hipStreamDestroy(h->hs_run); h->hs_run = nullptr; }
+    if (h->hs_out) { (void)hipStreamDestroy(h->hs_out); h->hs_out = nullptr; }
+    return hip_fail(e, "host flavour: creating the copy / compute streams and their events");
+  }
   h->pipeline_ready = true;
   return MMH_OK;
 }

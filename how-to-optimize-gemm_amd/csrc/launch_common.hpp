@@ -47,7 +47,9 @@ inline int streamk_grid(long tiles, int cus, int per_cu) {
 inline int streamk_wanted(const mmh_context *ctx, long tiles, int BM, int BN, int per_cu) {
   const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
   const int grid = streamk_grid(tiles, cus, per_cu);
-  if (grid == 0 || tiles % grid == 0) return 0;   // too few tiles, or already balanced
+  if (grid == 0) return 0;                         // too few tiles
+  if (tiles % grid == 0)                           // already balanced: persistent only on request, from two tiles per workgroup
+    return ctx->persist && tiles >= 2L * grid && tiles <= (1L << 24) ? grid : 0;
   if (tiles > (1L << 24)) return 0;
   // Small tiles in nearly full rounds: the plain launch idles less than the hand-overs cost (measured,
   // N = 1408 on 64x64 tiles: 484 tiles for 512 slots run 119 TFLOP/s plain, 109 under stream-K).  From
@@ -70,7 +72,7 @@ inline int streamk_wanted(const mmh_context *ctx, long tiles, int BM, int BN, in
 // even when the policy below prefers the plain launch (warm-up, tools).
 template <typename K>
 int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB, int threads, size_t lds, const char *what,
-                   const GemmArgs &g) {
+                   const GemmArgs &g, long decide_tiles = 0) {
   const int nbm = (g.m + BM - 1) / BM, nbn = (g.n + BN - 1) / BN;
   const long tiles = (long)nbm * nbn;
   const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
@@ -79,6 +81,9 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB,
     if (ok != MMH_OK) return ok;
   }
   const int per_cu = resident_per_cu(ctx, occ_kern, threads, lds);
+  // (decide_tiles: the count the plain-or-persistent decision looks at, when it is not the launch's own -- thin edge
+  // tiles of the K2W kernels; a persistent launch then still covers all `tiles`)
+  if (decide_tiles > 0 && streamk_wanted(ctx, decide_tiles, BM, BN, per_cu) == 0) return 1;
   const int grid = streamk_wanted(ctx, tiles, BM, BN, per_cu);
   if (grid == 0) return 1;
   int *flags = nullptr;

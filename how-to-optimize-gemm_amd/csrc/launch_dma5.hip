@@ -1,6 +1,7 @@
-// launch_dma5.hip -- launchers of the LDS-DMA tiles with a loader wave (sgemm_dma5.hpp, K2W): 64x64, 128x64 and 128x128,
-// each as one workgroup per tile or as the persistent stream-K form (chained parts), each in a whole-tile and a
-// guarded (EDGE: any m, n, k, 4-byte aligned operands) instantiation.  Part of libmmult_hip.so (see internal.hpp).
+// launch_dma5.hip -- launchers of the LDS-DMA tiles with loader waves (sgemm_dma5.hpp, K2W): 64x64, 128x64, 128x128 and
+// the whole-round tiles 96x96 / 160x96 / 160x160, each as one workgroup per tile or as the persistent stream-K form
+// (chained parts), each in a whole-tile and a guarded (EDGE: any m, n, k, 4-byte aligned operands) instantiation.
+// Part of libmmult_hip.so (see internal.hpp).
 #include "launch_common.hpp"
 #include "sgemm_dma5.hpp"
 
@@ -17,43 +18,64 @@ int dma5_form(const mmh_context *ctx, const GemmArgs &g) {
   return 1;
 }
 
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
+// SK: the tile has a stream-K form (the whole-round tiles are launched one workgroup per tile only)
+template <int BM, int BN, int WTM, int WTN, int NBUF, int NL, int D, bool SK = true>
 int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
-  using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF>;
+  constexpr int KB = 32;
+  using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
   const int form = dma5_form<BM, BN, KB>(ctx, g);
   if (form < 0) return 1;
   const bool edge = form == 1;
-  char what[224];
-  if (ctx && ctx->streamk) {
-    // the parts of a range as ONE stream of slices (MMH_OPT_STREAMK_CHAIN, default on), or each with a prologue of its own
-    const bool chained = ctx->sk_chain != 0;
-    auto kern = chained ? sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false, true>
-                        : sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false, false>;
-    auto kern_edge = chained ? sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true>
-                             : sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, false>;
-    auto occ = sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true>;
-    snprintf(what, sizeof what, "sgemm_dma5_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by a loader wave's LDS-DMA%s%s",
-             BM, BN, 16 * WTM, 16 * WTN, KB, NBUF, chained ? ", chained parts" : "", edge ? ", guarded" : "");
-    const int sk = launch_streamk(ctx, edge ? kern_edge : kern, occ, BM, BN, KB, T::THREADS, T::LDS_BYTES, what, g);
-    if (sk <= 0) return sk;
+  char what[256];
+  if constexpr (SK) {
+    if (ctx && ctx->streamk) {
+      // the parts of a range as ONE stream of slices (MMH_OPT_STREAMK_CHAIN, default on), or each with a prologue of its own
+      const bool chained = ctx->sk_chain != 0;
+      auto kern = chained ? sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false, true, NL, D>
+                          : sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false, false, NL, D>;
+      auto kern_edge = chained ? sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true, NL, D>
+                               : sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, false, NL, D>;
+      auto occ = sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true, NL, D>;
+      snprintf(what, sizeof what,
+               "sgemm_dma5_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by %d loader wave%s' LDS-DMA, fragments %d "
+               "k-steps ahead%s%s",
+               BM, BN, 16 * WTM, 16 * WTN, KB, NBUF, NL, NL > 1 ? "s" : "", D, chained ? ", chained parts" : "", edge ? ", guarded" : "");
+      // a thin last tile row / column (sgemm_mfma_dma5_kernel dispatches those last, at a fraction of a tile's cost) does
+      // not make a tile count ragged: plain or persistent is decided on the whole tiles alone
+      long decide = 0;
+      if (edge) {
+        const int nbm = (g.m + BM - 1) / BM, nbn = (g.n + BN - 1) / BN;
+        const int thin_row = (nbm > 1 && g.m - (nbm - 1) * BM <= 16) ? 1 : 0, thin_col = (nbn > 1 && g.n - (nbn - 1) * BN <= 16) ? 1 : 0;
+        if (thin_row || thin_col) decide = (long)(nbm - thin_row) * (nbn - thin_col);
+      }
+      const int sk = launch_streamk(ctx, edge ? kern_edge : kern, occ, BM, BN, KB, T::THREADS, T::LDS_BYTES, what, g, decide);
+      if (sk <= 0) return sk;
+    }
   }
   const int nbm = (g.m + BM - 1) / BM, nbn = (g.n + BN - 1) / BN;
-  auto kern = edge ? sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, true> : sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, false>;
+  auto kern = edge ? sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, true, NL, D>
+                   : sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, false, NL, D>;
   const int ok = allow_big_lds(kern, T::LDS_BYTES);
   if (ok != MMH_OK) return ok;
+  int nbm_arg = nbm;
+#ifdef MMH_AB_BUILD
+  if (!edge && ctx && ctx->ab_group_m > 0) nbm_arg |= ctx->ab_group_m << 16;   // A/B: raster group height (whole-tile kernel only)
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(T::THREADS), T::LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda, g.B,
-                     g.ldb, g.C, g.ldc, g.acc, nbm, nbn);
+                     g.ldb, g.C, g.ldc, g.acc, nbm_arg, nbn);
   HIP_TRY(hipGetLastError());
   snprintf(what, sizeof what,
-           "sgemm_mfma_dma5_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by a loader wave's LDS-DMA, %s%d workgroups of %d threads",
-           BM, BN, 16 * WTM, 16 * WTN, KB, NBUF, edge ? "guarded, " : "", nbm * nbn, T::THREADS);
+           "sgemm_mfma_dma5_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by %d loader wave%s' LDS-DMA, fragments %d k-steps "
+           "ahead, %s%d workgroups of %d threads",
+           BM, BN, 16 * WTM, 16 * WTN, KB, NBUF, NL, NL > 1 ? "s" : "", D, edge ? "guarded, " : "", nbm * nbn, T::THREADS);
   set_last_launch(what);
   return MMH_OK;
 }
 
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
+template <int BM, int BN, int WTM, int WTN, int NBUF, int NL, int D, bool SK = true>
 int warm_dma5_tile(mmh_context *ctx, float *scratch, hipStream_t s) {
-  using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF>;
+  constexpr int KB = 32;
+  using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
   int rc;
   auto plain = [&](auto kern) {
     const int ok = allow_big_lds(kern, T::LDS_BYTES);
@@ -63,13 +85,16 @@ int warm_dma5_tile(mmh_context *ctx, float *scratch, hipStream_t s) {
     HIP_TRY(hipGetLastError());
     return (int)MMH_OK;
   };
-  if ((rc = plain(sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, false>)) != MMH_OK) return rc;
-  if ((rc = plain(sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, true>)) != MMH_OK) return rc;
-  auto sk = sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false, true>;
-  auto ske = sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true>;
-  (void)resident_per_cu(ctx, ske, T::THREADS, T::LDS_BYTES);
-  if ((rc = warm_streamk_kernel(sk, BM, BN, KB, T::THREADS, 160 * 1024, scratch, s)) != MMH_OK) return rc;
-  return warm_streamk_kernel(ske, BM, BN, KB, T::THREADS, 160 * 1024, scratch, s);
+  if ((rc = plain(sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, false, NL, D>)) != MMH_OK) return rc;
+  if ((rc = plain(sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, true, NL, D>)) != MMH_OK) return rc;
+  if constexpr (SK) {
+    auto sk = sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false, true, NL, D>;
+    auto ske = sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true, NL, D>;
+    (void)resident_per_cu(ctx, ske, T::THREADS, T::LDS_BYTES);
+    if ((rc = warm_streamk_kernel(sk, BM, BN, KB, T::THREADS, 160 * 1024, scratch, s)) != MMH_OK) return rc;
+    return warm_streamk_kernel(ske, BM, BN, KB, T::THREADS, 160 * 1024, scratch, s);
+  }
+  return MMH_OK;
 }
 
 }  // namespace
@@ -79,18 +104,42 @@ bool dma5_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g) {
     case MMH_KERNEL_MFMA_64X64_DMA5: return dma5_form<64, 64, 32>(ctx, g) >= 0;
     case MMH_KERNEL_MFMA_128X64_DMA5: return dma5_form<128, 64, 32>(ctx, g) >= 0;
     case MMH_KERNEL_MFMA_128X128_DMA5: return dma5_form<128, 128, 32>(ctx, g) >= 0;
+    case MMH_KERNEL_MFMA_96X96_DMA5: return dma5_form<96, 96, 32>(ctx, g) >= 0;
     default: return false;
   }
 }
 
 int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
   switch (kernel) {
-    case MMH_KERNEL_MFMA_64X64_DMA5:    // 64x64 tile, 4 consumer waves of 32x32 + the loader, 48 KiB ring: 3 workgroups per CU
-      return launch_dma5_tile<64, 64, 32, 2, 2, 3>(ctx, g);
+    //                      BM   BN  WTM WTN NBUF NL D      (NL = 2: measured best for every tile, profiles/r04_notes.md)
+    case MMH_KERNEL_MFMA_64X64_DMA5:    // 64x64 tile, 4 consumer waves of 32x32 + two loaders, 48 KiB ring: 3 workgroups per CU
+      return launch_dma5_tile<64, 64, 2, 2, 3, 2, 2>(ctx, g);
     case MMH_KERNEL_MFMA_128X64_DMA5:   // 128x64 tile, consumers of 64x32, 72 KiB ring: 2 per CU
-      return launch_dma5_tile<128, 64, 32, 4, 2, 3>(ctx, g);
+      return launch_dma5_tile<128, 64, 4, 2, 3, 2, 2>(ctx, g);
     case MMH_KERNEL_MFMA_128X128_DMA5:  // 128x128 tile, consumers of 64x64, 96 KiB ring
-      return launch_dma5_tile<128, 128, 32, 4, 4, 3>(ctx, g);
+      return launch_dma5_tile<128, 128, 4, 4, 3, 2, 2>(ctx, g);
+    case MMH_KERNEL_MFMA_96X96_DMA5:    // 96x96 tile, consumers of 48x48 (column-blocked B), 72 KiB ring: 2 per CU
+      return launch_dma5_tile<96, 96, 3, 3, 3, 1, 2, false>(ctx, g);
+#ifdef MMH_AB_BUILD
+    // A/B (valid results): loader count and fragment look-ahead of the tiles above; the 160-wide whole-round tiles
+    case 64: return launch_dma5_tile<64, 64, 2, 2, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 65: return launch_dma5_tile<64, 64, 2, 2, 3, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 66: return launch_dma5_tile<64, 64, 2, 2, 3, 2, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 67: return launch_dma5_tile<64, 64, 2, 2, 3, 4, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 68: return launch_dma5_tile<128, 64, 4, 2, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 69: return launch_dma5_tile<128, 64, 4, 2, 3, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 70: return launch_dma5_tile<128, 64, 4, 2, 3, 2, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 71: return launch_dma5_tile<128, 64, 4, 2, 3, 4, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 72: return launch_dma5_tile<128, 128, 4, 4, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 73: return launch_dma5_tile<128, 128, 4, 4, 3, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 74: return launch_dma5_tile<128, 128, 4, 4, 3, 2, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 75: return launch_dma5_tile<128, 128, 4, 4, 3, 4, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 76: return launch_dma5_tile<96, 96, 3, 3, 3, 2, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 77: return launch_dma5_tile<96, 96, 3, 3, 3, 4, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 78: return launch_dma5_tile<96, 96, 3, 3, 3, 2, 3, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 79: return launch_dma5_tile<160, 96, 5, 3, 3, 1, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 80: return launch_dma5_tile<160, 160, 5, 5, 3, 1, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+#endif
     default:
       set_last_error("unknown kernel variant");
       return MMH_ERR_INVALID_ARG;
@@ -99,9 +148,10 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
 
 int warm_dma5(mmh_context *ctx, float *scratch, hipStream_t s) {
   int rc;
-  if ((rc = warm_dma5_tile<64, 64, 32, 2, 2, 3>(ctx, scratch, s)) != MMH_OK) return rc;
-  if ((rc = warm_dma5_tile<128, 64, 32, 4, 2, 3>(ctx, scratch, s)) != MMH_OK) return rc;
-  return warm_dma5_tile<128, 128, 32, 4, 4, 3>(ctx, scratch, s);
+  if ((rc = warm_dma5_tile<64, 64, 2, 2, 3, 2, 2>(ctx, scratch, s)) != MMH_OK) return rc;
+  if ((rc = warm_dma5_tile<128, 64, 4, 2, 3, 2, 2>(ctx, scratch, s)) != MMH_OK) return rc;
+  if ((rc = warm_dma5_tile<128, 128, 4, 4, 3, 2, 2>(ctx, scratch, s)) != MMH_OK) return rc;
+  return warm_dma5_tile<96, 96, 3, 3, 3, 1, 2, false>(ctx, scratch, s);
 }
 
 }  // namespace mmh

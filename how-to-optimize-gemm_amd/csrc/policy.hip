@@ -189,7 +189,8 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       const int d = launch_dma5(ctx, kernel, g);
       return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA_128X64, g);
     }
-    case MMH_KERNEL_MFMA_128X128_DMA5: {
+    case MMH_KERNEL_MFMA_128X128_DMA5:
+    case MMH_KERNEL_MFMA_96X96_DMA5: {
       const int d = launch_dma5(ctx, kernel, g);
       return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA, g);
     }
@@ -235,6 +236,9 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return launch_dma(ctx, kernel, g);
     case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59:
       return launch_dma32(ctx, kernel, g);
+    case 64: case 65: case 66: case 67: case 68: case 69: case 70: case 71: case 72: case 73: case 74: case 75: case 76: case 77:
+    case 78: case 79: case 80:
+      return launch_dma5(ctx, kernel, g);
 #endif
     default:
       return launch_reg(ctx, kernel, g);

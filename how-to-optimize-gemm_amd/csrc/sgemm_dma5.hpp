@@ -1,4 +1,4 @@
-// sgemm_dma5.hpp -- K2W: the LDS-DMA tiles with a LOADER wave (round 4).
+// sgemm_dma5.hpp -- K2W: the LDS-DMA tiles with LOADER waves (round 4).
 //
 // Why it exists.  In K2L (sgemm_dma.hpp) each of a workgroup's four waves issues its share of the LDS-DMA pieces between
 // its own MFMAs.  A `buffer_load_dwordx4 ... lds` keeps the issuing wave from issuing anything else for ~60-70 cycles
@@ -7,20 +7,43 @@
 // persistent stream-K launch of the 128x128 tile (N = 2176 .. 2560) -- nobody else fills the rest: 8 pieces x ~38 idle
 // cycles per 4096-cycle slice is the 7-8 % such launches sit below the many-workgroup sizes (profiles/r04_notes.md).
 // Two rebuilds of the loop on 64-cycle matrix instructions (sgemm_dma32.hpp, tools build) hide the pieces and lose more
-// elsewhere.  Here the pieces leave the MFMA waves altogether: a FIFTH wave does nothing but LDS-DMA -- all pieces of a
-// K-slice, two slices ahead, one counted `s_waitcnt vmcnt` and the slice's barrier -- and the four consumer waves run
-// K2L's fragment reads and MFMAs and nothing else.  Same images, same fragments, same MFMA, same k order: the bits
-// of every other kernel here.
+// elsewhere.  Here the pieces leave the MFMA waves altogether: NL extra waves do nothing but LDS-DMA -- the pieces of a
+// K-slice dealt round-robin over them, NBUF - 1 slices ahead, one counted `s_waitcnt vmcnt` and the slice's barrier --
+// and the four consumer waves run K2L's fragment reads and MFMAs and nothing else.  Same images, same fragments, same
+// MFMA, same k order: the bits of every other kernel here.
+//   * NL: one loader issues a 1 KiB piece per ~64 cycles = 16 B/clk; a 64x64 tile consumes exactly that (16 KiB per
+//     1024 matrix-pipe cycles), so its loader is the bound -- it gets TWO; the larger tiles (24 KiB / 2048, 32 KiB /
+//     4096 cycles) are served by one.
+//   * NBUF: ring depth.  A loader's `vmcnt` is a 6-bit counter, so (NBUF - 2) x (pieces per loader and slice) <= 63.
+//   * D: fragments are read D k-steps ahead of the MFMAs that use them; with one wave per SIMD a ds_read_b32/_b64
+//     stream reaches a fifth of the LDS rate (MI355X_MICROARCH.md, LDS: "from ~4 waves per SIMD"), so the one-
+//     workgroup-per-CU launches want more reads in flight than the co-resident ones.
+//
+// Tiles of 32 i x 32 j (round 4: 96x96, 160x160, 160x96 -- the shapes that land N = 1536, 2560, 1920 of the reference
+// sweep on one whole round of CUs).  The A side generalises at once (a fragment is one float per 16-row block).  For
+// an odd number of 16-column blocks per wave (WTN = 3, 5) the B fragment is WTN single floats, lane li -> column
+// 16 u + li of block u ("column-blocked"; the even widths keep K2L's WTN consecutive columns per lane and their vector
+// C stores); a k-row of B is then 384 / 640 bytes, 64 lanes x 16 bytes do not divide it, and the piece -> (row, chunk)
+// map repeats every 3 / 5 pieces = 8 k-rows: that many per-lane offsets, a scalar offset per group.  The two k-rows a
+// 32-lane half of a ds_read_b32 touches (kq = 0, 1) are kept on different banks by XOR-ing bit 4 of the column with the
+// row's parity -- on the source side of the DMA, as always.
+//
+// Thin edge tiles (EDGE instantiations).  One element past a tile boundary (N = 1025) pays a whole extra row and
+// column of tiles; all but one 16-row (16-column) block of such a tile hold no valid element.  A wave with at most one
+// valid block row (block column) runs a thin copy of the consumer side -- accumulators, a rolled K loop, stores -- that
+// keeps block row 0 (block column 0) only (a block of rows >= m or columns >= n is never stored): the tile's fragment
+// reads, barriers and DMA are unchanged, its matrix-pipe time drops to a half, a quarter or an eighth, and the whole
+// tiles of the launch keep the unrolled, branch-free loop.  A plain launch dispatches such tiles last.
 //
 // The loader needs no per-piece address registers: a piece is eight consecutive A rows (or 256 / BN k-rows of B), so a
 // lane's offset inside a piece is one VGPR per image and the piece's position is a scalar offset.
 //
 // Chained segments.  A persistent stream-K workgroup runs several (tile, K-range) segments back to back; K2L starts each
-// with an empty pipeline.  The loader instead walks ONE stream of slices through the ring: while the consumers finish
-// a segment's last two slices it already fetches the next segment's first two, the fragment reads at the end of the
+// with an empty pipeline.  The loaders instead walk ONE stream of slices through the ring: while the consumers finish
+// a segment's last slices they already fetch the next segment's first, the fragment reads at the end of the
 // last slice are the next segment's first, and the consumers' C / partial-tile stores -- and the drain that precedes a
 // publish, which now waits for THEIR stores only -- run under loads in flight.  The ring position a segment starts at
-// is then a run-time value: up to two slices run from copies of the slice body in front of the unrolled ring loop.
+// is then a run-time value: up to NBUF - 1 slices run from copies of the slice body in front of the unrolled ring loop.
 #pragma once
 #include <type_traits>
 
@@ -29,23 +52,41 @@
 
 namespace mmh {
 
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF>
+constexpr int dma5_gcd(int a, int b) { return b == 0 ? a : dma5_gcd(b, a % b); }
+
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, int NL = 1>
 struct Dma5Tile {
-  using T4 = DmaTile<BM, BN, KB, WTM, WTN, NBUF>;   // the consumers' geometry is K2L's
-  static_assert(T4::WAVES == 4, "four consumer waves, one per SIMD");
-  static constexpr int CONSUMERS = 4, LOADER = 4;   // wave index of the loader
-  static constexpr int THREADS = 64 * 5;
-  static constexpr int A_FLOATS = T4::A_FLOATS, B_FLOATS = T4::B_FLOATS, STAGE = T4::STAGE, KS = T4::KS;
-  static constexpr int CHA = T4::CHA, CHB = T4::CHB, NP = CHA + CHB;   // 1 KiB pieces per slice
-  static constexpr int RPC_A = T4::RPC_A, LPR_A = T4::LPR_A, RPC_B = T4::RPC_B, LPR_B = T4::LPR_B;
-  static constexpr int LA = NBUF - 1;
-  static_assert(NP <= 63, "vmcnt is a 6-bit counter");
-  static_assert(RPC_B % 2 == 0, "the half-swap of odd k-rows must not depend on the piece");
+  static_assert(KB == 32, "a K-slice row of A is 128 bytes: a piece of A is eight rows");
+  static_assert(BM == 32 * WTM && BN == 32 * WTN, "four consumer waves as 2 x 2, wave tile 16 WTM x 16 WTN");
+  static_assert(WTM >= 2 && WTM <= 6 && WTN >= 2 && WTN <= 6, "wave tile 32 .. 96 rows / columns");
+  static_assert(NBUF >= 3 && NBUF <= 6, "ring depth");
+  static_assert(NL == 1 || NL == 2 || NL == 4, "one, two or four loader waves");
+  static constexpr int CONSUMERS = 4, LOADER = 4;   // wave index of the first loader
+  static constexpr int WAVES_M = 2, WAVES_N = 2;
+  static constexpr int THREADS = 64 * (CONSUMERS + NL);
+  static constexpr bool BBLK = (WTN % 2) != 0;      // column-blocked B fragments (single floats)
+  static constexpr int A_FLOATS = BM * KB, B_FLOATS = KB * BN, STAGE = A_FLOATS + B_FLOATS, KS = KB / 4;
+  static constexpr int CHA = A_FLOATS / 256, CHB = B_FLOATS / 256, NP = CHA + CHB;   // 1 KiB pieces per slice
+  static constexpr int NPL = NP / NL;                                                // ... per loader
+  static constexpr int CPR_B = BN / 4;                                    // 16-byte chunks per k-row of B
+  static constexpr int PB = CPR_B / dma5_gcd(64, CPR_B);                  // pieces until the lane -> (row, chunk) map repeats
+  static constexpr int RB = 64 * PB / CPR_B;                              // k-rows those pieces hold
+  static constexpr int LA = NBUF - 1;                                     // slices of look-ahead
+  static_assert(CHA % NL == 0 && CHB % NL == 0, "the pieces of each image divide over the loaders");
+  static_assert(CHB % PB == 0 && RB % 2 == 0, "whole periods; the row-parity swizzle must not depend on the period");
+  static_assert((CHB / PB) % NL == 0, "B's piece periods divide over the loaders");
+  static_assert((LA - 1) * NPL <= 63, "vmcnt is a 6-bit counter");
   static constexpr size_t RING_BYTES = (size_t)NBUF * STAGE * sizeof(float);
   static constexpr size_t LDS_BYTES = RING_BYTES + 64;   // + the line the stream-K body passes a word through
+  // the 16-byte chunk of B's k-row r that belongs at physical chunk position pc of the LDS row
+  static __device__ __forceinline__ int src_chunk_b(int r, int pc) {
+    if constexpr (BBLK) return pc ^ ((r & 1) << 2);          // columns +-16 on odd rows
+    else if constexpr (WTN == 2) return pc ^ ((r & 1) << 3); // halves of a 64-float row swapped on odd rows (8-byte fragments)
+    else return pc;
+  }
 };
 
-// what follows a segment in its workgroup's stream, and the state carried from segment to segment (see sgemm_dma32.hpp)
+// what follows a segment in its workgroup's stream, and the state carried from segment to segment
 struct Dma5Next {
   int tm = 0, tn = 0, kb = 0, len = 0;
 };
@@ -54,46 +95,57 @@ struct Dma5Link {
   bool primed = false;
 };
 
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool PART_WT = false, bool EDGE = false, bool CHAIN = false>
+// D: fragment prefetch distance in k-steps (ring of SLOTS register sets, slot = k-step mod SLOTS)
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool PART_WT = false, bool EDGE = false, bool CHAIN = false,
+          int NL = 1, int D = 2>
 struct Dma5Segment {
-  using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF>;
+  using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
+  static constexpr bool BBLK = T::BBLK;
   typedef float bfrag_t __attribute__((ext_vector_type(WTN)));
   typedef float afrag_t __attribute__((ext_vector_type(WTM)));
   typedef float c_vec_u __attribute__((ext_vector_type(WTN), aligned(4)));
   using c_vec = std::conditional_t<EDGE, c_vec_u, bfrag_t>;
-  static constexpr int D = 2;   // fragments are read D k-steps ahead of the MFMAs that use them (ring of four sets)
+  static constexpr int SLOTS = D <= 3 ? 4 : 8;
+  static_assert(D >= 1 && D < T::KS && T::KS % SLOTS == 0 && D < SLOTS, "fragment slots are numbered by k-step mod SLOTS");
 
   struct Frags {
-    afrag_t a[4];
-    bfrag_t b[4];
+    float a[SLOTS][WTM];
+    float b[SLOTS][WTN];
   };
 
-  // per-lane constants: the consumers' fragment addresses, the loader's offsets inside a piece
+  // per-lane constants: the consumers' fragment addresses, the loaders' offsets inside a piece
   struct Lane {
-    int wave, wm, wn, li, kq;
+    int wave, wm, wn, li, kq, ld;
     bool loader;
-    int a_off[8], b_off;
-    uint32_t voff_a, voff_b;
+    int a_off[8], b_off[BBLK ? WTN : 1];
+    uint32_t voff_a, voff_b[T::PB];
     __device__ __forceinline__ void init(int lda, int ldb) {
       const int tid = threadIdx.x, lane = tid & 63;
       wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-      loader = wave == T::LOADER;
-      wm = wave / T::T4::WAVES_N;
-      wn = wave % T::T4::WAVES_N;
+      loader = wave >= T::LOADER;
+      ld = loader ? wave - T::LOADER : 0;
+      wm = (wave & 3) / T::WAVES_N;
+      wn = (wave & 3) % T::WAVES_N;
       li = lane & 15;
       kq = lane >> 4;
 #pragma unroll
       for (int j = 0; j < 8; ++j) a_off[j] = (wm * 16 * WTM + li) * KB + 4 * (j ^ (li & 7)) + kq;
-      b_off = WTN == 4 ? T::A_FLOATS + kq * BN + wn * 64 + 4 * li
-                       : T::A_FLOATS + kq * BN + 4 * ((wn * 8 + (li >> 1)) ^ ((kq & 1) << 3)) + 2 * (li & 1);
-      // loader: the 16-byte chunk a lane fetches is the one that belongs at its (swizzled) position of the image
-      {
-        const int r = lane / T::LPR_A, p = lane % T::LPR_A;                // piece j holds A rows RPC_A j + r
-        voff_a = (uint32_t)(r * lda + 4 * (p ^ (r & 7))) * 4u;             // (RPC_A = 8: the row's swizzle is r's)
+      if constexpr (BBLK) {
+#pragma unroll
+        for (int u = 0; u < WTN; ++u) b_off[u] = T::A_FLOATS + kq * BN + 16 * ((wn * WTN + u) ^ (kq & 1)) + li;
+      } else {
+        b_off[0] = WTN == 4 ? T::A_FLOATS + kq * BN + wn * 64 + 4 * li
+                            : T::A_FLOATS + kq * BN + 4 * ((wn * 8 + (li >> 1)) ^ ((kq & 1) << 3)) + 2 * (li & 1);
       }
+      // loaders: the 16-byte chunk a lane fetches is the one that belongs at its (swizzled) position of the image
       {
-        const int r = lane / T::LPR_B, p = lane % T::LPR_B;                // piece j holds k-rows RPC_B j + r
-        voff_b = (uint32_t)(r * ldb + 4 * (WTN == 2 ? (p ^ ((r & 1) << 3)) : p)) * 4u;
+        const int r = lane / 8, p = lane % 8;                              // piece j holds A rows 8 j + r
+        voff_a = (uint32_t)(r * lda + 4 * (p ^ (r & 7))) * 4u;
+      }
+#pragma unroll
+      for (int jj = 0; jj < T::PB; ++jj) {
+        const int c = 64 * jj + lane, r = c / T::CPR_B, pc = c % T::CPR_B; // piece PB g + jj holds k-rows RB g + r
+        voff_b[jj] = (uint32_t)(r * ldb + 4 * T::src_chunk_b(r, pc)) * 4u;
       }
     }
   };
@@ -102,9 +154,7 @@ struct Dma5Segment {
                                              int lda, const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                              int tm, int tn, int kb, int ke, bool init_from_c, const float *part_in,
                                              float *part_out, Frags &fr, Dma5Link &link, const Dma5Next nx = Dma5Next{}) {
-    constexpr int KS = T::KS, STAGE = T::STAGE, A_FLOATS = T::A_FLOATS, NP = T::NP, LA = T::LA;
-    static_assert(KB == 32 && T::RPC_A == 8, "a piece of A is eight rows of a 32-deep slice");
-    static_assert(KS % 4 == 0 && KS > 2 * D, "fragment slots are numbered by k-step mod 4");
+    constexpr int KS = T::KS, STAGE = T::STAGE, A_FLOATS = T::A_FLOATS, NPL = T::NPL, LA = T::LA;
     const int row0 = tm * BM, col0 = tn * BN;
     const int rows_valid = EDGE ? min(BM, m - row0) : BM;
     const int cols_valid = EDGE ? min(BN, n - col0) : BN;
@@ -125,9 +175,9 @@ struct Dma5Segment {
     }
 
     if (L.loader) {
-      // ------------------------------------------------------------------ the loader wave
-      // descriptors as base + extent SCALARS, packed where they are used (sgemm_dma32.hpp: a select between two
-      // 128-bit descriptors goes through scratch memory)
+      // ------------------------------------------------------------------ the loader waves
+      // descriptors as base + extent SCALARS, packed where they are used (a select between two 128-bit descriptors goes
+      // through scratch memory)
       auto ext_a = [&](int valid) { return EDGE ? (uint32_t)(((valid - 1) * lda + k) * 4) : 0x7fffffffu; };
       auto ext_b = [&](int valid) { return EDGE ? (uint32_t)(((k - 1) * ldb + valid) * 4) : 0x7fffffffu; };
       const float *own_pa = A + (size_t)row0 * lda, *own_pb = B + col0;
@@ -143,7 +193,8 @@ struct Dma5Segment {
         }
       }
       const int kdelta = nx.kb - ke;
-      auto issue = [&](float *buf, int kt) {   // all NP pieces of stream slice kt into ring buffer `buf`
+      const int ld = L.ld;
+      auto issue = [&](float *buf, int kt) {   // this loader's pieces of stream slice kt into ring buffer `buf`
         const bool own = kt < ke;
         const int ks = own ? kt : kt + kdelta;
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(own ? own_pa : next_pa), 0,
@@ -151,13 +202,20 @@ struct Dma5Segment {
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(own ? own_pb : next_pb), 0,
                                                                             own ? own_eb : next_eb, 0x00020000);
         const uint32_t off_a = (uint32_t)(ks * KB) * 4u, off_b = (uint32_t)(ks * KB) * (uint32_t)ldb * 4u;
-        static_for<T::CHA>([&](auto j_c) {
-          constexpr int j = decltype(j_c)::value;
-          DmaPiece::one(ra, buf + 256 * j, L.voff_a, off_a + (uint32_t)(T::RPC_A * j) * (uint32_t)lda * 4u);
+        // pieces j = NL i + ld of each image (ld is wave-uniform: scalar arithmetic)
+        static_for<T::CHA / NL>([&](auto i_c) {
+          constexpr int i = decltype(i_c)::value;
+          const int j = NL * i + ld;
+          DmaPiece::one(ra, buf + 256 * j, L.voff_a, off_a + (uint32_t)(8 * j) * (uint32_t)lda * 4u);
         });
-        static_for<T::CHB>([&](auto j_c) {
-          constexpr int j = decltype(j_c)::value;
-          DmaPiece::one(rb, buf + A_FLOATS + 256 * j, L.voff_b, off_b + (uint32_t)(T::RPC_B * j) * (uint32_t)ldb * 4u);
+        // B: whole periods g = NL i2 + ld (PB pieces each, whose lane offsets are compile-time picks)
+        static_for<T::CHB / T::PB / NL>([&](auto i_c) {
+          constexpr int i2 = decltype(i_c)::value;
+          const int g = NL * i2 + ld;
+          static_for<T::PB>([&](auto jj_c) {
+            constexpr int jj = decltype(jj_c)::value;
+            DmaPiece::one(rb, buf + A_FLOATS + 256 * (T::PB * g + jj), L.voff_b[jj], off_b + (uint32_t)(T::RB * g) * (uint32_t)ldb * 4u);
+          });
         });
       };
       if (!primed) {
@@ -165,14 +223,14 @@ struct Dma5Segment {
           constexpr int S = decltype(s_c)::value;
           issue(lds + S * STAGE, kb + S);
         });
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * NP) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * NPL) : "memory");
         __builtin_amdgcn_s_barrier();
       }
       int p2 = (pos + LA) % NBUF;   // ring position of stream slice kt + LA
       for (int kt = kb; kt < ke; ++kt) {
         issue(lds + p2 * STAGE, kt + LA);   // into the buffer slice kt - 1 was read from (its barrier is behind us)
         p2 = p2 == NBUF - 1 ? 0 : p2 + 1;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * NP) : "memory");   // stream slice kt + 1 is whole
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * NPL) : "memory");   // stream slice kt + 1 is whole
         __builtin_amdgcn_s_barrier();
       }
       if (!chain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may still be landing in LDS
@@ -180,68 +238,136 @@ struct Dma5Segment {
     }
 
     // -------------------------------------------------------------------- the consumer waves
+    // EDGE: how many of this wave's 16-row / 16-column blocks hold a valid element (wave-uniform).  Block t holds rows
+    // 16 (WTM wm + t) .. + 15 of the tile; block u holds, column-blocked, columns 16 (WTN wn + u) .. + 15, and with
+    // WTN consecutive columns per lane the columns 16 WTN wn + WTN li + u -- its first (li = 0) is its smallest.
+    // A wave with at most ONE valid block row (or block column) runs a thin copy of everything below that keeps,
+    // computes and stores block row 0 (block column 0) only: what a shape a few elements past a tile boundary needs
+    // (N = 1025: an edge tile's matrix-pipe time drops to a half, a quarter or -- the waves with no valid block --
+    // an MFMA per k-step).  The copies are whole (accumulators, K loop, stores): no accumulator ever merges from two
+    // paths, so the whole tiles' registers and loop are what they are without the thin forms.
+    if constexpr (EDGE) {
+      const int rv = rows_valid - L.wm * 16 * WTM, cv = cols_valid - L.wn * 16 * WTN;
+      const bool thin_m = __builtin_amdgcn_readfirstlane((int)(rv <= 16)) != 0;
+      const bool thin_n = __builtin_amdgcn_readfirstlane((int)(BBLK ? cv <= 16 : cv <= 1)) != 0;
+      if (thin_m && thin_n) {
+        consume(std::true_type{}, std::true_type{}, lds, L, m, n, k, C, ldc, row0, col0, rows_valid, cols_valid, kb, ke, pos, primed, chain,
+                init_from_c, part_in, part_out, fr);
+        return;
+      }
+      if (thin_m) {
+        consume(std::true_type{}, std::false_type{}, lds, L, m, n, k, C, ldc, row0, col0, rows_valid, cols_valid, kb, ke, pos, primed, chain,
+                init_from_c, part_in, part_out, fr);
+        return;
+      }
+      if (thin_n) {
+        consume(std::false_type{}, std::true_type{}, lds, L, m, n, k, C, ldc, row0, col0, rows_valid, cols_valid, kb, ke, pos, primed, chain,
+                init_from_c, part_in, part_out, fr);
+        return;
+      }
+    }
+    consume(std::false_type{}, std::false_type{}, lds, L, m, n, k, C, ldc, row0, col0, rows_valid, cols_valid, kb, ke, pos, primed, chain,
+            init_from_c, part_in, part_out, fr);
+  }
+
+  // The consumer side of a segment with NT x NU of the wave's WTM x WTN blocks kept (all of them, or -- thin edge
+  // tiles -- block row 0 / block column 0 only).
+  template <class TM1, class TN1>
+  static __device__ __forceinline__ void consume(TM1, TN1, float *lds, const Lane &L, int m, int n, int k, float *__restrict__ C,
+                                                 int ldc, int row0, int col0, int rows_valid, int cols_valid, int kb, int ke,
+                                                 int pos, bool primed, bool chain, bool init_from_c, const float *part_in,
+                                                 float *part_out, Frags &fr) {
+    constexpr int KS = T::KS, STAGE = T::STAGE;
+    constexpr bool THIN = TM1::value || TN1::value;
+    constexpr int NT = TM1::value ? 1 : WTM, NU = TN1::value ? 1 : WTN;   // blocks kept
+    const bool ragged_k = EDGE && ke * KB > k;
     const int crow = row0 + L.wm * 16 * WTM + 4 * L.kq;
-    const int ccol = col0 + L.wn * 16 * WTN + WTN * L.li;
-    const bool whole_c = !EDGE || (rows_valid == BM && cols_valid == BN);
-    f32x4 acc[WTM][WTN];
+    // even widths: this lane's WTN consecutive columns; column-blocked: column of block 0 (block u: + 16 u)
+    const int ccol = BBLK ? col0 + L.wn * 16 * WTN + L.li : col0 + L.wn * 16 * WTN + WTN * L.li;
+    const bool whole_c = !EDGE || (!THIN && rows_valid == BM && cols_valid == BN);
+    constexpr bool VEC = !BBLK && !THIN;   // this lane's columns of a row are one vector
+    auto col_of = [&](int u) { return BBLK ? ccol + 16 * u : ccol + u; };
+    f32x4 acc[NT][NU];
     if (part_in) {
 #pragma unroll
-      for (int t = 0; t < WTM; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bfrag_t v = *reinterpret_cast<const bfrag_t *>(part_in + (size_t)(crow + 16 * t + r - row0) * BN + (ccol - col0));
+          const float *src = part_in + (size_t)(crow + 16 * t + r - row0) * BN + (ccol - col0);
+          if constexpr (VEC) {
+            const bfrag_t v = *reinterpret_cast<const bfrag_t *>(src);
 #pragma unroll
-          for (int u = 0; u < WTN; ++u) acc[t][u][r] = v[u];
+            for (int u = 0; u < NU; ++u) acc[t][u][r] = v[u];
+          } else {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) acc[t][u][r] = src[BBLK ? 16 * u : u];
+          }
         }
     } else if (init_from_c) {
 #pragma unroll
-      for (int t = 0; t < WTM; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = crow + 16 * t + r;
-          bfrag_t v = {};
-          if (whole_c) {
-            v = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
-          } else if (row < m) {
+          float v[NU];
 #pragma unroll
-            for (int u = 0; u < WTN; ++u)
-              if (ccol + u < n) v[u] = C[(size_t)row * ldc + ccol + u];
+          for (int u = 0; u < NU; ++u) v[u] = 0.0f;
+          if constexpr (VEC) {
+            if (whole_c) {
+              const bfrag_t w = *reinterpret_cast<const c_vec *>(C + (size_t)row * ldc + ccol);
+#pragma unroll
+              for (int u = 0; u < NU; ++u) v[u] = w[u];
+            } else if (row < m) {
+#pragma unroll
+              for (int u = 0; u < NU; ++u)
+                if (col_of(u) < n) v[u] = C[(size_t)row * ldc + col_of(u)];
+            }
+          } else if (whole_c || row < m) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+              if (whole_c || col_of(u) < n) v[u] = C[(size_t)row * ldc + col_of(u)];
           }
 #pragma unroll
-          for (int u = 0; u < WTN; ++u) acc[t][u][r] = v[u];
+          for (int u = 0; u < NU; ++u) acc[t][u][r] = v[u];
         }
     } else {
 #pragma unroll
-      for (int t = 0; t < WTM; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int u = 0; u < WTN; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NU; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    auto frag_a = [&](const float *buf, auto ks_c) {
+    auto frag_a = [&](const float *buf, auto ks_c, float (&a)[WTM]) {
       constexpr int ks = decltype(ks_c)::value;
-      afrag_t a;
 #pragma unroll
       for (int t = 0; t < WTM; ++t) a[t] = buf[L.a_off[ks & 7] + 4 * (ks & ~7) + t * 16 * KB];
-      return a;
     };
-    auto frag_b = [&](const float *buf, auto ks_c) {
+    auto frag_b = [&](const float *buf, auto ks_c, float (&b)[WTN]) {
       constexpr int ks = decltype(ks_c)::value;
-      return *reinterpret_cast<const bfrag_t *>(buf + L.b_off + 4 * ks * BN);
+      if constexpr (BBLK) {
+#pragma unroll
+        for (int u = 0; u < WTN; ++u) b[u] = buf[L.b_off[u] + 4 * ks * BN];
+      } else {
+        const bfrag_t v = *reinterpret_cast<const bfrag_t *>(buf + L.b_off[0] + 4 * ks * BN);
+#pragma unroll
+        for (int u = 0; u < WTN; ++u) b[u] = v[u];
+      }
     };
     if (!primed) {
-      __builtin_amdgcn_s_barrier();   // the loader has the first slice in LDS
+      __builtin_amdgcn_s_barrier();   // the loaders have the first slice in LDS
       static_for<D>([&](auto d_c) {
         constexpr int d = decltype(d_c)::value;
-        fr.a[d] = frag_a(lds, d_c);
-        fr.b[d] = frag_b(lds, d_c);
+        frag_a(lds, d_c, fr.a[d]);
+        frag_b(lds, d_c, fr.b[d]);
       });
     }
     dma_stamp(1);
 
-    // One K-slice out of ring buffer `buf` (K2L's slice body without its DMA pieces): per k-step the two fragment reads
-    // for k-step ks + D, then the MFMAs of k-step ks; before k-step KS - D the slice's barrier -- from there on the reads go
-    // to the NEXT buffer (the loader's counted wait says it is whole), and every read of this one has been issued.
+    // One K-slice out of ring buffer `buf` (K2L's slice body without its DMA pieces): per k-step the fragment reads
+    // for k-step ks + D (all of them, thin or not: the next segment of a chain may be a whole tile), then the MFMAs of
+    // k-step ks; before k-step KS - D the slice's barrier -- from there on the reads go to the NEXT buffer (the loaders'
+    // counted wait says it is whole), and every read of this one has been issued.
     auto slice_at = [&](int kt, const float *buf, const float *nxt, auto tail_c) {
-      constexpr bool TAIL = decltype(tail_c)::value;   // EDGE: the problem's last, partial slice
+      constexpr bool TAIL = decltype(tail_c)::value;   // EDGE: a slice that may hold k's past the end (operands masked)
       const int krem = TAIL ? k - kt * KB : KB;
       static_for<KS>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
@@ -250,28 +376,31 @@ struct Dma5Segment {
           __builtin_amdgcn_s_barrier();
         }
         if constexpr (ks + D < KS) {
-          fr.a[(ks + D) & 3] = frag_a(buf, std::integral_constant<int, ks + D>{});
-          fr.b[(ks + D) & 3] = frag_b(buf, std::integral_constant<int, ks + D>{});
+          frag_a(buf, std::integral_constant<int, ks + D>{}, fr.a[(ks + D) % SLOTS]);
+          frag_b(buf, std::integral_constant<int, ks + D>{}, fr.b[(ks + D) % SLOTS]);
         } else {
-          fr.a[(ks + D) & 3] = frag_a(nxt, std::integral_constant<int, ks + D - KS>{});
-          fr.b[(ks + D) & 3] = frag_b(nxt, std::integral_constant<int, ks + D - KS>{});
+          frag_a(nxt, std::integral_constant<int, ks + D - KS>{}, fr.a[(ks + D) % SLOTS]);
+          frag_b(nxt, std::integral_constant<int, ks + D - KS>{}, fr.b[(ks + D) % SLOTS]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        afrag_t a = fr.a[ks & 3];
-        bfrag_t b = fr.b[ks & 3];
+        float a[NT], b[NU];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = fr.a[ks % SLOTS][t];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) b[u] = fr.b[ks % SLOTS][u];
         if constexpr (TAIL) {
           // A's columns past k are the next row's floats or the caller's padding (NaN included): zero this lane's
           // operands of the k's that do not exist (B's rows there are zeros by descriptor; belt and braces)
           const bool live = 4 * ks + L.kq < krem;
 #pragma unroll
-          for (int t = 0; t < WTM; ++t) a[t] = live ? a[t] : 0.0f;
+          for (int t = 0; t < NT; ++t) a[t] = live ? a[t] : 0.0f;
 #pragma unroll
-          for (int u = 0; u < WTN; ++u) b[u] = live ? b[u] : 0.0f;
+          for (int u = 0; u < NU; ++u) b[u] = live ? b[u] : 0.0f;
         }
 #pragma unroll
-        for (int t = 0; t < WTM; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int u = 0; u < WTN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
+          for (int u = 0; u < NU; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       });
     };
@@ -281,37 +410,50 @@ struct Dma5Segment {
     };
     const int ke_main = ragged_k ? ke - 1 : ke;
     int kt = kb;
-    // ONE exit per loop (with `break`s between the unrolled slices hipcc copies the accumulators on the hot path)
-    if constexpr (CHAIN) {   // up to two slices to reach ring position 0
-      if (pos == 1 && kt < ke_main) { slice(kt, std::integral_constant<int, 1>{}); ++kt; pos = 2; }
-      if (pos == 2 && kt < ke_main) { slice(kt, std::integral_constant<int, 2>{}); ++kt; pos = 0; }
-    }
-    while (kt + NBUF <= ke_main) {
-      slice(kt, std::integral_constant<int, 0>{});
-      slice(kt + 1, std::integral_constant<int, 1>{});
-      slice(kt + 2, std::integral_constant<int, 2>{});
-      kt += NBUF;
-    }
-    if (kt < ke_main) {   // (only reached at ring position 0)
-      slice(kt, std::integral_constant<int, 0>{});
-      ++kt;
-      pos = 1;
-      if (kt < ke_main) {
-        slice(kt, std::integral_constant<int, 1>{});
-        ++kt;
-        pos = 2;
-      }
-    }
-    if constexpr (EDGE) {
-      if (ragged_k) {   // one slice per tile pays for a run-time ring position (an address add per fragment read)
-        const int nx1 = pos == 2 ? 0 : pos + 1;
+    if constexpr (THIN) {
+      // a rolled loop over run-time ring positions (an address add per fragment read, the operands masked against k
+      // in every slice -- nothing beside the MFMAs saved), the problem's last slice included
+#pragma unroll 1
+      for (; kt < ke; ++kt) {
+        const int nx1 = pos == NBUF - 1 ? 0 : pos + 1;
         slice_at(kt, lds + pos * STAGE, lds + nx1 * STAGE, std::true_type{});
+        pos = nx1;
+      }
+    } else {
+      // ONE exit per loop (with `break`s between the unrolled slices hipcc copies the accumulators on the hot path)
+      if constexpr (CHAIN) {   // up to NBUF - 1 slices to reach ring position 0
+        static_for<NBUF - 1>([&](auto p_c) {
+          constexpr int P = decltype(p_c)::value + 1;
+          if (pos == P && kt < ke_main) {
+            slice(kt, std::integral_constant<int, P>{});
+            ++kt;
+            pos = (P + 1) % NBUF;
+          }
+        });
+      }
+      while (kt + NBUF <= ke_main) {
+        static_for<NBUF>([&](auto c_c) { slice(kt + decltype(c_c)::value, c_c); });
+        kt += NBUF;
+      }
+      static_for<NBUF - 1>([&](auto c_c) {   // (only reached at ring position 0)
+        constexpr int CUR = decltype(c_c)::value;
+        if (kt < ke_main) {
+          slice(kt, std::integral_constant<int, CUR>{});
+          ++kt;
+          pos = CUR + 1;
+        }
+      });
+      if constexpr (EDGE) {
+        if (ragged_k) {   // one slice per tile pays for a run-time ring position (an address add per fragment read)
+          const int nx1 = pos == NBUF - 1 ? 0 : pos + 1;
+          slice_at(kt, lds + pos * STAGE, lds + nx1 * STAGE, std::true_type{});
+        }
       }
     }
     if (!chain) {
       // keep the fragments prefetched past the last slice formally alive (see sgemm_dma.hpp)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < SLOTS; ++i) {
 #pragma unroll
         for (int u = 0; u < WTN; ++u) asm volatile("" ::"v"(fr.b[i][u]));
 #pragma unroll
@@ -323,24 +465,32 @@ struct Dma5Segment {
     auto out_vec = [&](int t, int r) {
       bfrag_t v;
 #pragma unroll
-      for (int u = 0; u < WTN; ++u) v[u] = acc[t][u][r];
+      for (int u = 0; u < WTN; ++u) v[u] = u < NU ? acc[t][u < NU ? u : 0][r] : 0.0f;
       return v;
     };
     if (part_out) {
       __amdgpu_buffer_rsrc_t rsrc_p;
       if constexpr (PART_WT) rsrc_p = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, BM * BN * 4, 0x00020000);
 #pragma unroll
-      for (int t = 0; t < WTM; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = crow + 16 * t + r;
           const bfrag_t v = out_vec(t, r);
-          if constexpr (PART_WT) {
-            const uint32_t off = (uint32_t)(((row - row0) * BN + (ccol - col0)) * 4);
+          const uint32_t off = (uint32_t)(((row - row0) * BN + (ccol - col0)) * 4);
+          if constexpr (!VEC) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+              constexpr int STEP = BBLK ? 16 : 1;
+              if constexpr (PART_WT) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)v[u]), rsrc_p, off + 4u * STEP * u, 0, 16);
+              else part_out[(size_t)(row - row0) * BN + (ccol - col0) + STEP * u] = v[u];
+            }
+          } else if constexpr (PART_WT) {
             if constexpr (WTN == 4) {
               typedef int i32x4_t __attribute__((ext_vector_type(4)));
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rsrc_p, off, 0, 16);
             } else {
+              static_assert(!VEC || WTN == 2 || WTN == 4 || !PART_WT, "write-through partial tiles: 8- or 16-byte vectors");
               typedef int i32x2_t __attribute__((ext_vector_type(2)));
               __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, v), rsrc_p, off, 0, 16);
             }
@@ -348,22 +498,24 @@ struct Dma5Segment {
             *reinterpret_cast<bfrag_t *>(part_out + (size_t)(row - row0) * BN + (ccol - col0)) = v;
           }
         }
-    } else if (whole_c) {
+    } else if (VEC && whole_c) {
+      if constexpr (VEC) {
 #pragma unroll
-      for (int t = 0; t < WTM; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<c_vec *>(C + (size_t)(crow + 16 * t + r) * ldc + ccol) = out_vec(t, r);
+          for (int r = 0; r < 4; ++r) *reinterpret_cast<c_vec *>(C + (size_t)(crow + 16 * t + r) * ldc + ccol) = out_vec(t, r);
+      }
     } else {
 #pragma unroll
-      for (int t = 0; t < WTM; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = crow + 16 * t + r;
           const bfrag_t v = out_vec(t, r);
-          if (row < m) {
+          if (whole_c || row < m) {
 #pragma unroll
-            for (int u = 0; u < WTN; ++u)
-              if (ccol + u < n) C[(size_t)row * ldc + ccol + u] = v[u];
+            for (int u = 0; u < NU; ++u)
+              if (whole_c || col_of(u) < n) C[(size_t)row * ldc + col_of(u)] = v[u];
           }
         }
     }
@@ -371,15 +523,42 @@ struct Dma5Segment {
 };
 
 // One workgroup per C tile (XCD-aware block -> tile map), whole K range.
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false>
-__global__ void __launch_bounds__(320)
+// EDGE: a last tile row / column that is THIN (at most 16 valid rows / columns: its waves run the thin copies of the
+// consumer) is taken out of the raster and dispatched LAST: the whole tiles fill the CUs first, in the order a launch
+// of the trimmed shape would, and the thin tiles -- a fraction of a whole tile's matrix-pipe time each -- land beside
+// them as second workgroups.  In raster order they would take first-round slots and push whole tiles into a second
+// round (N = 1025: 289 tiles of 64x64 for 256 CUs, 33 of them thin).
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false, int NL = 1, int D = 2>
+__global__ void __launch_bounds__(64 * (4 + NL))
 sgemm_mfma_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
                        float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, false, EDGE, false>;
+  using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, false, EDGE, false, NL, D>;
   int tm, tn;
   dma_stamp(0);
-  block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
+  if constexpr (EDGE) {
+    const int thin_row = (nbm > 1 && m - (nbm - 1) * BM <= 16) ? 1 : 0, thin_col = (nbn > 1 && n - (nbn - 1) * BN <= 16) ? 1 : 0;
+    const int nbm_f = nbm - thin_row, nbn_f = nbn - thin_col, n_full = nbm_f * nbn_f;
+    int r = (int)blockIdx.x - n_full;
+    if (r < 0) {
+      block_to_tile(blockIdx.x, n_full, nbm_f, nbn_f, tm, tn);
+    } else if (thin_col && r < nbm) {   // the thin column, top to bottom (its corner with a thin row included)
+      tm = r;
+      tn = nbn - 1;
+    } else {                            // the thin row, left to right
+      if (thin_col) r -= nbm;
+      tm = nbm - 1;
+      tn = r;
+    }
+  } else {
+#ifdef MMH_AB_BUILD   // tools build: the raster group height rides in nbm's upper half (0: GROUP_M)
+    const int gm = nbm >> 16;
+    nbm &= 0xffff;
+    block_to_tile_g(blockIdx.x, nbm * nbn, nbm, nbn, gm > 0 ? gm : GROUP_M, tm, tn);
+#else
+    block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
+#endif
+  }
   typename S::Lane L;
   L.init(lda, ldb);
   typename S::Frags fr;
@@ -395,15 +574,15 @@ sgemm_mfma_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda
 // looked at (they depend on nobody); should the word say the head's owner is not running (the wait-free path: leave),
 // they are dropped.
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE, bool CHAINED>
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE, bool CHAINED, int NL, int D>
 __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
                                               const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                               int accumulate, int nbm, int nbn, int *__restrict__ flags,
                                               float *__restrict__ parts, const int *__restrict__ order,
                                               const int *__restrict__ place, int *__restrict__ stats) {
   constexpr bool chained = CHAINED;
-  using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, true, EDGE, true>;
-  using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF>;
+  using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, true, EDGE, true, NL, D>;
+  using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
   const int nk = (k + KB - 1) / KB;
   const int Tn = nbm * nbn, G = gridDim.x;
   const int xcd = blockIdx.x % NXCD, local = blockIdx.x / NXCD;
@@ -507,7 +686,7 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
       }
       if (uniform(seen) != SK_HEAD_DONE) {
         // the head's owner is not running: it will find our mark and finish the tile itself.  The slices fetched
-        // ahead for this tail are dropped -- once they have landed (the loader's wait).
+        // ahead for this tail are dropped -- once they have landed (the loaders' wait).
         if (L.loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         link.primed = false;
         continue;
@@ -529,7 +708,7 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
            p.kind == HEAD ? my_slot : nullptr, fr, link, nx);
     if (p.kind == HEAD) {
       // Publish (cdna guide G16, recipe R1): the partial tile went out write-through (sc1) -- every storing wave
-      // drains ITS stores (the loader's loads in flight are its own business), the workgroup meets, ONE lane ORs DONE in.
+      // drains ITS stores (the loaders' loads in flight are their own business), the workgroup meets, ONE lane ORs DONE in.
       if (!L.loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0)
@@ -539,15 +718,15 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
 }
 
 // CHAINED = false: every part of a range starts with an empty pipeline (the A/B baseline, tools build)
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false, bool CHAINED = true>
-__global__ void __launch_bounds__(320)
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false, bool CHAINED = true, int NL = 1, int D = 2>
+__global__ void __launch_bounds__(64 * (4 + NL))
 sgemm_dma5_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B,
                           int ldb, float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn,
                           int *__restrict__ flags, float *__restrict__ parts, const int *__restrict__ order,
                           const int *__restrict__ place, int *__restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  streamk5_body<BM, BN, KB, WTM, WTN, NBUF, EDGE, CHAINED>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn, flags,
-                                                            parts, order, place, stats);
+  streamk5_body<BM, BN, KB, WTM, WTN, NBUF, EDGE, CHAINED, NL, D>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn,
+                                                                   flags, parts, order, place, stats);
 }
 
 }  // namespace mmh

@@ -86,19 +86,23 @@ __device__ __forceinline__ void static_for(F &&f) {
 // Bijective remap of the 1-D block id so that each XCD (private 4 MiB L2)
 // works on a contiguous run of C tiles, then a grouped raster inside the run
 // so that co-resident blocks share A row-panels and B column-panels.
-__device__ __forceinline__ void block_to_tile(int bid, int nblk, int nbm, int nbn,
-                                              int &tm, int &tn) {
+// (gm: tile rows per rasterisation group -- GROUP_M everywhere in the product; the tools build varies it for the
+// L2-reuse measurements of profiles/r04_notes.md)
+__device__ __forceinline__ void block_to_tile_g(int bid, int nblk, int nbm, int nbn, int gm, int &tm, int &tn) {
   const int xcd = bid % NXCD;
   const int local = bid / NXCD;
   const int q = nblk / NXCD, r = nblk % NXCD;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  const int per_group = GROUP_M * nbn;
+  const int per_group = gm * nbn;
   const int group = logical / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsize = min(nbm - first_m, GROUP_M);
+  const int first_m = group * gm;
+  const int gsize = min(nbm - first_m, gm);
   const int in_group = logical - group * per_group;
   tm = first_m + in_group % gsize;
   tn = in_group / gsize;
+}
+__device__ __forceinline__ void block_to_tile(int bid, int nblk, int nbm, int nbn, int &tm, int &tn) {
+  block_to_tile_g(bid, nblk, nbm, nbn, GROUP_M, tm, tn);
 }
 
 // What a split-K finisher adds to its accumulators before it stores the tile (sgemm_mfma_splitk_kernel):

@@ -6,7 +6,15 @@
 // A column-major library computes C^T = B^T * A^T, which is row-major C = A * B (the swapped-operand trick
 // of cuda/MMult_cuBLAS_1.cpp:17-18).  Part of libmmult_hip.so (see internal.hpp).
 #include <dlfcn.h>
-#include <hipblaslt/hipblaslt.h>   // types and enumerators only: every entry point is looked up at run time
+// hipBLASLt's header supplies types and enumerators only (every entry point is looked up at run time); a ROCm install
+// without the hipBLASLt development files still builds the library -- mmh_sgemm_hipblaslt then returns
+// MMH_ERR_UNSUPPORTED, as it does when the shared object is missing at run time.
+#if defined(__has_include)
+#if __has_include(<hipblaslt/hipblaslt.h>)
+#define MMH_HAVE_HIPBLASLT_H 1
+#include <hipblaslt/hipblaslt.h>
+#endif
+#endif
 
 #include <new>
 
@@ -71,6 +79,7 @@ int rocblas_sgemm_rowmajor(void **handle, int m, int n, int k, const float *dA, 
 }
 
 // -------------------------------------------------------------- hipBLASLt --
+#ifdef MMH_HAVE_HIPBLASLT_H
 namespace {
 struct BlasLtApi {
   void *lib = nullptr;
@@ -224,6 +233,13 @@ int hipblaslt_sgemm_rowmajor(void **state, int m, int n, int k, const float *dA,
   }
   return MMH_OK;
 }
+#else   // built without <hipblaslt/hipblaslt.h>: the comparator is absent, nothing else is
+void hipblaslt_release(void *&state) { state = nullptr; }
+int hipblaslt_sgemm_rowmajor(void **, int, int, int, const float *, int, const float *, int, float *, int, void *) {
+  set_last_error("this build of libmmult_hip.so was compiled without the hipBLASLt headers: no hipBLASLt comparator");
+  return MMH_ERR_UNSUPPORTED;
+}
+#endif
 
 // ------------------------------------------------------------------- RCCL --
 RcclApi &rccl_api() {

@@ -97,12 +97,19 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_64X64_DMA 25
 #define MMH_KERNEL_MFMA_128X64_DMA 27
 #define MMH_KERNEL_MFMA_128X128_DMA 28
-/* K2W (sgemm_dma5.hpp, round 4): K2L's tiles with a FIFTH wave that does nothing but the LDS-DMA (all pieces of a
- * K-slice, two slices ahead), so that the four MFMA waves never stall on a vector-memory issue; under stream-K the
- * loader walks the parts of a range as ONE stream of slices (MMH_OPT_STREAMK_CHAIN).  Same chain, same bits. */
+/* K2W (sgemm_dma5.hpp, round 4): K2L's tiles with LOADER waves that do nothing but the LDS-DMA (the pieces of a
+ * K-slice, two slices ahead; two loaders for the 64x64 tile, one for the others), so that the four MFMA waves never
+ * stall on a vector-memory issue; under stream-K the loaders walk the parts of a range as ONE stream of slices
+ * (MMH_OPT_STREAMK_CHAIN).  Thin edge tiles skip the MFMAs of 16-row / 16-column blocks that hold no element.
+ * Same chain, same bits. */
 #define MMH_KERNEL_MFMA_64X64_DMA5 29
 #define MMH_KERNEL_MFMA_128X64_DMA5 30
 #define MMH_KERNEL_MFMA_128X128_DMA5 31
+/* ... and a whole-round tile of 32 i x 32 j (wave tiles of 48 x 48; B fragments column-blocked): 96x96 lands
+ * N = 1536 of the reference sweep (cuda/parameters.h:5-7) on exactly 256 tiles.  One workgroup per tile only (no
+ * stream-K form).  (160x96 and 160x160 were built and measured too -- N = 1920, 2560 -- and lose to the chained
+ * stream-K launch of the 128-wide tiles; they live in the tools build, profiles/r04_notes.md.) */
+#define MMH_KERNEL_MFMA_96X96_DMA5 7
 /* K2M (sgemm_dma32.hpp, round 4): the same LDS-DMA ring feeding v_mfma_f32_32x32x2_f32 -- 64-cycle matrix
  * instructions, one conflict-free ds_read_b128 + two v_permlane32_swap per eight k's of A -- and, under stream-K,
  * CHAINED segments (a segment's tail fetches the next segment's first slices).  Same chain, same bits. */
@@ -252,6 +259,12 @@ int mmh_kernel_id(const char *short_name);
  * range as ONE stream of K-slices -- a part's last slices fetch the next part's first ones -- instead of starting every
  * part with an empty pipeline.  Same bits; 0 = the unchained form (the A/B baseline). */
 #define MMH_OPT_STREAMK_CHAIN 12
+/* MMH_OPT_PERSIST (default 0): 1 = tile counts that ARE whole rounds of the persistent grid (>= 2 tiles per
+ * workgroup) also run as the persistent launch: every workgroup walks its tiles in the phase tables' level order,
+ * so the co-resident workgroups of an XCD start together and stay in K lock-step (what a fresh workgroup per tile
+ * loses to dispatch stagger), and the K2W loaders fetch the next tile's first slices under the current tile's
+ * store.  No partial tiles are handed over in such a launch. */
+#define MMH_OPT_PERSIST 13
 int mmh_set_option(mmh_handle_t handle, int option, int value);
 /* The two tables of a phase-ordered stream-K launch (MMH_OPT_STREAMK_ORDER) for `tiles` tile slots of `nk`
  * K-slices on `grid` persistent workgroups, computed on the host (no device needed): order[grid] = the range

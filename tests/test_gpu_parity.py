@@ -23,7 +23,7 @@ KERNELS = ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "auto
            "valu_128x128", "valu_64x64", "naive", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma",
            "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma",
     "mfma32b_128x64_dma", "mfma32b_64x128_dma", "mfma32b_128x128_dma",
-    "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5"]
+    "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5"]
 
 
 def tol(k):
@@ -108,7 +108,7 @@ def test_seeded_inputs_vs_oracle(mm, oracle, shape, kernel):
 @pytest.mark.parametrize("kernel", ["mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma",
                                     "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma",
     "mfma32b_128x64_dma", "mfma32b_64x128_dma", "mfma32b_128x128_dma",
-    "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5"])
+    "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5"])
 def test_lds_dma_small_tile_kernel_is_the_same_chain(mm, oracle, kernel):
     """K2L (sgemm_dma.hpp): both operands by LDS-DMA into a ring of K-slice buffers, A as a ROW-major
     image read with ds_read2st64_b32.  Same MFMA, same k order -> the oracle's bits, for one slice, for
@@ -539,7 +539,7 @@ def test_unaligned_pointers_take_the_guarded_path(mm, oracle):
                                     "mfma_128x64_dma", "mfma_128x128_dma", "auto",
                                     "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma",
     "mfma32b_128x64_dma", "mfma32b_64x128_dma", "mfma32b_128x128_dma",
-    "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5"])
+    "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5"])
 def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
     """Every operand only 4-byte aligned, odd lda/ldb/ldc, ragged m/n/k, with
     poison around the matrices: the descriptor-bounded path must neither read
@@ -573,7 +573,7 @@ def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
 @pytest.mark.parametrize("kernel", ["mfma", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma", "auto",
                                     "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma",
     "mfma32b_128x64_dma", "mfma32b_64x128_dma", "mfma32b_128x128_dma",
-    "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5"])
+    "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5"])
 def test_nonfinite_padding_does_not_leak_through_the_k_tail(mm, oracle, kernel):
     """k not a multiple of the K-slice: the loads run into the next row / the
     padding, which here holds inf/nan (A's padding, B's padding and the rows of the buffer below B);

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 STEPS=${STEPS:-"k32tests sweep"}
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 if has k32tests; then   # the parity tests of the 32x32x2 LDS-DMA tiles only
-  ( time timeout 900 python -m pytest tests -m gpu -x -q -k "${K32_FILTER:-mfma32 or dma5}" ) > $OUT/pytest_k32.log 2>&1
+  ( time timeout 600 python -m pytest tests -m gpu -x -q -k "${K32_FILTER:-mfma32 or dma5}" ) > $OUT/pytest_k32.log 2>&1
   tail -5 $OUT/pytest_k32.log
 fi
 if has tests; then
@@ -39,5 +39,58 @@ for p, c in d.get("pmc_mean_per_dispatch", {}).items():
 PY
   done
   find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
+fi
+if has exp1; then       # round-4 batch 1: K2W loader count / ring depth / look-ahead, whole-round tiles, thin edge tiles, persistent launches
+  V64="mfma_64x64_dma,mfma_64x64_dma5,exp5_64x64_b3l1d2,exp5_64x64_b3l2d3,exp5_64x64_b4l2d2,exp5_64x64_b5l2d3,exp5_64x64_b5l2d6,exp5_64x64_b5l1d2"
+  V12864="mfma_128x64_dma,mfma_128x64_dma5,exp5_128x64_b3l1d3,exp5_128x64_b3l2d2,exp5_128x64_b4l1d6"
+  V128="mfma_128x128_dma,mfma_128x128_dma5,exp5_128x128_b3l1d3,exp5_128x128_b3l2d2,exp5_128x128_b4l2d6"
+  VNEW="mfma_96x96_dma5,exp5_96x96_b3l1d3,exp5_96x96_b4l1d2,mfma_160x96_dma5,mfma_160x160_dma5,exp5_160x160_b3l1d3"
+  timeout 300 python tools/tile_sweep.py --ab --check --sizes 1024:1536:128 --variants "auto,$V64,$V12864,mfma_96x96_dma5,exp5_96x96_b3l1d3,exp5_96x96_b4l1d2,rocblas,hipblaslt" \
+    --out $OUT/exp1_small > $OUT/exp1_small.log 2>&1; tail -6 $OUT/exp1_small.log | cut -c1-900
+  timeout 300 python tools/tile_sweep.py --ab --check --shapes "1664,1664,1664;1792,1792,1792;1920,1920,1920;2048,2048,2048;2176,2176,2176;2304,2304,2304;2432,2432,2432;2560,2560,2560;2688,2688,2688" \
+    --variants "auto,mfma_64x64_dma,mfma_64x64_dma5,$V12864,$V128,$VNEW,rocblas,hipblaslt" --out $OUT/exp1_mid > $OUT/exp1_mid.log 2>&1; tail -10 $OUT/exp1_mid.log | cut -c1-900
+  timeout 300 python tools/tile_sweep.py --ab --check --shapes "3072,3072,3072;4096,4096,4096;6144,6144,6144" \
+    --variants "auto,mfma_128x64_dma,mfma_128x64_dma/p1,mfma_128x64_dma5,mfma_128x64_dma5/p1,exp5_128x64_b3l1d3,mfma_64x64_dma,mfma_64x64_dma/p1,mfma_64x64_dma5,mfma_64x64_dma5/p1,mfma_96x96_dma5,mfma_160x160_dma5,mfma_256x256,rocblas,hipblaslt" \
+    --out $OUT/exp1_big > $OUT/exp1_big.log 2>&1; tail -4 $OUT/exp1_big.log | cut -c1-900
+  timeout 300 python tools/tile_sweep.py --ab --check --shapes "1025,1025,1025;1040,1040,1040;1281,1281,1281;1409,1409,1409;2049,2049,2049;1023,1023,1023;1100,1100,1100;1537,1537,1537;2561,2561,2561" \
+    --variants "auto,mfma_64x64_dma,mfma_64x64_dma5,mfma_128x64_dma,mfma_128x64_dma5,mfma_128x128_dma5,mfma_96x96_dma5,mfma_160x160_dma5,rocblas,hipblaslt" --out $OUT/exp1_edge > $OUT/exp1_edge.log 2>&1; tail -10 $OUT/exp1_edge.log | cut -c1-700
+  for grp in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+    d=$OUT/exp1_pmc_$(echo $grp | cut -d' ' -f1)
+    ( cd /tmp && timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OLDPWD/$d -o pmc -- python $OLDPWD/tools/pmc_launch.py --ab --n 4096 \
+        --variants "mfma_128x64_dma,mfma_128x64_dma/p1,mfma_128x64_dma5,mfma_128x64_dma5/p1,mfma_64x64_dma,mfma_64x64_dma5/p1,mfma_256x256" ) > $d.log 2>&1
+  done
+  python tools/pmc_by_kernel.py $OUT/exp1_pmc_FETCH_SIZE $OUT/exp1_pmc_WRITE_SIZE > $OUT/exp1_pmc.json 2>> $OUT/exp1_pmc.err; cat $OUT/exp1_pmc.json | head -120
+  find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
+fi
+if has exp2; then       # round-4 batch 2: four loaders, thin tiles last, raster group height / padded rows (fabric traffic), create time
+  V64="mfma_64x64_dma,mfma_64x64_dma5,exp5_64x64_l1d2,exp5_64x64_l4d2,exp5_64x64_l2d3,exp5_64x64_l4d3"
+  V12864="mfma_128x64_dma,mfma_128x64_dma5,exp5_128x64_l1d2,exp5_128x64_l4d2,exp5_128x64_l2d3,exp5_128x64_l4d3"
+  V128="mfma_128x128_dma,mfma_128x128_dma5,exp5_128x128_l1d2,exp5_128x128_l4d2,exp5_128x128_l2d3,exp5_128x128_l4d3"
+  V96="mfma_96x96_dma5,exp5_96x96_l2d2,exp5_96x96_l4d2,exp5_96x96_l2d3"
+  timeout 300 python tools/tile_sweep.py --ab --check --sizes 1024:1536:128 --variants "auto,$V64,$V12864,$V96,rocblas,hipblaslt" \
+    --out $OUT/exp2_small > $OUT/exp2_small.log 2>&1; tail -6 $OUT/exp2_small.log | cut -c1-900
+  timeout 300 python tools/tile_sweep.py --ab --check --shapes "1664,1664,1664;1792,1792,1792;1920,1920,1920;2048,2048,2048;2176,2176,2176;2304,2304,2304;2432,2432,2432;2560,2560,2560;2688,2688,2688;3200,3200,3200;3584,3584,3584;4096,4096,4096" \
+    --variants "auto,mfma_64x64_dma,mfma_64x64_dma5,$V12864,$V128,rocblas,hipblaslt" --out $OUT/exp2_mid > $OUT/exp2_mid.log 2>&1; tail -13 $OUT/exp2_mid.log | cut -c1-900
+  timeout 300 python tools/tile_sweep.py --ab --check --shapes "1025,1025,1025;1040,1040,1040;1032,1032,1032;1281,1281,1281;1409,1409,1409;1537,1537,1537;2049,2049,2049;2561,2561,2561;4097,4097,4097;1023,1023,1023" \
+    --variants "auto,mfma_64x64_dma,mfma_64x64_dma/sk0,mfma_64x64_dma5,mfma_64x64_dma5/sk0,mfma_128x64_dma5,mfma_128x64_dma5/sk0,mfma_128x128_dma5,mfma_96x96_dma5,rocblas,hipblaslt" --out $OUT/exp2_edge > $OUT/exp2_edge.log 2>&1; tail -11 $OUT/exp2_edge.log | cut -c1-700
+  for grp in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+    d=$OUT/exp2_pmc_$(echo $grp | cut -d' ' -f1)
+    ( cd /tmp && timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OLDPWD/$d -o pmc -- python $OLDPWD/tools/pmc_launch.py --ab --n 4096 --warm 30 --reps 6 \
+        --variants "mfma_128x64_dma5,mfma_128x64_dma5/g1,mfma_128x64_dma5/g2,mfma_128x64_dma5/g4,mfma_128x64_dma5/g16,mfma_128x64_dma5/g32" ) > $d.log 2>&1
+    d=$OUT/exp2_pmcpad_$(echo $grp | cut -d' ' -f1)
+    ( cd /tmp && timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OLDPWD/$d -o pmc -- python $OLDPWD/tools/pmc_launch.py --ab --n 4096 --pad 32 --warm 30 --reps 6 \
+        --variants "mfma_128x64_dma5,mfma_128x64_dma5/g4,mfma_128x64_dma5/g16" ) > $d.log 2>&1
+  done
+  python tools/pmc_by_kernel.py $OUT/exp2_pmc_FETCH_SIZE $OUT/exp2_pmc_WRITE_SIZE --group 36 > $OUT/exp2_pmc.json 2>> $OUT/exp2_pmc.err
+  python tools/pmc_by_kernel.py $OUT/exp2_pmcpad_FETCH_SIZE $OUT/exp2_pmcpad_WRITE_SIZE --group 36 > $OUT/exp2_pmcpad.json 2>> $OUT/exp2_pmc.err
+  python - $OUT/exp2_pmc.json $OUT/exp2_pmcpad.json <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    for k, v in json.load(open(f)).items():
+        if v.get("_n_FETCH_SIZE", 0) >= 3:
+            print(f.split("/")[-1], k[-60:], "us", v.get("_us_FETCH_SIZE"), "fetch MB", round(v.get("fetch_bytes", 0) / 1e6, 1), "l2hit", v.get("l2_hit"))
+PY
+  find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
+  timeout 200 python tools/create_time.py --runs 2 > $OUT/create_time.json 2>&1; cat $OUT/create_time.json | tr -d '\n' | cut -c1-600; echo
 fi
 du -sh $OUT

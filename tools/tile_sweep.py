@@ -7,7 +7,7 @@ rules are read off (round 4; the reference's `NEW := MMult_xxx` switch, cuda/mak
 
 A variant is a kernel's short name (mmh_kernel_id) optionally followed by /sk0 (MMH_OPT_STREAMK = 0: one
 workgroup per tile), /sk1 (the library's own policy, the default) or /sk2 (stream-K whenever the tile count is
-ragged), and /nc (MMH_OPT_STREAMK_CHAIN = 0: the K2M tiles' stream-K parts unchained); `rocblas` / `hipblaslt` are the vendor comparators.  Protocol as tools/offgrid_sweep.py: every burst
+ragged), /p1 (MMH_OPT_PERSIST = 1: whole rounds of the persistent grid run persistent too), and /nc (MMH_OPT_STREAMK_CHAIN = 0: the K2M tiles' stream-K parts unchained); `rocblas` / `hipblaslt` are the vendor comparators.  Protocol as tools/offgrid_sweep.py: every burst
 through the C ABI after ~--warm-ms of untimed launches of its own variant, --rounds interleaved rounds, medians.
 --check compares every variant's C with the first variant's, bit for bit.  Needs a GPU."""
 from __future__ import annotations
@@ -44,9 +44,12 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--warm-ms", type=float, default=20.0)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--ab", action="store_true", help="load libmmult_hip_ab.so (the exp5_* / ablation ids)")
     args = ap.parse_args()
     import torch
     import how_to_optimize_gemm_amd as H
+    if args.ab:
+        H.use_ab_library()
     mm = H.MMult(0, "auto")
     stream = torch.cuda.current_stream().cuda_stream
     variants = args.variants.split(",")
@@ -59,6 +62,7 @@ def main():
         sk = [x for x in parts[1:] if x.startswith("sk")]
         mm.set_streamk(int(sk[0][2:]) if sk else 1)
         mm.set_option(H.OPT_STREAMK_CHAIN, 0 if "nc" in parts[1:] else 1)
+        mm.set_option(H.OPT_PERSIST, 1 if "p1" in parts[1:] else 0)
 
     for (m, n, k) in parse_shapes(args):
         need = m * k + k * n + m * n
@@ -108,6 +112,7 @@ def main():
         rows.append(row)
         print(json.dumps({kk: vv for kk, vv in row.items() if kk != "launched"}), flush=True)
     mm.set_streamk(1)
+    mm.set_option(H.OPT_PERSIST, 0)
     mm.close()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(rows, open(args.out + ".json", "w"), indent=1)
