@@ -80,6 +80,10 @@ def parse_args():
                     help="run the multi-GPU code path (process group, broadcast, all_reduce) even with one rank")
     ap.add_argument("--ramp-csv", default="", help="write the per-launch clock-ramp trace to this CSV")
     ap.add_argument("--ramp", type=int, default=RAMP, help="per-launch traced launches that open the run (0: none)")
+    ap.add_argument("--b-chunks", type=int, default=8,
+                    help="N > 1: K-chunks the streamed broadcast of B travels in (gemm_with_streamed_b)")
+    ap.add_argument("--no-single-gpu-reference", action="store_true",
+                    help="N > 1: skip rank 0's run of the WHOLE problem on one GPU (the denominator of scaling_efficiency)")
     ap.add_argument("--sweep", action="store_true",
                     help="also run the reference's square sweep under this run's sharding (extras.sweep_gflops_sharded)")
     return ap.parse_args()
@@ -313,7 +317,7 @@ def main():
 
     overlap_ms = None
     if sharded:
-        # broadcast hidden behind the GEMM: B in 8 K-chunks, consumed with accumulate (same bits)
+        # broadcast hidden behind the GEMM: B in --b-chunks K-chunks, consumed with accumulate (same bits)
         def gemm_acc(x, y, out, accumulate):
             mm.sgemm(x.shape[0], n, x.shape[1], x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0),
                      out.data_ptr(), out.stride(0), accumulate, stream)
@@ -324,7 +328,7 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                sh.gemm_with_streamed_b(gemm_acc, a, b, c_stream, src=0, chunks=8, always=True)
+                sh.gemm_with_streamed_b(gemm_acc, a, b, c_stream, src=0, chunks=args.b_chunks, always=True)
                 torch.cuda.synchronize()
                 dist.barrier()
                 dt = (time.perf_counter() - t0) * 1e3
@@ -365,6 +369,26 @@ def main():
     kern_ms = mm.time_sgemm(rows, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n,
                             warmup=1, reps=args.steps, stream=stream) if rows else 0.0
     launched = H.last_launch()
+
+    # N > 1: every rank's own kernel time, and -- in the SAME process group, right behind the timed region -- the whole
+    # problem on rank 0's GPU alone: the denominator of scaling_efficiency = value(N) / (N * value(1)).
+    per_rank_ms, single_ms = None, None
+    if sharded:
+        t = torch.tensor([kern_ms], device=dev, dtype=torch.float64)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        per_rank_ms = [round(float(x.item()), 4) for x in parts]
+        if not args.no_single_gpu_reference:
+            if rank == 0:
+                try:
+                    a1 = torch.rand((m, n), device=dev) * 2 - 1
+                    c1 = torch.empty((m, n), device=dev)
+                    single_ms = mm.time_sgemm(m, n, n, a1.data_ptr(), n, b.data_ptr(), n, c1.data_ptr(), n, warmup=1,
+                                              reps=max(2, min(args.steps, 5)), stream=stream)
+                    del a1, c1
+                except Exception:      # (out of memory beside the panel buffers: report none rather than fail the run)
+                    single_ms = None
+            dist.barrier()
 
     # --sweep: the reference's square sweep under this run's sharding (row panels over the ranks, B replicated
     # before the timed launches -- data placement, as above).  Every rank times its own panel with a hipEvent pair
@@ -463,6 +487,25 @@ def main():
             out["backend"] = str(dist.get_backend())
             out["bcast_ms"] = round(bcast_ms, 3)
             out["bcast_gbps"] = round(4.0 * n * n / (bcast_ms * 1e-3) / 1e9, 1) if bcast_ms else None
+            out["gemm_ms_per_rank"] = per_rank_ms               # each rank's own hipEvent time per launch of its panel
+            out["gemm_ms"] = max(per_rank_ms) if per_rank_ms else None
+            if single_ms:
+                v1 = 2.0 * m * n * n * 1e-9 / (single_ms * 1e-3)
+                out["single_gpu_value"] = round(v1, 1)          # the whole problem on rank 0's GPU, same process group
+                out["single_gpu_ms"] = round(single_ms, 4)
+                out["scaling_efficiency"] = round(gflops / (world * v1), 4)
+            # what the committed one-GPU dry run (profiles/r03_shard_dryrun.md) predicts for this line: every rank's
+            # panel at the single-GPU rate, the broadcast at one xGMI link (153 GB/s) flat or over all links
+            # (scatter + all-gather), the streamed form hiding all but one chunk of it
+            link = 153e9
+            flat_ms = 4.0 * n * n / link * 1e3
+            out["model"] = {"what": "predictions beside the measurements: value = N x the one-GPU panel rate; broadcast of B over one "
+                                    "153 GB/s xGMI link flat, or scattered over the N-1 links and all-gathered; streamed = GEMM + one chunk",
+                            "bcast_flat_ms": round(flat_ms, 3) if world > 1 else 0.0,
+                            "bcast_scatter_allgather_ms": round(2.0 * flat_ms / max(world - 1, 1) * (world - 1) / world, 3) if world > 1 else 0.0,
+                            "b_chunks": args.b_chunks,
+                            "streamed_ms": round(ms_per_step + (flat_ms / max(args.b_chunks, 1) if world > 1 else 0.0), 3),
+                            "value_at_linear_scaling": round(world * out["single_gpu_value"], 1) if single_ms else None}
             out["value_incl_bcast"] = round(2.0 * m * n * n * 1e-9 / ((ms_per_step + bcast_ms) * 1e-3), 1)
             if overlap_ms is not None:
                 out["bcast_overlapped_ms"] = round(overlap_ms, 3)

@@ -38,8 +38,9 @@ KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma_64x64_dma": 25, "mfma_128x64_dma": 27, "mfma_128x128_dma": 28,
            "mfma_64x64_dma5": 29, "mfma_128x64_dma5": 30, "mfma_128x128_dma5": 31,
            "mfma_96x96_dma5": 7,
-           "mfma32_64x64_dma": 48, "mfma32_128x64_dma": 49, "mfma32_128x128_dma": 50, "mfma32_64x128_dma": 51,
-           "mfma32b_128x64_dma": 60, "mfma32b_64x128_dma": 61, "mfma32b_128x128_dma": 62}
+           }
+# (tools build only, libmmult_hip_ab.so: the 32x32x2 tiles mfma32_* / mfma32b_* (ids 48-51, 60-62), exp5_*, the rim --
+# their names resolve through the library's own table, mmh_kernel_id)
 # kernels that keep the one-chain-per-element contract (bit-identical results); the split-K ids do not
 CHAIN_KERNELS = [k for k in KERNELS if "splitk" not in k]
 
@@ -47,7 +48,7 @@ CHAIN_KERNELS = [k for k in KERNELS if "splitk" not in k]
 EXPORTS = [
     "mmh_strerror", "mmh_last_error", "mmh_last_launch", "mmh_version", "mmh_is_ab_build", "mmh_device_count",
     "mmh_device_info",
-    "mmh_create", "mmh_destroy", "mmh_warm", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name", "mmh_kernel_id",
+    "mmh_create", "mmh_destroy", "mmh_warm", "mmh_reserve_stream", "mmh_set_kernel", "mmh_get_kernel", "mmh_kernel_name", "mmh_kernel_id",
     "mmh_set_option", "mmh_get_option",
     "mmh_sgemm", "mmh_sgemm_host", "mmh_sgemm_host_timed", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
     "mmh_sgemm_rocblas", "mmh_sgemm_hipblaslt", "mmh_shard_rows",
@@ -69,15 +70,19 @@ _lib: Optional[C.CDLL] = None
 _lib_path = LIB_PATH
 
 
-def use_ab_library() -> str:
-    """tools/ only: load libmmult_hip_ab.so (the product kernels plus the scheduling A/B variants and
-    the timing-only ablation builds, whose results are WRONG) instead of the product library.  Must be
-    called before the first lib(); builds the library on demand."""
+def use_ab_library(build: bool = True) -> str:
+    """tools/ only: load libmmult_hip_ab.so (the product kernels plus the scheduling A/B variants, the families that
+    measured slower -- the 32x32x2 tiles, the rim -- and the timing-only ablation builds, whose results are WRONG)
+    instead of the product library.  Must be called before the first lib(); builds the library on demand
+    (build=False: only if it is already there -- raises otherwise)."""
     global _lib_path
     if _lib is not None and _lib_path != AB_LIB_PATH:
         raise MMultError(ERR_INVALID_ARG, "use_ab_library", "the product library is already loaded")
-    from . import build as _build
-    _build.build_ab_library()
+    if build:
+        from . import build as _build
+        _build.build_ab_library()
+    elif not os.path.exists(AB_LIB_PATH):
+        raise MMultError(ERR_UNSUPPORTED, "use_ab_library", "libmmult_hip_ab.so has not been built")
     _lib_path = AB_LIB_PATH
     return AB_LIB_PATH
 
@@ -159,6 +164,7 @@ def lib() -> C.CDLL:
     L.mmh_create.argtypes = [C.POINTER(vp), C.c_int]
     L.mmh_destroy.argtypes = [vp]
     L.mmh_warm.argtypes = [vp]
+    L.mmh_reserve_stream.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     L.mmh_kernel_id.argtypes = [C.c_char_p]
     L.mmh_set_kernel.argtypes = [vp, C.c_int]
     L.mmh_get_kernel.argtypes = [vp, ip]
@@ -295,6 +301,11 @@ class MMult:
         k = C.c_int(0)
         _check(lib().mmh_get_kernel(self._h, C.byref(k)), "mmh_get_kernel")
         return k.value
+
+    def reserve_stream(self, stream: int, m: int, n: int, k: int) -> None:
+        """Give `stream` (a raw hipStream_t) a stream-K workspace set of its own, large enough for any launch of an
+        m x n x k problem: what a launch that is to be CAPTURED on that stream needs (include/mmult_hip.h, hipGraphs)."""
+        _check(lib().mmh_reserve_stream(self._h, stream, m, n, k), "mmh_reserve_stream")
 
     def set_streamk(self, on) -> None:
         """False / 0 never, True / 1 when a round would be > 7 % empty (default), 2 whenever ragged."""

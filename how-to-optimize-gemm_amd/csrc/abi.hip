@@ -92,9 +92,9 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       workspaces_suspect(h);   // a launch that timed out may have left hand-off counters behind
       return MMH_OK;
     case MMH_OPT_IGEMM_MODE:
-      if ((value >= 0 && value <= 8)
+      if ((value >= 0 && value <= 8 && value != 7)
 #ifdef MMH_AB_BUILD
-          || (value >= 10 && value <= 13)
+          || value == 7 || (value >= 10 && value <= 13)
 #endif
       ) {
         h->igemm_mode = value;
@@ -133,8 +133,12 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       h->dma_edge = value ? 1 : 0;     //    for rows that are 16-byte aligned; 2 (default): for any 4-byte aligned rows
       h->dma_dword_rows = value >= 2 ? 1 : 0;
       return MMH_OK;
-    case MMH_OPT_RIM:
+    case MMH_OPT_RIM:   // the rim lives in the tools build (measured: it does not pay); the product accepts "off" only
+#ifdef MMH_AB_BUILD
       if (value < 0 || value > 16) return MMH_ERR_INVALID_ARG;
+#else
+      if (value != 0) return MMH_ERR_INVALID_ARG;
+#endif
       h->rim = value;
       return MMH_OK;
     case MMH_OPT_STREAMK_CHAIN:
@@ -224,6 +228,9 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_128X64_DMA5: return "MMult_hip_mfma_128x64_dma5";
     case MMH_KERNEL_MFMA_128X128_DMA5: return "MMult_hip_mfma_128x128_dma5";
     case MMH_KERNEL_MFMA_96X96_DMA5: return "MMult_hip_mfma_96x96_dma5";
+    case MMH_KERNEL_MFMA_SPLITK: return "MMult_hip_mfma_splitk";
+    case MMH_KERNEL_MFMA_SPLITK_128X64: return "MMult_hip_mfma_splitk_128x64";
+#ifdef MMH_AB_BUILD
     case MMH_KERNEL_MFMA32_64X64_DMA: return "MMult_hip_mfma32_64x64_dma";
     case MMH_KERNEL_MFMA32_128X64_DMA: return "MMult_hip_mfma32_128x64_dma";
     case MMH_KERNEL_MFMA32_64X128_DMA: return "MMult_hip_mfma32_64x128_dma";
@@ -231,9 +238,6 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA32B_128X64_DMA: return "MMult_hip_mfma32b_128x64_dma";
     case MMH_KERNEL_MFMA32B_64X128_DMA: return "MMult_hip_mfma32b_64x128_dma";
     case MMH_KERNEL_MFMA32B_128X128_DMA: return "MMult_hip_mfma32b_128x128_dma";
-    case MMH_KERNEL_MFMA_SPLITK: return "MMult_hip_mfma_splitk";
-    case MMH_KERNEL_MFMA_SPLITK_128X64: return "MMult_hip_mfma_splitk_128x64";
-#ifdef MMH_AB_BUILD
     case 19: return "exp_dma_b";
     case 16: return "cadence_3";
     case 17: return "cadence_4";
@@ -267,20 +271,8 @@ const char *mmh_kernel_name(int kernel) {
     case 58: return "abl32_64x64_no_a_reads";
     case 59: return "abl32_64x64_mfma_only";
     case 64: return "exp5_64x64_l1d2";
-    case 65: return "exp5_64x64_l4d2";
-    case 66: return "exp5_64x64_l2d3";
-    case 67: return "exp5_64x64_l4d3";
     case 68: return "exp5_128x64_l1d2";
-    case 69: return "exp5_128x64_l4d2";
-    case 70: return "exp5_128x64_l2d3";
-    case 71: return "exp5_128x64_l4d3";
     case 72: return "exp5_128x128_l1d2";
-    case 73: return "exp5_128x128_l4d2";
-    case 74: return "exp5_128x128_l2d3";
-    case 75: return "exp5_128x128_l4d3";
-    case 76: return "exp5_96x96_l2d2";
-    case 77: return "exp5_96x96_l4d2";
-    case 78: return "exp5_96x96_l2d3";
     case 79: return "exp5_160x96_l1d2";
     case 80: return "exp5_160x160_l1d2";
 #endif
@@ -297,6 +289,12 @@ int mmh_kernel_id(const char *name) {
     if (s && (want == s || strcmp(name, s) == 0)) return id;   // (the A/B ids of the tools build carry bare names)
   }
   return -1;
+}
+
+int mmh_reserve_stream(mmh_handle_t h, void *stream, int m, int n, int k) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return reserve_stream(h, static_cast<hipStream_t>(stream), m, n, k);
 }
 
 int mmh_warm(mmh_handle_t h) {

@@ -32,8 +32,11 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
   const int cus_ = h->cu_count > 0 ? h->cu_count : 256;
   if (igemm_s8_inplace_ok(dA, lda, dB, ldb, k) &&
       (h->igemm_mode == 7 || h->igemm_mode == 8 || (h->igemm_mode == 0 && igemm_s8_big_tile(m, n, cus_)))) {
+#ifdef MMH_AB_BUILD   // (the 16-MFMA-per-phase form: tools build only)
     if (h->igemm_mode == 7) HIP_TRY(launch_igemm_s8_pp<4>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
-    else HIP_TRY(launch_igemm_s8_pp<2>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
+    else
+#endif
+    HIP_TRY(launch_igemm_s8_pp<2>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
     return MMH_OK;
   }
   // Default mode: operands the in-place kernel cannot take as they are (an odd leading dimension, a

@@ -31,6 +31,18 @@
 
 #include "../../include/mmult_hip.h"
 
+// Kernel ids of the tools build (libmmult_hip_ab.so) that name whole tile families; the product library neither
+// defines nor accepts them.  K2M (sgemm_dma32.hpp, round 4): the LDS-DMA ring feeding v_mfma_f32_32x32x2_f32 -- 64-cycle
+// matrix instructions, one conflict-free ds_read_b128 + two v_permlane32_swap per eight k's of A -- and the two-block
+// form v_mfma_f32_32x32x1_2b_f32; measured slower than the 16x16x4 tiles (profiles/r04_notes.md).
+#define MMH_KERNEL_MFMA32_64X64_DMA 48
+#define MMH_KERNEL_MFMA32_128X64_DMA 49
+#define MMH_KERNEL_MFMA32_128X128_DMA 50
+#define MMH_KERNEL_MFMA32_64X128_DMA 51
+#define MMH_KERNEL_MFMA32B_128X64_DMA 60
+#define MMH_KERNEL_MFMA32B_64X128_DMA 61
+#define MMH_KERNEL_MFMA32B_128X128_DMA 62
+
 namespace mmh {
 
 // ---- error text (thread-local, state.hip) ----
@@ -79,6 +91,9 @@ struct GemmArgs {
   // "rim" launches (sgemm_dma.hpp): m x n above is the TRIMMED problem the tiles cover, rim_m x rim_n the whole
   // one -- the strips in between run on the vector ALU in extra workgroups of the same launch.  0: no rim.
   int rim_m = 0, rim_n = 0;
+  // launch form: 0 = the launcher's own rule (a kernel the caller forced), 1 = one workgroup per tile, 2 = the
+  // persistent stream-K launch -- what MMH_KERNEL_AUTO's cost table decided (policy.hip)
+  int form = 0;
 };
 
 }  // namespace mmh
@@ -159,7 +174,7 @@ int check_sticky(mmh_context *h);
   HIP_TRY(guard_.enter((h)->device));                  \
   if (int st_ = ::mmh::check_sticky(h); st_ != MMH_OK) return st_
 
-int create_context(mmh_context **out, int device);
+int create_context(mmh_context **out, int device, bool warm = true);   // warm: unless the environment says MMH_LAZY=1
 void destroy_context(mmh_context *h);
 int warm_context(mmh_context *h);
 
@@ -187,6 +202,7 @@ bool known_kernel(int kernel);
 // ---- stream-K workspaces (state.hip) ----
 // the stream's own hand-off words (>= tiles of them, all zero) and partial-tile slots (>= parts_bytes)
 int workspace_for(mmh_context *ctx, hipStream_t s, long tiles, size_t parts_bytes, int **flags, float **parts);
+int reserve_stream(mmh_context *ctx, hipStream_t s, int m, int n, int k);   // mmh_reserve_stream
 void workspaces_suspect(mmh_context *ctx);   // a launch may have died half-way: every set is memset before its next use
 bool build_sk_tables(long tiles, int nk, int grid, int *order, int *place);
 int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place);

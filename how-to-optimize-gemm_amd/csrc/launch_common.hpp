@@ -81,11 +81,19 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB,
     if (ok != MMH_OK) return ok;
   }
   const int per_cu = resident_per_cu(ctx, occ_kern, threads, lds);
-  // (decide_tiles: the count the plain-or-persistent decision looks at, when it is not the launch's own -- thin edge
-  // tiles of the K2W kernels; a persistent launch then still covers all `tiles`)
-  if (decide_tiles > 0 && streamk_wanted(ctx, decide_tiles, BM, BN, per_cu) == 0) return 1;
-  const int grid = streamk_wanted(ctx, tiles, BM, BN, per_cu);
-  if (grid == 0) return 1;
+  // g.form (MMH_KERNEL_AUTO's cost table has decided): 1 = plain, 2 = persistent whenever the count is ragged; 0 = a
+  // kernel the caller forced: the rule of streamk_wanted.  (decide_tiles: the count that rule looks at, when it is
+  // not the launch's own -- thin edge tiles of the K2W kernels; a persistent launch then still covers all `tiles`.)
+  if (g.form == 1) return 1;
+  int grid = 0;
+  if (g.form == 2) {
+    grid = streamk_grid(tiles, cus, per_cu);
+    if (grid == 0 || tiles % grid == 0 || tiles > (1L << 24)) return 1;
+  } else {
+    if (decide_tiles > 0 && streamk_wanted(ctx, decide_tiles, BM, BN, per_cu) == 0) return 1;
+    grid = streamk_wanted(ctx, tiles, BM, BN, per_cu);
+    if (grid == 0) return 1;
+  }
   int *flags = nullptr;
   float *parts = nullptr;   // one partial-tile slot per range
   int rc = workspace_for(ctx, g.s, tiles, (size_t)grid * BM * BN * sizeof(float), &flags, &parts);

@@ -26,6 +26,9 @@ int launch_dma_tile(mmh_context *ctx, const GemmArgs &g) {
   if (form < 0) return 1;
   const bool edge = form == 1;
   char what[224];
+#ifndef MMH_AB_BUILD
+  if (g.rim_m) return 1;   // (the rim is part of the tools build)
+#else
   constexpr bool RIM_TILE = BN == 64 && ((BM == 64 && WTM == 2) || (BM == 128 && WTM == 4)) && WTN == 2;
   if (g.rim_m && !RIM_TILE) return 1;
   if constexpr (RIM_TILE) if (g.rim_m) {
@@ -60,6 +63,7 @@ int launch_dma_tile(mmh_context *ctx, const GemmArgs &g) {
     set_last_launch(what);
     return MMH_OK;
   }
+#endif
   if (ctx && ctx->streamk) {
     auto kern = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false>;
     auto kern_edge = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true>;
@@ -96,6 +100,7 @@ int warm_dma_tile(mmh_context *ctx, float *scratch, hipStream_t s) {
   };
   if ((rc = plain(sgemm_mfma_dma_kernel<BM, BN, KB, WTM, WTN, NBUF, false>)) != MMH_OK) return rc;
   if ((rc = plain(sgemm_mfma_dma_kernel<BM, BN, KB, WTM, WTN, NBUF, true>)) != MMH_OK) return rc;
+#ifdef MMH_AB_BUILD
   if constexpr (BN == 64) {   // the rim forms (AUTO only trims onto the 64-wide tiles)
     auto rim = [&](auto kern) {
       const int ok = allow_big_lds(kern, T::LDS_BYTES);
@@ -108,6 +113,7 @@ int warm_dma_tile(mmh_context *ctx, float *scratch, hipStream_t s) {
     if ((rc = rim(sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, false>)) != MMH_OK) return rc;
     if ((rc = rim(sgemm_mfma_dma_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, true>)) != MMH_OK) return rc;
   }
+#endif
   auto sk = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false>;
   auto ske = sgemm_dma_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true>;
   (void)resident_per_cu(ctx, ske, T::THREADS, T::LDS_BYTES);

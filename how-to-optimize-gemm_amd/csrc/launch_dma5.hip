@@ -111,32 +111,24 @@ bool dma5_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g) {
 
 int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
   switch (kernel) {
-    //                      BM   BN  WTM WTN NBUF NL D      (NL = 2: measured best for every tile, profiles/r04_notes.md)
+    //                      BM   BN  WTM WTN NBUF NL D
+    // (loader counts as measured, profiles/r04_notes.md: one loader wave on a consumer's SIMD holds that consumer back
+    // -- and the workgroup, at every barrier; two or four spread the pieces -- 128x128 under chained stream-K at N = 2560:
+    // 127.9 / 144.4 / 145.2 TFLOP/s with 1 / 2 / 4 loaders, 128x64 at N = 2432: 139.5 / 139.7 / 143.5)
     case MMH_KERNEL_MFMA_64X64_DMA5:    // 64x64 tile, 4 consumer waves of 32x32 + two loaders, 48 KiB ring: 3 workgroups per CU
       return launch_dma5_tile<64, 64, 2, 2, 3, 2, 2>(ctx, g);
-    case MMH_KERNEL_MFMA_128X64_DMA5:   // 128x64 tile, consumers of 64x32, 72 KiB ring: 2 per CU
-      return launch_dma5_tile<128, 64, 4, 2, 3, 2, 2>(ctx, g);
-    case MMH_KERNEL_MFMA_128X128_DMA5:  // 128x128 tile, consumers of 64x64, 96 KiB ring
-      return launch_dma5_tile<128, 128, 4, 4, 3, 2, 2>(ctx, g);
-    case MMH_KERNEL_MFMA_96X96_DMA5:    // 96x96 tile, consumers of 48x48 (column-blocked B), 72 KiB ring: 2 per CU
+    case MMH_KERNEL_MFMA_128X64_DMA5:   // 128x64 tile, consumers of 64x32 + four loaders, 72 KiB ring: 2 per CU
+      return launch_dma5_tile<128, 64, 4, 2, 3, 4, 2>(ctx, g);
+    case MMH_KERNEL_MFMA_128X128_DMA5:  // 128x128 tile, consumers of 64x64 + four loaders, 96 KiB ring
+      return launch_dma5_tile<128, 128, 4, 4, 3, 4, 2>(ctx, g);
+    case MMH_KERNEL_MFMA_96X96_DMA5:    // 96x96 tile, consumers of 48x48 (column-blocked B) + one loader, 72 KiB ring: 2 per CU
       return launch_dma5_tile<96, 96, 3, 3, 3, 1, 2, false>(ctx, g);
 #ifdef MMH_AB_BUILD
-    // A/B (valid results): loader count and fragment look-ahead of the tiles above; the 160-wide whole-round tiles
+    // A/B (valid results): ONE loader wave (round 4's first form), and the 160-wide whole-round tiles that lost to the
+    // chained stream-K launch of the 128-wide ones (N = 2560: 140.8 against 145.2; N = 1920 on 160x96: 130.9 against 137.5)
     case 64: return launch_dma5_tile<64, 64, 2, 2, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 65: return launch_dma5_tile<64, 64, 2, 2, 3, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 66: return launch_dma5_tile<64, 64, 2, 2, 3, 2, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 67: return launch_dma5_tile<64, 64, 2, 2, 3, 4, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 68: return launch_dma5_tile<128, 64, 4, 2, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 69: return launch_dma5_tile<128, 64, 4, 2, 3, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 70: return launch_dma5_tile<128, 64, 4, 2, 3, 2, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 71: return launch_dma5_tile<128, 64, 4, 2, 3, 4, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 72: return launch_dma5_tile<128, 128, 4, 4, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 73: return launch_dma5_tile<128, 128, 4, 4, 3, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 74: return launch_dma5_tile<128, 128, 4, 4, 3, 2, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 75: return launch_dma5_tile<128, 128, 4, 4, 3, 4, 3>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 76: return launch_dma5_tile<96, 96, 3, 3, 3, 2, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 77: return launch_dma5_tile<96, 96, 3, 3, 3, 4, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    case 78: return launch_dma5_tile<96, 96, 3, 3, 3, 2, 3, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 79: return launch_dma5_tile<160, 96, 5, 3, 3, 1, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 80: return launch_dma5_tile<160, 160, 5, 5, 3, 1, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
 #endif
@@ -149,9 +141,20 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
 int warm_dma5(mmh_context *ctx, float *scratch, hipStream_t s) {
   int rc;
   if ((rc = warm_dma5_tile<64, 64, 2, 2, 3, 2, 2>(ctx, scratch, s)) != MMH_OK) return rc;
-  if ((rc = warm_dma5_tile<128, 64, 4, 2, 3, 2, 2>(ctx, scratch, s)) != MMH_OK) return rc;
-  if ((rc = warm_dma5_tile<128, 128, 4, 4, 3, 2, 2>(ctx, scratch, s)) != MMH_OK) return rc;
+  if ((rc = warm_dma5_tile<128, 64, 4, 2, 3, 4, 2>(ctx, scratch, s)) != MMH_OK) return rc;
+  if ((rc = warm_dma5_tile<128, 128, 4, 4, 3, 4, 2>(ctx, scratch, s)) != MMH_OK) return rc;
   return warm_dma5_tile<96, 96, 3, 3, 3, 1, 2, false>(ctx, scratch, s);
 }
+
+#ifdef MMH_DMA_TIMELINE
+// timeline build only: where the plain K2W kernels write their timeline stamps (this translation unit's copy of
+// g_dma_stamps; 4 x uint64 per workgroup; NULL switches them off).  tools/dma5_timeline.py.
+extern "C" int mmh_ab_set_stamps5(mmh_handle_t h, void *stamps) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dma_stamps), &stamps, sizeof(void *)));
+  return MMH_OK;
+}
+#endif
 
 }  // namespace mmh

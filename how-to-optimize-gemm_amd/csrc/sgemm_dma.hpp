@@ -431,6 +431,7 @@ sgemm_mfma_dma_kernel(int m, int n, int k, const float *__restrict__ A, int lda,
   dma_stamp_after_stores(3);
 }
 
+#ifdef MMH_AB_BUILD   // the rim is part of the tools build only (libmmult_hip_ab.so)
 // ---- the rim (opt-in: MMH_OPT_RIM; measured, it does not pay -- profiles/r03_notes.md section 6) ---------------------
 // A shape a few elements past a tile boundary (N = 1025: `m % 64`, `n % 64` small) pays a whole extra row AND column
 // of tiles for one element each way -- 13 % more tile work at N = 1025 and, worse, a second tile on 33 of 256 CUs
@@ -605,6 +606,7 @@ sgemm_mfma_dma_rim_kernel(int m0, int n0, int k, const float *__restrict__ A, in
   DmaSegment<BM, BN, KB, WTM, WTN, NBUF, false, EDGE>::run(lds, m0, n0, k, A, lda, B, ldb, C, ldc, tm, tn, 0,
                                                            (k + KB - 1) / KB, accumulate != 0);
 }
+#endif   // MMH_AB_BUILD (the rim)
 
 // Segment policy of this tile for the chained stream-K control flow (streamk_body in sgemm_mfma.hpp,
 // K2p) -- tile counts that do not divide the chip run as one persistent workgroup per CU over ranges

@@ -281,6 +281,9 @@ struct Dma5Segment {
     constexpr bool THIN = TM1::value || TN1::value;
     constexpr int NT = TM1::value ? 1 : WTM, NU = TN1::value ? 1 : WTN;   // blocks kept
     const bool ragged_k = EDGE && ke * KB > k;
+    // a thin wave's K loop is a chain of short steps (a fragment read, one or two MFMAs): it runs at the front of its
+    // SIMD's issue order, beside the co-resident whole tile's waves whose MFMAs fill the matrix pipe either way
+    if constexpr (THIN) __builtin_amdgcn_s_setprio(3);
     const int crow = row0 + L.wm * 16 * WTM + 4 * L.kq;
     // even widths: this lane's WTN consecutive columns; column-blocked: column of block 0 (block u: + 16 u)
     const int ccol = BBLK ? col0 + L.wn * 16 * WTN + L.li : col0 + L.wn * 16 * WTN + WTN * L.li;
@@ -410,16 +413,10 @@ struct Dma5Segment {
     };
     const int ke_main = ragged_k ? ke - 1 : ke;
     int kt = kb;
-    if constexpr (THIN) {
-      // a rolled loop over run-time ring positions (an address add per fragment read, the operands masked against k
-      // in every slice -- nothing beside the MFMAs saved), the problem's last slice included
-#pragma unroll 1
-      for (; kt < ke; ++kt) {
-        const int nx1 = pos == NBUF - 1 ? 0 : pos + 1;
-        slice_at(kt, lds + pos * STAGE, lds + nx1 * STAGE, std::true_type{});
-        pos = nx1;
-      }
-    } else {
+    {
+      // (thin waves run the same unrolled ring: a rolled copy with a run-time ring position was measured first -- hipcc
+      // reuses the address registers as fragment destinations there and waits for EVERY read before the next MFMA, one
+      // LDS round trip per k-step: 1.05 us per slice, twice a whole tile's, profiles/r04_notes.md)
       // ONE exit per loop (with `break`s between the unrolled slices hipcc copies the accumulators on the hot path)
       if constexpr (CHAIN) {   // up to NBUF - 1 slices to reach ring position 0
         static_for<NBUF - 1>([&](auto p_c) {
@@ -461,6 +458,7 @@ struct Dma5Segment {
       }
     }
     dma_stamp(2);
+    if constexpr (THIN) __builtin_amdgcn_s_setprio(0);
 
     auto out_vec = [&](int t, int r) {
       bfrag_t v;

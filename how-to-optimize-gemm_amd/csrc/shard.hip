@@ -14,13 +14,14 @@ using namespace mmh;
 struct mmh_shard {
   int ngpus = 0;
   int kernel = MMH_KERNEL_AUTO;
-  int rccl_ranks = 0;                 // ranks of the communicator (0 when ngpus == 1: no RCCL)
+  int rccl_ranks = 0;                 // ranks of the communicator (0 when ngpus == 1: no RCCL -- unless MMH_SHARD_FORCE_RCCL)
   std::vector<int> devices;
   std::vector<mmh_context *> ctx;     // one product handle per device (stream-K workspaces etc.)
   std::vector<hipStream_t> streams;
   std::vector<DevBuf> a, b, c;        // per device: A panel, B, C panel
   std::vector<void *> comms;
   bool shared_device = false;         // test mode: several logical ranks on one device, B replicated by device copies
+  bool lazy = false;                  // the per-device product handles are created without the warm-up (one-shot form)
   std::vector<std::pair<void *, size_t>> pinned;   // host ranges mmh_shard_pin registered
 };
 
@@ -92,7 +93,11 @@ int mmh_shard_unpin(mmh_shard_t sh, void *host) {
   return MMH_ERR_INVALID_ARG;
 }
 
-int mmh_shard_create(mmh_shard_t *out, int ngpus, const int *devices) {
+static int shard_create(mmh_shard_t *out, int ngpus, const int *devices, bool lazy);
+
+int mmh_shard_create(mmh_shard_t *out, int ngpus, const int *devices) { return shard_create(out, ngpus, devices, false); }
+
+static int shard_create(mmh_shard_t *out, int ngpus, const int *devices, bool lazy) {
   if (!out) return MMH_ERR_INVALID_ARG;
   *out = nullptr;
   if (ngpus <= 0 || ngpus > 64) return MMH_ERR_INVALID_ARG;
@@ -112,7 +117,15 @@ int mmh_shard_create(mmh_shard_t *out, int ngpus, const int *devices) {
     set_last_error("fewer visible devices (" + std::to_string(count) + ") than ngpus (" + std::to_string(ngpus) + ")");
     return MMH_ERR_NO_DEVICE;
   }
-  if (ngpus > 1 && !shared && !rccl_api().ok) {
+  // MMH_SHARD_FORCE_RCCL=1 (an explicit test switch, like the one above): a ONE-device shard builds a one-rank
+  // communicator and mmh_shard_sgemm issues its ncclBroadcast on it, so that the loader, ncclCommInitAll, the stream
+  // wiring and the error paths of the RCCL branch run on a one-GPU box before an 8-GPU node is the first to see them.
+  bool force_rccl = false;
+  if (ngpus == 1) {
+    const char *e = std::getenv("MMH_SHARD_FORCE_RCCL");
+    force_rccl = e && *e && *e != '0';
+  }
+  if (((ngpus > 1 && !shared) || force_rccl) && !rccl_api().ok) {
     set_last_error("librccl.so could not be loaded");
     return MMH_ERR_UNSUPPORTED;
   }
@@ -140,14 +153,14 @@ int mmh_shard_create(mmh_shard_t *out, int ngpus, const int *devices) {
   sh->comms.assign(ngpus, nullptr);
   int rc = MMH_OK;
   for (int d = 0; d < ngpus && rc == MMH_OK; ++d) {
-    rc = create_context(&sh->ctx[d], sh->devices[d]);
+    rc = create_context(&sh->ctx[d], sh->devices[d], !lazy);
     if (rc != MMH_OK) break;
     if (hipSetDevice(sh->devices[d]) != hipSuccess || hipStreamCreate(&sh->streams[d]) != hipSuccess) {
       set_last_error("hipStreamCreate failed");
       rc = MMH_ERR_HIP;
     }
   }
-  if (rc == MMH_OK && ngpus > 1 && !shared) {
+  if (rc == MMH_OK && ((ngpus > 1 && !shared) || force_rccl)) {
     // ONE communicator for the life of the handle (creating it costs far more than any GEMM here)
     if (rccl_api().comm_init_all(sh->comms.data(), ngpus, sh->devices.data()) != 0) {
       set_last_error("ncclCommInitAll failed");
@@ -248,7 +261,7 @@ int mmh_shard_sgemm(mmh_shard_t sh, int m, int n, int k, const float *A, int lda
     for (int d = 1; d < G; ++d)
       HIP_TRY(hipMemcpyAsync(sh->b[d].p, sh->b[0].p, (size_t)k * n * sizeof(float), hipMemcpyDeviceToDevice, sh->streams[d]));
     for (int d = 1; d < G; ++d) HIP_TRY(hipStreamSynchronize(sh->streams[d]));
-  } else if (G > 1 && k > 0) {
+  } else if ((G > 1 || sh->rccl_ranks > 0) && k > 0) {
     RcclApi &api = rccl_api();
     bool bad = api.group_start() != 0;
     for (int d = 0; d < G && !bad; ++d) {
@@ -265,7 +278,7 @@ int mmh_shard_sgemm(mmh_shard_t sh, int m, int n, int k, const float *A, int lda
       HIP_TRY(hipStreamSynchronize(sh->streams[d]));
     }
   }
-  if (timings_ms) timings_ms[1] = (G > 1 && k > 0) ? ms_since(t) : 0.f;
+  if (timings_ms) timings_ms[1] = ((G > 1 || sh->rccl_ranks > 0) && k > 0) ? ms_since(t) : 0.f;
   // ---- independent row-panel GEMMs (gemm_reps back-to-back launches per device: phase time / reps) ----
   t = clk::now();
   for (int rep = 0; rep < gemm_reps; ++rep)
@@ -302,7 +315,9 @@ int mmh_sgemm_sharded(int ngpus, int m, int n, int k, const float *A, int lda, c
   if (rc != MMH_OK) return rc;
   if (ngpus <= 0 || !known_kernel(kernel)) return MMH_ERR_INVALID_ARG;
   mmh_shard_t sh = nullptr;
-  if ((rc = mmh_shard_create(&sh, ngpus, nullptr)) != MMH_OK) return rc;
+  // (a handle that lives for one call: the per-device product handles skip mmh_create's warm-up -- forty one-tile
+  // launches and a 64 MiB workspace per device that a single GEMM does not amortise)
+  if ((rc = shard_create(&sh, ngpus, nullptr, true)) != MMH_OK) return rc;
   rc = mmh_shard_set_kernel(sh, kernel);
   if (rc == MMH_OK) rc = mmh_shard_sgemm(sh, m, n, k, A, lda, B, ldb, C, ldc, 1, timings_ms);
   mmh_shard_destroy(sh);

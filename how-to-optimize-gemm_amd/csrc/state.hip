@@ -85,8 +85,12 @@ bool known_kernel(int kernel) { return mmh_kernel_name(kernel) != nullptr; }
 // the previous stream by handle; ROCm 7.2 crashes inside hipEventRecord / hipStreamSynchronize on a destroyed
 // stream, it does not return an error.)  Sets are created on first use and kept; beyond eight, the least
 // recently used one that no captured graph points at is released after a device-wide synchronisation (its stream
-// may be gone).  A launch that is being CAPTURED into a hipGraph uses the capture stream's set, which is then never
-// evicted and only ever retires (never frees) a buffer that has to grow.
+// may be gone).  A launch that is being CAPTURED into a hipGraph uses the capture stream's OWN set (mmh_reserve_stream,
+// or an earlier eager launch on that stream, made it), which is then never evicted and only ever retires (never
+// frees) a buffer that has to grow; a capture stream without a large-enough set is refused -- no set is ever shared
+// between streams.
+// A stream must be synchronised before it is destroyed: sets are keyed by the stream's handle value, which the runtime
+// may hand out again while the old stream's last launch is still in flight.
 // ---------------------------------------------------------------------------------------------------
 int workspace_for(mmh_context *ctx, hipStream_t s, long tiles, size_t parts_bytes, int **flags, float **parts) {
   const bool cap = capturing(s);
@@ -94,23 +98,16 @@ int workspace_for(mmh_context *ctx, hipStream_t s, long tiles, size_t parts_byte
   for (auto *e : ctx->ws)
     if (e->stream == s) w = e;
   const size_t need_flags = (size_t)tiles * sizeof(int);
-  if (cap && (!w || need_flags > w->flags.bytes || parts_bytes > w->parts.bytes)) {
-    // Nothing may be allocated while a stream is capturing.  A capture stream without a (large enough) set of its
-    // own BORROWS the most recently used set that is large enough -- normally the one the shape's eager warm-up
-    // call used -- which from now on belongs to the graph as well (see include/mmult_hip.h, hipGraphs).
-    w = nullptr;
-    for (auto *e : ctx->ws)
-      if (need_flags <= e->flags.bytes && parts_bytes <= e->parts.bytes && !e->flags_dirty && (!w || e->stamp > w->stamp)) w = e;
-    if (!w) {
-      set_last_error("a stream-K launch cannot allocate its workspaces while the stream is capturing: run the shape once "
-                     "eagerly (any stream) before capturing it");
-      return MMH_ERR_UNSUPPORTED;
-    }
-    w->captured = true;
-    w->stamp = ++ctx->ws_stamp;
-    *flags = static_cast<int *>(w->flags.p);
-    *parts = static_cast<float *>(w->parts.p);
-    return MMH_OK;
+  if (cap && (!w || need_flags > w->flags.bytes || parts_bytes > w->parts.bytes || w->flags_dirty)) {
+    // Nothing may be allocated (or cleared outside the graph) while a stream is capturing, and a graph must not share
+    // hand-off words and partial-tile slots with launches it is not ordered against: a captured stream-K launch uses
+    // the CAPTURE STREAM'S OWN set or nothing.  (Round 3 borrowed the most recently used set of any stream -- a replay
+    // beside an eager launch on that set's stream then raced on the words, and the caller could not know which stream
+    // that was.)  The stream gets a set by launching the shape eagerly once, or from mmh_reserve_stream.
+    set_last_error("a stream-K launch cannot allocate its workspaces while the stream is capturing: give the capture stream a "
+                   "set of its own first -- mmh_reserve_stream(handle, stream, m, n, k), or one eager call of the shape on "
+                   "that stream");
+    return MMH_ERR_UNSUPPORTED;
   }
   if (!w) {
     size_t evictable = 0;
@@ -158,6 +155,28 @@ int workspace_for(mmh_context *ctx, hipStream_t s, long tiles, size_t parts_byte
 
 void workspaces_suspect(mmh_context *ctx) {
   for (auto *e : ctx->ws) e->flags_dirty = true;
+}
+
+// mmh_reserve_stream: `s` gets a workspace set of its own that is large enough for any stream-K launch MMH_KERNEL_AUTO
+// (or a forced tile) can make of an m x n x k problem -- eagerly, so that launches of the shape can then be CAPTURED on
+// `s`.  Upper bounds: one hand-off word per 64x64 tile; one partial-tile slot per persistent workgroup of the tile
+// family with the largest slots x grid (256x256: one per CU; the smaller tiles: 64 KiB per CU between them).
+int reserve_stream(mmh_context *ctx, hipStream_t s, int m, int n, int k) {
+  if (m <= 0 || n <= 0 || k <= 0) return MMH_ERR_INVALID_ARG;
+  if (capturing(s)) {
+    set_last_error("mmh_reserve_stream must run before the capture begins (it allocates)");
+    return MMH_ERR_UNSUPPORTED;
+  }
+  const long cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+  const long tiles64 = (long)((m + 63) / 64) * ((n + 63) / 64);
+  const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
+  size_t parts = (size_t)cus * 3 * 64 * 64 * sizeof(float);                            // 64x64: three workgroups per CU
+  parts = std::max(parts, (size_t)cus * 2 * 128 * 64 * sizeof(float));                  // 128x64: two
+  parts = std::max(parts, (size_t)cus * 128 * 128 * sizeof(float));                     // 128x128: one
+  if (tiles256 >= cus) parts = std::max(parts, (size_t)cus * 256 * 256 * sizeof(float));   // 256x256: one
+  int *flags = nullptr;
+  float *p = nullptr;
+  return workspace_for(ctx, s, tiles64, parts, &flags, &p);
 }
 
 // The two tables of a stream-K launch (streamk_body's `order` and `place`), per shape, cached in the handle.
@@ -287,7 +306,7 @@ bool is_gfx950(int device) {
 }
 }  // namespace
 
-int create_context(mmh_context **out, int device) {
+int create_context(mmh_context **out, int device, bool warm) {
   *out = nullptr;
   int count = 0;
   mmh_device_count(&count);
@@ -331,7 +350,7 @@ int create_context(mmh_context **out, int device) {
   // handle (cuda/test_MMult.cpp:43-44), not inside the first timed MY_MMult.  MMH_LAZY=1 defers it to
   // mmh_warm / first use.
   const char *lazy = std::getenv("MMH_LAZY");
-  if (!(lazy && *lazy && *lazy != '0')) {
+  if (warm && !(lazy && *lazy && *lazy != '0')) {
     const int rc = warm_context(ctx);
     if (rc != MMH_OK) {
       destroy_context(ctx);
@@ -354,9 +373,19 @@ int warm_context(mmh_context *h) {
       (rc = warm_dma32(h, p, nullptr)) == MMH_OK && (rc = warm_dma5(h, p, nullptr)) == MMH_OK) rc = warm_valu(h, p, nullptr);
   // the hand-off workspaces at the size the largest stream-K launch of a square sweep needs
   if (rc == MMH_OK) {
+    // (not fatal: on a device that is short of memory -- beside a torch process, say -- the set is allocated by the
+    // first launch that needs one, at the size it needs, as a handle created with MMH_LAZY=1 does)
     int *flags = nullptr;
     float *parts = nullptr;
-    rc = workspace_for(h, nullptr, 1 << 16, (size_t)(64u << 20), &flags, &parts);   // the null stream's set
+    if (workspace_for(h, nullptr, 1 << 16, (size_t)(64u << 20), &flags, &parts) != MMH_OK) {   // the null stream's set
+      (void)hipGetLastError();
+      for (auto *e : h->ws)
+        if (e->stream == nullptr) {
+          e->flags.release();
+          e->parts.release();
+          e->flags_dirty = true;
+        }
+    }
   }
   const hipError_t e = hipStreamSynchronize(nullptr);
   scratch.release();

@@ -110,18 +110,10 @@ typedef struct mmh_context *mmh_handle_t;
  * stream-K form).  (160x96 and 160x160 were built and measured too -- N = 1920, 2560 -- and lose to the chained
  * stream-K launch of the 128-wide tiles; they live in the tools build, profiles/r04_notes.md.) */
 #define MMH_KERNEL_MFMA_96X96_DMA5 7
-/* K2M (sgemm_dma32.hpp, round 4): the same LDS-DMA ring feeding v_mfma_f32_32x32x2_f32 -- 64-cycle matrix
- * instructions, one conflict-free ds_read_b128 + two v_permlane32_swap per eight k's of A -- and, under stream-K,
- * CHAINED segments (a segment's tail fetches the next segment's first slices).  Same chain, same bits. */
-#define MMH_KERNEL_MFMA32_64X64_DMA 48
-#define MMH_KERNEL_MFMA32_128X64_DMA 49
-#define MMH_KERNEL_MFMA32_128X128_DMA 50
-#define MMH_KERNEL_MFMA32_64X128_DMA 51
-/* ... and on the two-block form v_mfma_f32_32x32x1_2b_f32 (64-row wave tiles; the A operands of four consecutive k's
- * are the four registers of one ds_read_b128 as they stand) */
-#define MMH_KERNEL_MFMA32B_128X64_DMA 60
-#define MMH_KERNEL_MFMA32B_64X128_DMA 61
-#define MMH_KERNEL_MFMA32B_128X128_DMA 62
+/* (Tools build only -- libmmult_hip_ab.so, never this library: K2M, the same LDS-DMA ring feeding
+ * v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x1_2b_f32 (ids 48-51, 60-62; measured slower than the 16x16x4 tiles,
+ * profiles/r04_notes.md), the one-loader and 160-wide forms of K2W (64, 68, 72, 79, 80), the scheduling A/Bs and the
+ * timing-only ablations (16-19, 21-24, 32-47, 52-59).  mmh_set_kernel of the product library rejects them all.) */
 /* OPT-IN split-K (sgemm_mfma.hpp K2s): the K range of every tile runs as S concurrent parts whose
  * partial tiles are summed in part order.  Deterministic, inside the reference harness's tolerance,
  * but NOT the one-chain-per-element bits every other variant returns; never chosen unless asked for
@@ -176,18 +168,23 @@ int mmh_device_info(int device, char *name, int *cu_count, int *clock_mhz);
  * (MMH_OPT_STREAMK_DELEGATIONS counts the hand-overs that took the slow path).  Only the OPT-IN split-K
  * kernels wait for workgroups that may not be resident -- bounded, raising the sticky error below.
  *
- * hipGraphs.  After one eager call of a shape (on any stream), launches capture into a graph.  Nothing can be
- * allocated while a stream is capturing, so a captured stream-K launch uses the workspace set of the capture
- * stream if it has one that is large enough, and otherwise BORROWS the most recently used set that is --
- * normally the one the eager call just used; it records the upload of its phase-order tables as a node of the
- * graph and pins them (a shape that was never launched eagerly is captured with plain-order ranges).  A set a
- * graph points at is never released; a buffer of it that must grow is replaced and the old one lives as long
- * as the handle.  While a graph with stream-K launches RUNS it owns that set, like any buffer it was captured
- * with: do not launch the same handle eagerly on the set's stream at the same time.  Every entry point runs on the handle's device and restores the
+ * hipGraphs.  Launches capture into a graph once the CAPTURE STREAM owns a stream-K workspace set that is large
+ * enough: nothing can be allocated while a stream is capturing, and a graph must not share hand-off words and
+ * partial-tile slots with launches it is not ordered against, so a captured stream-K launch uses the capture stream's
+ * own set or is refused (MMH_ERR_UNSUPPORTED) -- sets are never shared between streams.  A stream gets its set from
+ * mmh_reserve_stream(handle, stream, m, n, k) (eager; sized for anything MMH_KERNEL_AUTO or a forced tile can launch
+ * for that shape) or from one eager call of the shape on that stream; a shape that was never launched eagerly is
+ * captured with plain-order ranges, otherwise the launch records the upload of its phase-order tables as a node of
+ * the graph and pins them.  A set a graph points at is never released; a buffer of it that must grow is replaced and
+ * the old one lives as long as the handle.  While a graph with stream-K launches RUNS it owns the capture stream's
+ * set, like any buffer it was captured with: do not launch the same handle eagerly on the capture stream while a replay
+ * may be running on another stream.  Synchronise a stream before destroying it (its set is found by the stream's
+ * handle value, which the runtime may reuse).  Every entry point runs on the handle's device and restores the
  * caller's current device before it returns. */
 int mmh_create(mmh_handle_t *handle, int device);
 int mmh_destroy(mmh_handle_t handle);
 int mmh_warm(mmh_handle_t handle);
+int mmh_reserve_stream(mmh_handle_t handle, void *stream, int m, int n, int k);
 int mmh_set_kernel(mmh_handle_t handle, int kernel);
 int mmh_get_kernel(mmh_handle_t handle, int *kernel);
 /* Name of a kernel variant ("MMult_hip_mfma", ...), NULL if unknown; and the id of a short name ("mfma",
@@ -367,7 +364,10 @@ int mmh_shard_sgemm(mmh_shard_t shard, int m, int n, int k, const float *A, int 
  * the memory is freed; mmh_shard_destroy unpins whatever is left.
  * (Test mode: with MMH_SHARD_SHARE_DEVICE=1 in the environment, a device list that names ONE device ngpus times
  * creates ngpus LOGICAL ranks on it -- B replicated by device copies, no RCCL -- so that the phase plumbing of
- * an N-rank shard, empty row panels included, runs on a box with one GPU.  Never entered implicitly.) */
+ * an N-rank shard, empty row panels included, runs on a box with one GPU.  Never entered implicitly.
+ * Second test switch: with MMH_SHARD_FORCE_RCCL=1 a ONE-device shard (ngpus == 1) builds a one-rank communicator
+ * (ncclCommInitAll) and mmh_shard_sgemm issues its ncclBroadcast on it -- rccl_ranks = 1 -- so that the RCCL branch
+ * has run once before the first multi-GPU node sees it.) */
 int mmh_shard_pin(mmh_shard_t shard, void *host, size_t bytes);
 int mmh_shard_unpin(mmh_shard_t shard, void *host);
 /* RCCL as this library sees it: loads librccl (dlopen) and returns ncclGetVersion's code in *version;

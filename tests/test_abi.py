@@ -142,14 +142,17 @@ def test_product_library_carries_no_ablation_builds():
     tools-only libmmult_hip_ab.so: the product library neither names nor contains them."""
     L = H.lib()
     assert L.mmh_is_ab_build() == 0
-    for kid in list(range(16, 20)) + list(range(21, 25)) + list(range(32, 45)):
+    tools_only = (list(range(16, 20)) + list(range(21, 25)) + list(range(32, 48)) +     # scheduling A/Bs, ablations, 8-wave forms
+                  list(range(48, 64)) + list(range(64, 96)))                              # 32x32x2 tiles (round 4), exp5_*, 160-wide tiles
+    for kid in tools_only:
         assert H.kernel_name(kid) is None, kid
     blob = open(H.LIB_PATH, "rb").read()
     assert b"ablate" not in blob and b"cadence_" not in blob
+    # round 4: the rim, the 32x32x2 tiles and the one-loader K2W forms left the product library too
+    assert b"dma_rim_kernel" not in blob and b"sgemm_dma32" not in blob and b"exp5_" not in blob
     # every id the Python mirror offers is a product kernel
     assert sorted(H.KERNELS.values()) == sorted(set(H.KERNELS.values()))
-    ab_only = set(range(16, 20)) | set(range(21, 25)) | set(range(32, 45))
-    assert not ab_only & set(H.KERNELS.values())
+    assert not set(tools_only) & set(H.KERNELS.values())
 
 
 def test_no_device_fails_loudly_without_fallback():

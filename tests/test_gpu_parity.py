@@ -21,8 +21,6 @@ pytestmark = pytest.mark.gpu
 
 KERNELS = ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "auto", "mfma_pipe", "mfma_simple", "valu",
            "valu_128x128", "valu_64x64", "naive", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma",
-           "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma",
-    "mfma32b_128x64_dma", "mfma32b_64x128_dma", "mfma32b_128x128_dma",
     "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5"]
 
 
@@ -106,8 +104,6 @@ def test_seeded_inputs_vs_oracle(mm, oracle, shape, kernel):
 
 
 @pytest.mark.parametrize("kernel", ["mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma",
-                                    "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma",
-    "mfma32b_128x64_dma", "mfma32b_64x128_dma", "mfma32b_128x128_dma",
     "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5"])
 def test_lds_dma_small_tile_kernel_is_the_same_chain(mm, oracle, kernel):
     """K2L (sgemm_dma.hpp): both operands by LDS-DMA into a ring of K-slice buffers, A as a ROW-major
@@ -537,8 +533,6 @@ def test_unaligned_pointers_take_the_guarded_path(mm, oracle):
 
 @pytest.mark.parametrize("kernel", ["mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "mfma_64x64_dma",
                                     "mfma_128x64_dma", "mfma_128x128_dma", "auto",
-                                    "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma",
-    "mfma32b_128x64_dma", "mfma32b_64x128_dma", "mfma32b_128x128_dma",
     "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5"])
 def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
     """Every operand only 4-byte aligned, odd lda/ldb/ldc, ragged m/n/k, with
@@ -571,8 +565,6 @@ def test_misaligned_operands_and_odd_leading_dimensions(mm, oracle, kernel):
 
 
 @pytest.mark.parametrize("kernel", ["mfma", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma", "auto",
-                                    "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma",
-    "mfma32b_128x64_dma", "mfma32b_64x128_dma", "mfma32b_128x128_dma",
     "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5"])
 def test_nonfinite_padding_does_not_leak_through_the_k_tail(mm, oracle, kernel):
     """k not a multiple of the K-slice: the loads run into the next row / the
@@ -633,7 +625,7 @@ def test_int8_bit_exact(mm, oracle):
     assert np.array_equal(out.cpu().numpy(), oracle.ref_igemm_s8(a, b, c0.copy()))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 8])      # (7, the 16-MFMA-per-phase ping-pong: tools build, tests/test_tools_build.py)
 def test_int8_every_kernel_bit_exact(mm, oracle, mode):
     """Each int8 kernel forced in turn (MMH_OPT_IGEMM_MODE: 1 in-kernel transpose, 2 simple,
     3 / 4 packed-B LDS-DMA with 128x128 / 256x256 tiles, 5 / 6 B read in place likewise, 7 / 8 the ping-pong
@@ -855,6 +847,8 @@ def test_launches_capture_into_a_hip_graph(mm, oracle):
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
+    for (m, n, k) in shapes:              # the capture stream needs a stream-K workspace set of its own (never borrowed)
+        mm.reserve_stream(side.cuda_stream, m, n, k)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):

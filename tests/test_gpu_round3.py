@@ -21,8 +21,6 @@ def dev(x):
 
 
 DMA_KERNELS = ["mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma",
-               "mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma",
-    "mfma32b_128x64_dma", "mfma32b_64x128_dma", "mfma32b_128x128_dma",
     "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5"]
 
 
@@ -203,6 +201,7 @@ def test_captured_stream_k_launches_keep_their_phase_tables(oracle):
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        h.reserve_stream(side.cuda_stream, m, n, k)      # a captured stream-K launch uses the capture stream's own set
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, stream=side):
@@ -228,6 +227,58 @@ def test_captured_stream_k_launches_keep_their_phase_tables(oracle):
             graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(c, eager), rep
+        assert h.streamk_timeouts() == 0
+    finally:
+        h.close()
+
+
+def test_a_capture_never_borrows_another_streams_workspaces(oracle):
+    """Round-3 advisor finding: a stream-K launch captured on a stream without a workspace set of its own used to
+    BORROW the most recently used set of any other stream -- a replay beside an eager launch on that stream then
+    raced on the hand-off words.  Now the capture is refused (MMH_ERR_UNSUPPORTED, nothing launched) until the
+    capture stream owns a set (mmh_reserve_stream); with one, an eager launch on the ORIGINAL stream running beside
+    replays leaves both results bit-exact."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    h = H.MMult(0, "auto")
+    try:
+        m, n, k = 2944, 3072, 160
+        a, b = oracle.harness_inputs(m, n, k, seed=22)
+        da, db = dev(a), dev(b)
+        eager = h.matmul(da, db).clone()
+        assert "streamk" in H.last_launch(), H.last_launch()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        c = torch.empty((m, n), device="cuda")
+        refused = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            try:
+                with torch.cuda.graph(graph, stream=side):
+                    try:
+                        h.matmul(da, db, out=c)
+                    except H.MMultError as e:
+                        refused = e
+            except Exception:
+                pass                                     # an empty capture may not instantiate: not what is tested
+        assert refused is not None and refused.status == H.ERR_UNSUPPORTED, refused
+        torch.cuda.current_stream().wait_stream(side)
+        h.reserve_stream(side.cuda_stream, m, n, k)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                h.matmul(da, db, out=c)
+        torch.cuda.current_stream().wait_stream(side)
+        c2 = torch.empty((m, n), device="cuda")
+        for rep in range(4):                             # replays on `side` beside eager launches on the current stream
+            c.fill_(float("nan"))
+            c2.fill_(float("nan"))
+            with torch.cuda.stream(side):
+                graph.replay()
+            h.matmul(da, db, out=c2)
+            torch.cuda.synchronize()
+            assert torch.equal(c, eager) and torch.equal(c2, eager), rep
         assert h.streamk_timeouts() == 0
     finally:
         h.close()
@@ -356,57 +407,38 @@ def test_single_process_shard_with_empty_panels_and_pinned_host_arrays():
     assert r.returncode == 0 and "shard-pinned ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
-RIM_SHAPES = [(1025, 1025, 1025), (1024, 1027, 300), (1031, 1024, 77), (1032, 1032, 64), (2049, 2049, 129),
-              (1288, 1025, 511), (3073, 1026, 96), (257, 4097, 200), (1025, 1281, 257), (1153, 1025, 190)]
+_SHARD_RCCL1 = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import how_to_optimize_gemm_amd as H
+from oracle import oracle
+assert H.rccl_version() > 0
+with H.ShardedMMult(1, kernel="auto") as sh:
+    assert sh.info() == {"ngpus": 1, "rccl_ranks": 0}              # without the switch: one device, no RCCL
+os.environ["MMH_SHARD_FORCE_RCCL"] = "1"
+for (m, n, k) in ((384, 256, 128), (1000, 640, 96), (4096, 512, 64)):
+    a, b = oracle.harness_inputs(m, n, k, seed=m)
+    with H.ShardedMMult(1, kernel="auto") as sh:
+        assert sh.info() == {"ngpus": 1, "rccl_ranks": 1}, sh.info()   # ncclCommInitAll(1) ran
+        for rep in range(2):
+            c = np.full((m, n), np.nan, dtype=np.float32)
+            got, t = sh.sgemm(a, b, c, gemm_reps=2)
+            assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True)), (m, n, k, rep)
+            assert t["bcast"] > 0.0, t                               # the ncclBroadcast was issued and waited for
+got = H.sgemm_sharded(1, a, b, kernel="auto")                        # the one-shot form through the same branch
+assert np.array_equal(got[0] if isinstance(got, tuple) else got, oracle.ref_mmult(a, b, fma=True))
+print("shard-rccl1 ok")
+"""
 
 
-def test_the_rim_runs_on_the_vector_alu_with_the_tiles_bits(oracle):
-    """MMH_OPT_RIM (sgemm_dma.hpp, "the rim"; opt-in, off by default since it measured slower than the edge tiles it
-    replaces): shapes a few elements past a multiple of 64 run as the tiles of the trimmed shape + extra vector-ALU
-    workgroups for the strips beyond it, in one launch -- where tiles and rim units are all resident at once.  Every element -- tile or
-    rim -- is the oracle's fused chain over ascending k: bit-equal to the oracle and to the same handle with the rim
-    switched off, for overwrite and accumulate, with odd leading dimensions and NaN in every padding column."""
-    import torch
-    import how_to_optimize_gemm_amd as H
-    mm = H.MMult(0, "auto")
-    try:
-        assert mm.get_option(H.OPT_RIM) == 0
-        rims = 0
-        for i, (m, n, k) in enumerate(RIM_SHAPES):
-            a, b = oracle.harness_inputs(m, n, k, seed=m + 7 * n + k)
-            lda, ldb, ldc = k + (i % 3), n + (i % 2) * 3, n + ((i + 1) % 2) * 5
-            abuf = torch.full((m * lda + 9,), float("nan"), device="cuda")
-            bbuf = torch.full((k * ldb + 9,), float("nan"), device="cuda")
-            cbuf = torch.full((m * ldc + 9,), float("nan"), device="cuda")
-            off = i % 2
-            av = abuf[off:off + m * lda].view(m, lda)
-            bv = bbuf[off:off + k * ldb].view(k, ldb)
-            cv = cbuf[off:off + m * ldc].view(m, ldc)
-            av[:, :k] = dev(a)
-            bv[:, :n] = dev(b)
-            c0 = np.random.default_rng(i).uniform(-1, 1, (m, n)).astype(np.float32)
-            for accumulate in (False, True):
-                want = oracle.ref_mmult(a, b, c0.copy() if accumulate else None, fma=True)
-                for rim in (8, 0):
-                    mm.set_option(H.OPT_RIM, rim)
-                    cv[:, :n] = dev(c0)
-                    mm.sgemm(m, n, k, av.data_ptr(), lda, bv.data_ptr(), ldb, cv.data_ptr(), ldc, accumulate,
-                             torch.cuda.current_stream().cuda_stream)
-                    launched = H.last_launch()
-                    if rim == 0:
-                        assert "rim" not in launched, launched
-                    rims += "on the rim" in launched
-                    got = cv[:, :n].cpu().numpy()
-                    assert np.array_equal(got, want), (m, n, k, accumulate, launched)
-                    if ldc > n:
-                        assert torch.isnan(cv[:, n:]).all(), (m, n, k)
-                    assert torch.isnan(cbuf[:off]).all() and torch.isnan(cbuf[off + m * ldc:]).all()
-        assert rims >= 8, rims          # the small shapes trim onto a one-round plain launch of the 64x64 tile
-        mm.set_option(H.OPT_RIM, 0)
-        with pytest.raises(H.MMultError):
-            mm.set_option(H.OPT_RIM, 17)
-    finally:
-        mm.close()
+def test_single_device_shard_through_a_one_rank_rccl_communicator():
+    """the C side's RCCL branch (csrc/shard.hip: loader, ncclCommInitAll, one ncclBroadcast per
+    device inside a group, the per-device stream waits, communicator teardown) had never executed -- ngpus == 1 skips
+    it and gpurun offers one GPU.  MMH_SHARD_FORCE_RCCL=1 makes a one-device shard build a ONE-rank communicator and
+    broadcast B on it: rccl_ranks == 1, the broadcast phase takes time, the result is the single-GPU chain's bits."""
+    r = subprocess.run([sys.executable, "-c", _SHARD_RCCL1, REPO], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "shard-rccl1 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_the_host_plan_is_what_the_device_launches(mm):

@@ -93,4 +93,20 @@ PY
   find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
   timeout 200 python tools/create_time.py --runs 2 > $OUT/create_time.json 2>&1; cat $OUT/create_time.json | tr -d '\n' | cut -c1-600; echo
 fi
+if has dataset; then    # every (tile family, launch form) forced over the fit / held-out shape lists: what MMH_KERNEL_AUTO's table is fitted on
+  DV="auto,mfma_64x64_dma5/sk0,mfma_64x64_dma5/sk2,mfma_128x64_dma5/sk0,mfma_128x64_dma5/sk2,mfma_128x128_dma5/sk0,mfma_128x128_dma5/sk2,mfma_96x96_dma5,mfma_256x256/sk0,mfma_256x256/sk2,mfma_64x64_dma,mfma_128x64_dma,mfma_128x128_dma"
+  for which in ${DATASETS:-fit heldout}; do
+    timeout 900 python tools/tile_sweep.py --shape-file tools/policy_shapes_$which.txt --variants "$DV" --rounds 2 --reps 10 --warm-ms 10 \
+      --out $OUT/dataset_$which > $OUT/dataset_$which.log 2>&1
+    tail -2 $OUT/dataset_$which.log | cut -c1-300
+  done
+fi
+if has edge2; then      # thin tiles: plain against persistent launches of the K2W tiles one element past a tile boundary
+  timeout 300 python tools/tile_sweep.py --check --shapes "${EDGE_SHAPES:-1025,1025,1025;1040,1040,1040;1281,1281,1281;1409,1409,1409;1537,1537,1537;2049,2049,2049;2561,2561,2561;1024,1024,1024;1023,1023,1023;1100,1100,1100}" \
+    --variants "auto,mfma_64x64_dma,mfma_64x64_dma/sk0,mfma_64x64_dma5,mfma_64x64_dma5/sk0,mfma_128x64_dma5,mfma_128x64_dma5/sk0,mfma_96x96_dma5,rocblas,hipblaslt" --out $OUT/edge2 > $OUT/edge2.log 2>&1; tail -11 $OUT/edge2.log | cut -c1-600
+fi
+if has tl5; then        # per-workgroup timeline of plain K2W launches (thin tiles last)
+  timeout 600 python tools/dma5_timeline.py --kernel ${TL_KERNEL:-mfma_64x64_dma5} --shape ${TL_SHAPES:-1025,1025,1025 1024,1024,1024 1040,1040,1040} > $OUT/tl5_${TL_KERNEL:-mfma_64x64_dma5}.txt 2>&1
+  cat $OUT/tl5_${TL_KERNEL:-mfma_64x64_dma5}.txt | grep -v amdgpu.ids
+fi
 du -sh $OUT

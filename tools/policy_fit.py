@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""policy_fit.py -- fit MMH_KERNEL_AUTO's cost table to a measured dataset and judge it on held-out shapes (no GPU).
+
+    python tools/policy_fit.py --fit gpurun_out/r04/dataset_fit.json [--heldout gpurun_out/r04/dataset_heldout.json]
+                               [--emit how-to-optimize-gemm_amd/csrc/policy_table.inc] [--report profiles/r04_auto_regret.md]
+
+The dataset (tools/tile_sweep.py over tools/policy_shapes_*.txt) holds, per shape, the TFLOP/s of every tile family
+forced as a plain launch (/sk0) and as a persistent stream-K launch (/sk2).  The model AUTO evaluates per candidate
+(csrc/policy.hip, the same arithmetic as predict() below):
+
+    plain:     t = fix_p + cmax * nk * s_p[min(cmax, w)]          cmax = ceil(tiles / CUs): tiles on the fullest CU
+    stream-K:  t = fix_s + (tiles * nk / CUs) * s_s[w']           w' = persistent workgroups per CU
+
+with nk = ceil(k / 32) K-slices per tile and w the family's co-residency; a plain launch of more than one round of
+workgroups whose last round is not full (cmax > w, tiles not a multiple of w CUs) is priced `margin` times its prediction -- the 90th percentile of measured / predicted over the fit
+set's multi-round plain rows: which CU gets the last tiles, and when, is the dispatcher's business, and the residuals
+of those rows are one-sided.  s_x[o] is what a CU takes per tile-slice
+with o tiles co-resident, fix_x everything that does not scale with K (launch, pipeline fill, C store, hand-over).
+All of it is per family, in microseconds, least squares in relative error over the fit set's rows of that family
+and form.  Everything is expressed per CU, so the table serves any CU count (partitioned devices).
+
+This replaces round 3's hand-set thresholds (the reference's `NEW := MMult_xxx` choice, cuda/makefile:1-3)."""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CUS = 256
+# family: (kernel short name, BM, BN, co-resident workgroups per CU, has a stream-K form)
+FAMILIES = {
+    "t64": ("mfma_64x64_dma5", 64, 64, 3, True),
+    "t128x64": ("mfma_128x64_dma5", 128, 64, 2, True),
+    "t128": ("mfma_128x128_dma5", 128, 128, 1, True),
+    "t96": ("mfma_96x96_dma5", 96, 96, 2, False),
+    "t256": ("mfma_256x256", 256, 256, 1, True),
+}
+
+
+def geometry(fam, m, n, k, cus=CUS):
+    _, bm, bn, w, has_sk = FAMILIES[fam]
+    nbm, nbn = -(-m // bm), -(-n // bn)
+    tiles = nbm * nbn
+    nk = -(-k // 32)
+    cmax = -(-tiles // cus)
+    wp = 0
+    for cand in range(w, 0, -1):
+        if tiles >= cand * cus:
+            wp = cand
+            break
+    sk_possible = has_sk and wp > 0 and tiles % (wp * cus) != 0
+    return dict(tiles=tiles, nk=nk, cmax=cmax, occ=min(cmax, w), wp=wp, sk_possible=sk_possible, w=w)
+
+
+def rows_of(dataset):
+    """(family, form, shape, microseconds) for every measured candidate whose launch took the form it was asked for."""
+    out = []
+    for r in dataset:
+        m, n, k = r["m"], r["n"], r["k"]
+        flops = 2.0 * m * n * k
+        for fam, (kern, *_rest) in FAMILIES.items():
+            for suffix, form in (("/sk0", "plain"), ("/sk2", "sk"), ("", "plain")):
+                key = kern + suffix
+                tf = r.get(key)
+                if not tf:
+                    continue
+                if "forms" in r:      # compacted dataset (--compact): p = persistent, 1 = plain, x = another family ran
+                    code = r["forms"].get(key, "x")
+                    is_sk, own = code == "p", code != "x"
+                else:
+                    launched = r.get("launched", {}).get(key, "")
+                    is_sk = "persistent" in launched
+                    own = "LDS-DMA" in launched or fam == "t256"
+                if (form == "sk") != is_sk:
+                    continue
+                if not own:
+                    continue      # fell back to a register-staged tile (descriptor window): not this family
+                out.append((fam, form, (m, n, k), flops / tf / 1e6))
+    return out
+
+
+def compact(dataset):
+    """The dataset without its launch strings: per measured variant one letter (p = persistent launch, 1 = one
+    workgroup per tile, x = the family did not take the shape) -- what is committed under profiles/."""
+    out = []
+    for r in dataset:
+        c = {k: v for k, v in r.items() if k not in ("launched", "bit_equal_to_first")}
+        forms = {}
+        for key, text in r.get("launched", {}).items():
+            fam_ok = "LDS-DMA" in text or key.startswith("mfma_256x256") or key == "auto"
+            forms[key] = "x" if not fam_ok else ("p" if "persistent" in text else "1")
+        c["forms"] = forms
+        out.append(c)
+    return out
+
+
+def fit(rows):
+    table = {}
+    for fam, (_, bm, bn, w, has_sk) in FAMILIES.items():
+        entry = {"bm": bm, "bn": bn, "w": w, "fix_p": 0.0, "s_p": [0.0] * 3, "fix_s": 0.0, "s_s": [0.0] * 3, "n_p": 0, "n_s": 0,
+                 "rms_p": 0.0, "rms_s": 0.0}
+        for form in ("plain", "sk"):
+            sel = [(s, us) for (f, fo, s, us) in rows if f == fam and fo == form]
+            if len(sel) < 4:
+                continue
+            X, y = [], []
+            for (m, n, k), us in sel:
+                g = geometry(fam, m, n, k)
+                feat = [1.0, 0.0, 0.0, 0.0]
+                if form == "plain":
+                    feat[g["occ"]] = g["cmax"] * g["nk"]
+                else:
+                    feat[g["wp"]] = g["tiles"] * g["nk"] / CUS
+                X.append([f / us for f in feat])      # relative error
+                y.append(1.0)
+            X, y = np.array(X), np.array(y)
+            used = [j for j in range(4) if np.any(X[:, j] != 0)]
+            sol, *_ = np.linalg.lstsq(X[:, used], y, rcond=None)
+            coef = [0.0] * 4
+            for j, v in zip(used, sol):
+                coef[j] = max(float(v), 0.0)
+            # occupancies never observed inherit the nearest observed one
+            for j in (1, 2, 3):
+                if coef[j] == 0.0:
+                    near = [coef[i] for i in (j - 1, j + 1, j - 2, j + 2) if 1 <= i <= 3 and coef[i] > 0]
+                    coef[j] = near[0] if near else 0.0
+            res = X @ np.array(coef) - y
+            if form == "plain":
+                entry.update(fix_p=coef[0], s_p=coef[1:], n_p=len(sel), rms_p=float(np.sqrt(np.mean(res ** 2))))
+            else:
+                entry.update(fix_s=coef[0], s_s=coef[1:], n_s=len(sel), rms_s=float(np.sqrt(np.mean(res ** 2))))
+        table[fam] = entry
+    # multi-round plain launches: their residuals are one-sided (the tail of the last round) -- price them at the 90th
+    # percentile of measured / predicted
+    ratios = []
+    for (f, fo, (m, n, k), us) in rows:
+        g = geometry(f, m, n, k)
+        if fo == "plain" and g["cmax"] > g["w"] and g["tiles"] % (g["w"] * CUS) != 0 and table[f]["n_p"]:
+            e = table[f]
+            ratios.append(us / (e["fix_p"] + g["cmax"] * g["nk"] * e["s_p"][g["occ"] - 1]))
+    table["_margin"] = round(float(np.percentile(ratios, 90)), 3) if ratios else 1.0
+    return table
+
+
+def predict(table, fam, form, m, n, k, cus=CUS):
+    e = table[fam]
+    g = geometry(fam, m, n, k, cus)
+    if form == "plain":
+        t = e["fix_p"] + g["cmax"] * g["nk"] * e["s_p"][g["occ"] - 1]
+        return t * table.get("_margin", 1.0) if g["cmax"] > g["w"] and g["tiles"] % (g["w"] * cus) != 0 else t
+    if not g["sk_possible"] or e["n_s"] == 0:
+        return math.inf
+    return e["fix_s"] + g["tiles"] * g["nk"] / cus * e["s_s"][g["wp"] - 1]
+
+
+def choose(table, m, n, k, cus=CUS):
+    best, best_t = None, math.inf
+    for fam in FAMILIES:
+        if k > 8192 and fam != "t256":
+            continue          # B beyond the Infinity Cache: the big tile, not part of the fit
+        for form in ("plain", "sk"):
+            t = predict(table, fam, form, m, n, k, cus)
+            if t < best_t:
+                best, best_t = (fam, form), t
+    return best, best_t
+
+
+def measured(r, fam, form):
+    kern = FAMILIES[fam][0]
+    for key in ([kern + "/sk2"] if form == "sk" else [kern + "/sk0", kern]):
+        if r.get(key):
+            return r[key]
+    return None
+
+
+def regret(table, dataset):
+    out = []
+    for r in dataset:
+        m, n, k = r["m"], r["n"], r["k"]
+        (fam, form), _ = choose(table, m, n, k)
+        got = measured(r, fam, form)
+        cands = {}
+        for f in FAMILIES:
+            for fo in ("plain", "sk"):
+                v = measured(r, f, fo)
+                if v:
+                    cands[(f, fo)] = v
+        best = max(cands.values())
+        out.append(dict(shape=(m, n, k), chosen=f"{fam}/{form}", tf=got, best=best, best_is=max(cands, key=cands.get),
+                        regret=1.0 - (got or 0.0) / best, old_auto=r.get("auto")))
+    return out
+
+
+def emit(table, path, source):
+    with open(path, "w") as f:
+        f.write("// policy_table.inc -- GENERATED by tools/policy_fit.py from " + source + "; do not edit by hand.\n")
+        f.write("// Per tile family: co-residency w, then microseconds: plain launches t = fix_p + cmax * nk * s_p[min(cmax, w) - 1],\n")
+        f.write("// persistent stream-K launches t = fix_s + tiles * nk / CUs * s_s[w' - 1] (tools/policy_fit.py has the derivation;\n")
+        f.write("// rows / rms relative residual of each fit behind it).\n")
+        fams = {k: v for k, v in table.items() if not k.startswith("_")}
+        for fam, e in fams.items():
+            f.write(f"// {fam}: plain {e['n_p']} rows, rms {e['rms_p']:.3f}; stream-K {e['n_s']} rows, rms {e['rms_s']:.3f}\n")
+        f.write(f"#define MMH_POLICY_MULTIROUND_MARGIN {table.get('_margin', 1.0):.3f}f   // plain launches of more than one round: p90 of measured / predicted\n")
+        f.write("#define MMH_POLICY_FAMILIES \\\n")
+        for fam, e in fams.items():
+            kern = {"t64": "MMH_KERNEL_MFMA_64X64_DMA5", "t128x64": "MMH_KERNEL_MFMA_128X64_DMA5", "t128": "MMH_KERNEL_MFMA_128X128_DMA5",
+                    "t96": "MMH_KERNEL_MFMA_96X96_DMA5", "t256": "MMH_KERNEL_MFMA_256X256"}[fam]
+            sp = ", ".join(f"{v:.6f}f" for v in e["s_p"])
+            ss = ", ".join(f"{v:.6f}f" for v in e["s_s"])
+            f.write(f"  {{{kern}, {e['bm']}, {e['bn']}, {e['w']}, {1 if e['n_s'] else 0}, {e['fix_p']:.4f}f, {{{sp}}}, {e['fix_s']:.4f}f, {{{ss}}}}}, \\\n")
+        f.write("\n")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fit", required=True)
+    ap.add_argument("--heldout", default="")
+    ap.add_argument("--emit", default="")
+    ap.add_argument("--report", default="")
+    ap.add_argument("--compact", default="", help="write the fit (and held-out) dataset without launch strings: PREFIX_fit.json, PREFIX_heldout.json")
+    args = ap.parse_args()
+    fit_set = json.load(open(args.fit))
+    if args.compact:
+        json.dump(compact(fit_set), open(args.compact + "_fit.json", "w"), separators=(",", ":"))
+        if args.heldout:
+            json.dump(compact(json.load(open(args.heldout))), open(args.compact + "_heldout.json", "w"), separators=(",", ":"))
+    table = fit(rows_of(fit_set))
+    print("multi-round plain margin", table["_margin"])
+    for fam, e in table.items():
+        if fam.startswith("_"):
+            continue
+        print(fam, json.dumps({k: (round(v, 4) if isinstance(v, float) else [round(x, 5) for x in v] if isinstance(v, list) else v)
+                               for k, v in e.items()}))
+    lines = []
+    for label, path in (("fit", args.fit), ("held-out", args.heldout)):
+        if not path:
+            continue
+        rg = regret(table, json.load(open(path)))
+        rs = np.array([x["regret"] for x in rg])
+        old = np.array([1.0 - (x["old_auto"] or 0.0) / x["best"] for x in rg])
+        summary = (f"{label}: {len(rg)} shapes; regret of the table's choice against the best measured candidate: mean {rs.mean() * 100:.2f} %, "
+                   f"p90 {np.percentile(rs, 90) * 100:.2f} %, max {rs.max() * 100:.2f} %; the round-3 rules on the same rows (old `auto` column): "
+                   f"mean {old.mean() * 100:.2f} %, max {old.max() * 100:.2f} %")
+        print(summary)
+        lines.append(summary)
+        worst = sorted(rg, key=lambda x: -x["regret"])[:12]
+        for x in worst:
+            lines.append(f"  {x['shape']}: chose {x['chosen']} {x['tf']} TF, best {x['best_is'][0]}/{x['best_is'][1]} {x['best']} ({x['regret'] * 100:.1f} %)")
+        for l in lines[-12:]:
+            print(l)
+    if args.emit:
+        emit(table, args.emit, os.path.basename(args.fit))
+        print("wrote", args.emit)
+    if args.report:
+        with open(args.report, "w") as f:
+            f.write("# MMH_KERNEL_AUTO: fitted cost table and its regret (tools/policy_fit.py)\n\n```\n")
+            f.write(f"multi-round plain margin {table['_margin']}\n")
+            for fam, e in table.items():
+                if fam.startswith("_"):
+                    continue
+                f.write(fam + " " + json.dumps({k: (round(v, 4) if isinstance(v, float) else [round(x, 5) for x in v] if isinstance(v, list) else v)
+                                                for k, v in e.items()}) + "\n")
+            f.write("```\n\n" + "\n".join(lines) + "\n")
+        print("wrote", args.report)
+
+
+if __name__ == "__main__":
+    main()

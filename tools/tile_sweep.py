@@ -28,6 +28,8 @@ VENDORS = ["rocblas", "hipblaslt"]
 
 
 def parse_shapes(args):
+    if args.shape_file:
+        return [tuple(int(x) for x in line.split(",")) for line in open(args.shape_file) if line.strip()]
     if args.shapes:
         return [tuple(int(x) for x in s.split(",")) for s in args.shapes.split(";") if s]
     lo, hi, step = (int(x) for x in args.sizes.split(":"))
@@ -38,6 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="1024:4096:128")
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--shape-file", default="", help="one m,n,k per line (tools/policy_shapes.py)")
     ap.add_argument("--variants", default=DEFAULT)
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "tile_sweep"))
     ap.add_argument("--reps", type=int, default=20)
@@ -53,7 +56,9 @@ def main():
     mm = H.MMult(0, "auto")
     stream = torch.cuda.current_stream().cuda_stream
     variants = args.variants.split(",")
-    big = torch.rand((1 << 28,), device="cuda") * 2 - 1
+    shapes = parse_shapes(args)
+    need_max = max(m * k + k * n + m * n for (m, n, k) in shapes)
+    big = torch.rand((max(1 << 28, need_max),), device="cuda") * 2 - 1
     rows = []
 
     def select(v):
@@ -64,7 +69,7 @@ def main():
         mm.set_option(H.OPT_STREAMK_CHAIN, 0 if "nc" in parts[1:] else 1)
         mm.set_option(H.OPT_PERSIST, 1 if "p1" in parts[1:] else 0)
 
-    for (m, n, k) in parse_shapes(args):
+    for (m, n, k) in shapes:
         need = m * k + k * n + m * n
         a = big[:m * k].view(m, k)
         b = big[m * k:m * k + k * n].view(k, n)
