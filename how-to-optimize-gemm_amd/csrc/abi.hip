@@ -156,6 +156,9 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       if (value < 0 || value > 1024) return MMH_ERR_INVALID_ARG;
       h->ab_group_m = value;
       return MMH_OK;
+    case 102:   // A/B: chained stream-K heads publish on the spot instead of on the next part's first slice
+      h->ab_nodefer = value ? 1 : 0;
+      return MMH_OK;
 #endif
     default:
       return MMH_ERR_INVALID_ARG;

@@ -138,6 +138,7 @@ struct mmh_context {
   int dma_edge = 1;            // ragged / 4-byte-aligned shapes may run the guarded LDS-DMA tiles (MMH_OPT_DMA_EDGE)
   int dma_dword_rows = 1;      // ... including operands whose rows are only 4-byte aligned (odd lda / ldb / base)
   int sk_chain = 1;            // stream-K launches of the K2M tiles run a range's parts as one stream of slices (MMH_OPT_STREAMK_CHAIN)
+  int ab_nodefer = 0;          // tools build only (option 102): stream-K heads publish on the spot (no deferred publish)
   int ab_group_m = 0;          // tools build only (option 101): raster group height of the plain K2W launch, 0 = GROUP_M
   int persist = 0;             // whole rounds of the persistent grid run persistent too (MMH_OPT_PERSIST)
   int rim = 0;                 // MMH_KERNEL_AUTO trims up to this many rows / columns past a 64-boundary off the tiles (MMH_OPT_RIM; off: measured, it does not pay)

@@ -27,6 +27,10 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
   if (form < 0) return 1;
   const bool edge = form == 1;
   char what[256];
+  GemmArgs ga = g;
+#ifdef MMH_AB_BUILD   // A/B switches ride in the upper bits of `accumulate` (sgemm_dma5.hpp)
+  if (ctx) ga.acc |= (ctx->ab_nodefer ? 2 : 0) | ((ctx->ab_group_m & 0xff) << 8);
+#endif
   if constexpr (SK) {
     if (ctx && ctx->streamk) {
       // the parts of a range as ONE stream of slices (MMH_OPT_STREAMK_CHAIN, default on), or each with a prologue of its own
@@ -48,7 +52,7 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
         const int thin_row = (nbm > 1 && g.m - (nbm - 1) * BM <= 16) ? 1 : 0, thin_col = (nbn > 1 && g.n - (nbn - 1) * BN <= 16) ? 1 : 0;
         if (thin_row || thin_col) decide = (long)(nbm - thin_row) * (nbn - thin_col);
       }
-      const int sk = launch_streamk(ctx, edge ? kern_edge : kern, occ, BM, BN, KB, T::THREADS, T::LDS_BYTES, what, g, decide);
+      const int sk = launch_streamk(ctx, edge ? kern_edge : kern, occ, BM, BN, KB, T::THREADS, T::LDS_BYTES, what, ga, decide);
       if (sk <= 0) return sk;
     }
   }
@@ -57,12 +61,8 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
                    : sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, false, NL, D>;
   const int ok = allow_big_lds(kern, T::LDS_BYTES);
   if (ok != MMH_OK) return ok;
-  int nbm_arg = nbm;
-#ifdef MMH_AB_BUILD
-  if (!edge && ctx && ctx->ab_group_m > 0) nbm_arg |= ctx->ab_group_m << 16;   // A/B: raster group height (whole-tile kernel only)
-#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(T::THREADS), T::LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda, g.B,
-                     g.ldb, g.C, g.ldc, g.acc, nbm_arg, nbn);
+                     g.ldb, g.C, g.ldc, edge ? g.acc : ga.acc, nbm, nbn);
   HIP_TRY(hipGetLastError());
   snprintf(what, sizeof what,
            "sgemm_mfma_dma5_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by %d loader wave%s' LDS-DMA, fragments %d k-steps "

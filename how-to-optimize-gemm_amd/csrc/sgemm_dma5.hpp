@@ -76,6 +76,12 @@ struct Dma5Tile {
   static_assert(CHB % PB == 0 && RB % 2 == 0, "whole periods; the row-parity swizzle must not depend on the period");
   static_assert((CHB / PB) % NL == 0, "B's piece periods divide over the loaders");
   static_assert((LA - 1) * NPL <= 63, "vmcnt is a 6-bit counter");
+  // Raster group height: the tiles an XCD runs at one time (64 of the 128x64 tile: 32 CUs x 2) form a GM x 64 / GM patch
+  // of the grouped raster; what its L2 must hold per K-slice is the patch's A rows + B columns.  Measured at N = 4096 on
+  // the 128x64 tile (profiles/r04_notes.md, FETCH_SIZE x 2 per launch): GM = 1 / 2 / 4 / 8 / 16 / 32 -> 2.28 / 1.34 /
+  // 1.07 / 1.34 / 2.29 / 4.35 GB -- 512 rows of A per patch is the sweet spot (the 64-row tiles' 8), and 4 beats 8 at
+  // equal footprint: a k-row of B is contiguous, a K-slice of A one 128-byte line per row.  Time does not move.
+  static constexpr int GM = 512 / BM >= 1 ? 512 / BM : 1;
   static constexpr size_t RING_BYTES = (size_t)NBUF * STAGE * sizeof(float);
   static constexpr size_t LDS_BYTES = RING_BYTES + 64;   // + the line the stream-K body passes a word through
   // the 16-byte chunk of B's k-row r that belongs at physical chunk position pc of the LDS row
@@ -94,6 +100,12 @@ struct Dma5Link {
   int pos = 0;
   bool primed = false;
 };
+// A stream-K HEAD part's publish, deferred into the part that follows it (a WHOLE tile: nothing it depends on): the
+// partial tile went out as write-through stores; instead of draining them on the spot -- every consumer wave idle for
+// a store round trip, then a workgroup barrier -- the drain rides on the next part's first slice barrier, by which
+// time the stores have long completed, and one lane ORs DONE in after it.
+// (run()'s pub_flag: the tile's hand-over word, null = nothing pending; pub_reply: thread 0's copy of what the word held
+// when DONE went in.  Every slice's barrier point carries a wave-uniform test of "pending" -- two scalar instructions.)
 
 // D: fragment prefetch distance in k-steps (ring of SLOTS register sets, slot = k-step mod SLOTS)
 template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool PART_WT = false, bool EDGE = false, bool CHAIN = false,
@@ -153,7 +165,8 @@ struct Dma5Segment {
   static __device__ __forceinline__ void run(float *lds, const Lane &L, int m, int n, int k, const float *__restrict__ A,
                                              int lda, const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                              int tm, int tn, int kb, int ke, bool init_from_c, const float *part_in,
-                                             float *part_out, Frags &fr, Dma5Link &link, const Dma5Next nx = Dma5Next{}) {
+                                             float *part_out, Frags &fr, Dma5Link &link, const Dma5Next nx, int *pub_flag,
+                                             int &pub_reply) {
     constexpr int KS = T::KS, STAGE = T::STAGE, A_FLOATS = T::A_FLOATS, NPL = T::NPL, LA = T::LA;
     const int row0 = tm * BM, col0 = tn * BN;
     const int rows_valid = EDGE ? min(BM, m - row0) : BM;
@@ -252,22 +265,22 @@ struct Dma5Segment {
       const bool thin_n = __builtin_amdgcn_readfirstlane((int)(BBLK ? cv <= 16 : cv <= 1)) != 0;
       if (thin_m && thin_n) {
         consume(std::true_type{}, std::true_type{}, lds, L, m, n, k, C, ldc, row0, col0, rows_valid, cols_valid, kb, ke, pos, primed, chain,
-                init_from_c, part_in, part_out, fr);
+                init_from_c, part_in, part_out, fr, pub_flag, pub_reply);
         return;
       }
       if (thin_m) {
         consume(std::true_type{}, std::false_type{}, lds, L, m, n, k, C, ldc, row0, col0, rows_valid, cols_valid, kb, ke, pos, primed, chain,
-                init_from_c, part_in, part_out, fr);
+                init_from_c, part_in, part_out, fr, pub_flag, pub_reply);
         return;
       }
       if (thin_n) {
         consume(std::false_type{}, std::true_type{}, lds, L, m, n, k, C, ldc, row0, col0, rows_valid, cols_valid, kb, ke, pos, primed, chain,
-                init_from_c, part_in, part_out, fr);
+                init_from_c, part_in, part_out, fr, pub_flag, pub_reply);
         return;
       }
     }
     consume(std::false_type{}, std::false_type{}, lds, L, m, n, k, C, ldc, row0, col0, rows_valid, cols_valid, kb, ke, pos, primed, chain,
-            init_from_c, part_in, part_out, fr);
+            init_from_c, part_in, part_out, fr, pub_flag, pub_reply);
   }
 
   // The consumer side of a segment with NT x NU of the wave's WTM x WTN blocks kept (all of them, or -- thin edge
@@ -276,7 +289,7 @@ struct Dma5Segment {
   static __device__ __forceinline__ void consume(TM1, TN1, float *lds, const Lane &L, int m, int n, int k, float *__restrict__ C,
                                                  int ldc, int row0, int col0, int rows_valid, int cols_valid, int kb, int ke,
                                                  int pos, bool primed, bool chain, bool init_from_c, const float *part_in,
-                                                 float *part_out, Frags &fr) {
+                                                 float *part_out, Frags &fr, int *pub_flag, int &pub_reply) {
     constexpr int KS = T::KS, STAGE = T::STAGE;
     constexpr bool THIN = TM1::value || TN1::value;
     constexpr int NT = TM1::value ? 1 : WTM, NU = TN1::value ? 1 : WTN;   // blocks kept
@@ -369,14 +382,26 @@ struct Dma5Segment {
     // for k-step ks + D (all of them, thin or not: the next segment of a chain may be a whole tile), then the MFMAs of
     // k-step ks; before k-step KS - D the slice's barrier -- from there on the reads go to the NEXT buffer (the loaders'
     // counted wait says it is whole), and every read of this one has been issued.
+    // a HEAD's deferred publish (see Dma5Link's neighbour above): pending until the first slice barrier of this part
+    bool pend = CHAIN && __builtin_amdgcn_readfirstlane((int)(pub_flag != nullptr)) != 0;
     auto slice_at = [&](int kt, const float *buf, const float *nxt, auto tail_c) {
       constexpr bool TAIL = decltype(tail_c)::value;   // EDGE: a slice that may hold k's past the end (operands masked)
       const int krem = TAIL ? k - kt * KB : KB;
       static_for<KS>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         if constexpr (ks == KS - D) {
+          if constexpr (CHAIN) {
+            if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial-tile stores have completed
+          }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
+          if constexpr (CHAIN) {
+            if (pend) {   // ... and so have every other consumer wave's: ONE lane sets DONE
+              if (threadIdx.x == 0)
+                pub_reply = __hip_atomic_fetch_or(pub_flag, SK_HEAD_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              pend = false;
+            }
+          }
         }
         if constexpr (ks + D < KS) {
           frag_a(buf, std::integral_constant<int, ks + D>{}, fr.a[(ks + D) % SLOTS]);
@@ -539,7 +564,7 @@ sgemm_mfma_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda
     const int nbm_f = nbm - thin_row, nbn_f = nbn - thin_col, n_full = nbm_f * nbn_f;
     int r = (int)blockIdx.x - n_full;
     if (r < 0) {
-      block_to_tile(blockIdx.x, n_full, nbm_f, nbn_f, tm, tn);
+      block_to_tile_g(blockIdx.x, n_full, nbm_f, nbn_f, Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>::GM, tm, tn);
     } else if (thin_col && r < nbm) {   // the thin column, top to bottom (its corner with a thin row included)
       tm = r;
       tn = nbn - 1;
@@ -549,19 +574,21 @@ sgemm_mfma_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda
       tn = r;
     }
   } else {
-#ifdef MMH_AB_BUILD   // tools build: the raster group height rides in nbm's upper half (0: GROUP_M)
-    const int gm = nbm >> 16;
-    nbm &= 0xffff;
-    block_to_tile_g(blockIdx.x, nbm * nbn, nbm, nbn, gm > 0 ? gm : GROUP_M, tm, tn);
+#ifdef MMH_AB_BUILD   // tools build: the raster group height rides in bits 8-15 of `accumulate` (0: the tile's own)
+    const int gm = (accumulate >> 8) & 0xff;
+    accumulate &= 1;
+    block_to_tile_g(blockIdx.x, nbm * nbn, nbm, nbn, gm > 0 ? gm : Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>::GM, tm, tn);
 #else
-    block_to_tile(blockIdx.x, nbm * nbn, nbm, nbn, tm, tn);
+    block_to_tile_g(blockIdx.x, nbm * nbn, nbm, nbn, Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>::GM, tm, tn);
 #endif
   }
   typename S::Lane L;
   L.init(lda, ldb);
   typename S::Frags fr;
   Dma5Link link;
-  S::run(lds, L, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0, (k + KB - 1) / KB, accumulate != 0, nullptr, nullptr, fr, link);
+  int no_reply = 0;
+  S::run(lds, L, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, 0, (k + KB - 1) / KB, accumulate != 0, nullptr, nullptr, fr, link,
+         Dma5Next{}, nullptr, no_reply);
   dma_stamp_after_stores(3);
 }
 
@@ -581,6 +608,15 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
   constexpr bool chained = CHAINED;
   using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, true, EDGE, true, NL, D>;
   using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
+#ifdef MMH_AB_BUILD   // tools build: bit 1 of `accumulate` = publish every head on the spot, bits 8-15 = raster group height
+  const bool ab_nodefer = (accumulate & 2) != 0;
+  const int ab_gm = (accumulate >> 8) & 0xff;
+  accumulate &= 1;
+  const int GMr = ab_gm > 0 ? ab_gm : T::GM;
+#else
+  constexpr bool ab_nodefer = false;
+  constexpr int GMr = T::GM;
+#endif
   const int nk = (k + KB - 1) / KB;
   const int Tn = nbm * nbn, G = gridDim.x;
   const int xcd = blockIdx.x % NXCD, local = blockIdx.x / NXCD;
@@ -596,9 +632,9 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
   const int t_last = (int)((u1 - 1) / nk), k_last_end = (int)(u1 - (long long)t_last * nk);
   auto tile_of = [&](int t, int &tm, int &tn) {   // grouped raster, no XCD remap (the ranges are XCD-contiguous)
     const int tt = __builtin_amdgcn_readfirstlane(place ? place[t] : t);
-    const int per_group = GROUP_M * nbn;
-    const int group = tt / per_group, first_m = group * GROUP_M;
-    const int gsize = min(nbm - first_m, GROUP_M);
+    const int per_group = GMr * nbn;
+    const int group = tt / per_group, first_m = group * GMr;
+    const int gsize = min(nbm - first_m, GMr);
     const int in_group = tt - group * per_group;
     tm = first_m + in_group % gsize;
     tn = in_group / gsize;
@@ -633,6 +669,17 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
   int head_reply = 0;   // thread 0: what the word held when DONE went in
   if (last_partial && threadIdx.x == 0)   // "I am running": whoever needs the head may wait for it
     (void)__hip_atomic_fetch_or(&flags[t_last], SK_HEAD_RUNNING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Publish (cdna guide G16, recipe R1): the partial tile went out write-through (sc1) -- every storing wave drains ITS
+  // stores (the loaders' loads in flight are their own business), the workgroup meets, ONE lane ORs DONE in.
+  auto publish_now = [&]() {
+    if (!L.loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+      head_reply = __hip_atomic_fetch_or(&flags[t_last], SK_HEAD_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  int *pending = nullptr;       // a HEAD's hand-over word whose DONE rides on the next part's first slice (chained parts only)
+  int early = SK_EMPTY;         // thread 0: the TAIL's hand-over word as read BEFORE the head's store drain
+  bool have_early = false;
   for (int s = 0;; ++s) {
     Part p;
     if (s < n_parts) {
@@ -650,11 +697,15 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
       p = Part{t_last, k_last_end, nk, LEFT_TO_US};
     }
     Dma5Next nx;
-    if (chained && s + 1 < n_parts) {
+    int next_kind = -1;
+    if (s + 1 < n_parts) {
       const Part f = part_at(s + 1);
-      tile_of(f.t, nx.tm, nx.tn);
-      nx.kb = f.kb;
-      nx.len = f.ke - f.kb;
+      next_kind = f.kind;
+      if (chained) {
+        tile_of(f.t, nx.tm, nx.tn);
+        nx.kb = f.kb;
+        nx.len = f.ke - f.kb;
+      }
     }
     const float *part_in = nullptr;
     if (p.kind == TAIL) {
@@ -662,7 +713,12 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
       if (threadIdx.x == 0) {
         long long polls = 0;
         for (;;) {
-          seen = __hip_atomic_load(&flags[t_first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (have_early) {
+            seen = early;   // (read while our own head's stores were draining: no round trip of its own)
+            have_early = false;
+          } else {
+            seen = __hip_atomic_load(&flags[t_first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           if (seen & SK_HEAD_DONE) break;
           if ((seen & SK_HEAD_RUNNING) && ++polls < (1ll << 22)) {   // resident and on its way: bounded by ITS OWN work
             __builtin_amdgcn_s_sleep(8);
@@ -702,15 +758,22 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
     nx.tn = __builtin_amdgcn_readfirstlane(nx.tn);
     nx.kb = __builtin_amdgcn_readfirstlane(nx.kb);
     nx.len = __builtin_amdgcn_readfirstlane(nx.len);
+    int *const pub_flag = pending;
+    pending = nullptr;
     S::run(lds, L, m, n, k, A, lda, B, ldb, C, ldc, tm, tn, pkb, pke, pkb == 0 && accumulate != 0, part_in,
-           p.kind == HEAD ? my_slot : nullptr, fr, link, nx);
+           p.kind == HEAD ? my_slot : nullptr, fr, link, nx, pub_flag, head_reply);
     if (p.kind == HEAD) {
-      // Publish (cdna guide G16, recipe R1): the partial tile went out write-through (sc1) -- every storing wave
-      // drains ITS stores (the loaders' loads in flight are their own business), the workgroup meets, ONE lane ORs DONE in.
-      if (!L.loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0)
-        head_reply = __hip_atomic_fetch_or(&flags[t_last], SK_HEAD_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (chained && !ab_nodefer && next_kind == WHOLE && nk >= 3) {
+        // a whole tile follows, which depends on nobody: the publish rides on its first slice's barrier (Dma5Publish)
+        pending = &flags[t_last];
+      } else {
+        if (next_kind == TAIL && threadIdx.x == 0) {
+          // our tail's hand-over word, read while our head's stores drain (one round trip instead of two)
+          early = __hip_atomic_load(&flags[t_first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          have_early = true;
+        }
+        publish_now();
+      }
     }
   }
 }

@@ -192,20 +192,23 @@ def test_headline_size_4096(mm, oracle):
     c64 = oracle.ref_mmult_f64(a, b)
     assert np.abs(got - c64).max() <= 1.05 * np.abs(unfused - c64).max() + 1e-6
     # every kernel variant is the same chain -> identical bits.  "auto" is what bench.py and the
-    # harness run at this size: it launches the 128x64 LDS-DMA tile on a plain launch (2048 tiles = four whole
-    # rounds of two workgroups per CU; round 2 ran the 256x256 tile here), and that launch -- like the 64x64
-    # LDS-DMA and the 256x256 tile -- is checked here against the oracle on the FULL matrix, not on sampled rows.
+    # harness run at this size: it launches the 128x64 K2W tile (LDS-DMA by loader waves) on a plain launch (2048
+    # tiles = four whole rounds of two workgroups per CU; round 3 ran K2L's 128x64 tile here, round 2 the 256x256 tile),
+    # and that launch -- like the K2L tiles and the 256x256 tile -- is checked here against the oracle on the FULL
+    # matrix, not on sampled rows.
     import how_to_optimize_gemm_amd as H
-    for kern in ("auto", "mfma_256x256", "mfma_64x64_dma", "mfma_128x64_dma", "mfma256", "mfma_tiles", "mfma_128x64", "valu",
-                 "valu_128x128"):
+    for kern in ("auto", "mfma_256x256", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x64_dma5", "mfma_64x64_dma5", "mfma256",
+                 "mfma_tiles", "mfma_128x64", "valu", "valu_128x128"):
         mm.set_kernel(kern)
         out = mm.matmul(dev(a), dev(b)).cpu().numpy()
         if kern == "mfma_256x256":
             assert "sgemm_mfma_kernel<256,256>" in H.last_launch(), (kern, H.last_launch())
         if kern == "mfma_64x64_dma":
             assert "sgemm_mfma_dma_kernel<64,64>" in H.last_launch() and "4096 workgroups" in H.last_launch(), (kern, H.last_launch())
-        if kern in ("auto", "mfma_128x64_dma"):
+        if kern == "mfma_128x64_dma":
             assert "sgemm_mfma_dma_kernel<128,64>" in H.last_launch() and "2048 workgroups" in H.last_launch(), (kern, H.last_launch())
+        if kern in ("auto", "mfma_128x64_dma5"):
+            assert "sgemm_mfma_dma5_kernel<128,64>" in H.last_launch() and "2048 workgroups" in H.last_launch(), (kern, H.last_launch())
         assert np.array_equal(out, fused), kern
     # accumulate mode at the headline size, through the headline kernel: C's value starts each chain
     mm.set_kernel("auto")
@@ -241,7 +244,7 @@ def test_big_tile_full_matrix_vs_oracle(mm, oracle, shape, expect):
     assert np.array_equal(mm.matmul(dev(a), dev(b)).cpu().numpy(), got), H.last_launch()
     assert mm.streamk_timeouts() == 0
     if shape == (4352, 4352, 4352):
-        assert "sgemm_dma_streamk_kernel<128,64>" in H.last_launch(), H.last_launch()
+        assert "sgemm_dma5_streamk_kernel" in H.last_launch() and "chained parts" in H.last_launch(), H.last_launch()
 
 
 def test_sweep_sizes_integer_pattern_exact(mm, oracle):
@@ -379,23 +382,27 @@ def test_stream_k_is_bit_identical(mm, oracle, shape):
 
 
 def test_auto_on_large_ragged_shapes_uses_the_big_tile_and_keeps_the_bits(mm, oracle):
-    """AUTO on large ragged shapes: whole rounds of 256x256 tiles whose edge padding is no worse than
-    128x128's run the guarded 256x256 tile (4000 x 4000: 256 tiles); 5000 x 5000 -- 6241 tiles of 64x64, 24.4 per
-    CU, a last round 97.5 % full -- runs the guarded 64x64 LDS-DMA tile on a plain launch, as 5120 does on the
-    grid.  Same bits as one workgroup per 128x128 tile and as the oracle."""
+    """AUTO on large ragged shapes (whatever the cost table picks -- tests/test_auto_plan.py and
+    test_the_host_plan_is_what_the_device_launches pin the choice; round 3's rules ran the guarded 256x256 tile at
+    4000 x 4000 and the guarded 64x64 tile at 5000 x 5000): a guarded launch, the same bits as one workgroup per
+    128x128 tile and as the oracle; and with K = 16384 (B beyond the Infinity Cache) the 256x256 tile."""
     import torch
     import how_to_optimize_gemm_amd as H
-    for (m, n, k, expect) in [(4000, 4000, 40, "sgemm_mfma_kernel<256,256>"), (5000, 5000, 72, "sgemm_mfma_dma_kernel<64,64>")]:
+    for (m, n, k) in [(4000, 4000, 40), (5000, 5000, 72), (4000, 4000, 1000)]:
         a, b = oracle.harness_inputs(m, n, k, seed=m + k)
         da, db = dev(a), dev(b)
         mm.set_kernel("auto")
         got = mm.matmul(da, db)
-        assert expect in H.last_launch() and "guarded" in H.last_launch(), H.last_launch()
+        assert "guarded" in H.last_launch(), H.last_launch()
         assert mm.streamk_timeouts() == 0
         mm.set_kernel("mfma_tiles")
         assert torch.equal(got, mm.matmul(da, db))
         assert np.array_equal(got.cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
     mm.set_kernel("auto")
+    x = torch.rand((512, 16384), device="cuda")
+    y = torch.rand((16384, 4096), device="cuda")
+    mm.matmul(x, y)
+    assert "sgemm_mfma_kernel<256,256>" in H.last_launch() or "mfma_streamk_kernel<256,256>" in H.last_launch(), H.last_launch()
 
 
 @pytest.mark.parametrize("kernel", ["mfma", "mfma_256x256", "mfma_128x64", "mfma_64x64", "valu"])

@@ -17,6 +17,13 @@ if has tests; then
   ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $OUT/pytest_gpu.log 2>&1
   tail -5 $OUT/pytest_gpu.log
 fi
+if has hsweep; then     # the reference harness over the square sweep: auto (sustained), both vendor libraries, REF=skip (fast)
+  H=how-to-optimize-gemm_amd/harness
+  for kk in ${HSWEEP_KERNELS:-auto rocblas hipblaslt}; do
+    ( cd $H && echo "version = 'MMult_hip_${kk}';" > ../../$OUT/hsweep_${kk}.m && env KERNEL=$kk REF=skip WARMUP_MS=50 TRIALS=3 timeout 600 ./test_MMult.x >> ../../$OUT/hsweep_${kk}.m ) 2> $OUT/hsweep_${kk}.err
+  done
+  paste <(awk 'NF==3 && $1+0>0{print $1, $2}' $OUT/hsweep_auto.m) <(awk 'NF==3 && $1+0>0{print $2}' $OUT/hsweep_rocblas.m) <(awk 'NF==3 && $1+0>0{print $2}' $OUT/hsweep_hipblaslt.m)
+fi
 if has sweep; then      # every tile family forced, plain and stream-K, over the reference sweep
   timeout 900 python tools/tile_sweep.py --check ${SWEEP_ARGS:-} --out $OUT/tile_sweep${SWEEP_TAG:-} > $OUT/tile_sweep${SWEEP_TAG:-}.log 2>&1
   tail -30 $OUT/tile_sweep${SWEEP_TAG:-}.log | cut -c1-400
@@ -100,6 +107,14 @@ if has dataset; then    # every (tile family, launch form) forced over the fit /
       --out $OUT/dataset_$which > $OUT/dataset_$which.log 2>&1
     tail -2 $OUT/dataset_$which.log | cut -c1-300
   done
+fi
+if has ab3; then        # deferred publish and raster group height, A/B in one process (tools build)
+  timeout 300 python tools/tile_sweep.py --ab --check --rounds 5 --shapes "2176,2176,2176;2304,2304,2304;2432,2432,2432;2560,2560,2560;2816,2816,2816;3200,3200,3200;3584,3584,3584;3968,3968,3968" \
+    --variants "mfma_128x128_dma5/sk2,mfma_128x128_dma5/sk2/nd,mfma_128x128_dma5/sk2/g8,mfma_128x128_dma5/sk2/nd/g8,mfma_128x64_dma5/sk2,mfma_128x64_dma5/sk2/g8,mfma_128x64_dma5/sk2/nd/g8" \
+    --out $OUT/ab3_mid > $OUT/ab3_mid.log 2>&1; tail -9 $OUT/ab3_mid.log | cut -c1-500
+  timeout 300 python tools/tile_sweep.py --ab --check --rounds 5 --shapes "1152,1152,1152;1280,1280,1280;1664,1664,1664;1792,1792,1792;1920,1920,1920;2048,2048,2048;4096,4096,4096;3072,3072,3072" \
+    --variants "mfma_64x64_dma5/sk2,mfma_64x64_dma5/sk2/nd,mfma_128x64_dma5/sk2,mfma_128x64_dma5/sk2/nd,mfma_128x64_dma5/sk2/g8,mfma_128x64_dma5/sk0,mfma_128x64_dma5/sk0/g8,mfma_128x128_dma5/sk0,mfma_128x128_dma5/sk0/g8,mfma_64x64_dma5/sk0" \
+    --out $OUT/ab3_small > $OUT/ab3_small.log 2>&1; tail -9 $OUT/ab3_small.log | cut -c1-600
 fi
 if has edge2; then      # thin tiles: plain against persistent launches of the K2W tiles one element past a tile boundary
   timeout 300 python tools/tile_sweep.py --check --shapes "${EDGE_SHAPES:-1025,1025,1025;1040,1040,1040;1281,1281,1281;1409,1409,1409;1537,1537,1537;2049,2049,2049;2561,2561,2561;1024,1024,1024;1023,1023,1023;1100,1100,1100}" \

@@ -68,6 +68,10 @@ def main():
         mm.set_streamk(int(sk[0][2:]) if sk else 1)
         mm.set_option(H.OPT_STREAMK_CHAIN, 0 if "nc" in parts[1:] else 1)
         mm.set_option(H.OPT_PERSIST, 1 if "p1" in parts[1:] else 0)
+        if args.ab:      # tools build: /gN raster group height, /nd publish stream-K heads on the spot
+            gm = [x for x in parts[1:] if x.startswith("g") and x[1:].isdigit()]
+            mm.set_option(101, int(gm[0][1:]) if gm else 0)
+            mm.set_option(102, 1 if "nd" in parts[1:] else 0)
 
     for (m, n, k) in shapes:
         need = m * k + k * n + m * n
