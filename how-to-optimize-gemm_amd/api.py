@@ -31,6 +31,7 @@ OPT_SPLITK, OPT_HOST_PANELS, OPT_STREAMK_SPIN_LIMIT, OPT_FAULT_INJECT, OPT_STREA
 OPT_RIM = 11
 OPT_STREAMK_CHAIN = 12
 OPT_PERSIST = 13
+OPT_RIM5 = 14
 KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
            "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11, "mfma_256x256": 12,
@@ -674,6 +675,6 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
 
 __all__ = ["MMult", "ShardedMMult", "MMultError", "lib", "use_ab_library", "device_count", "rccl_version", "shard_rows",
            "kernel_name", "last_launch", "use_timeline_library", "streamk_plan", "auto_plan", "sgemm_sharded", "KERNELS", "CHAIN_KERNELS", "AB_LIB_PATH",
-           "OPT_SPLITK", "OPT_HOST_PANELS", "OPT_STREAMK_SPIN_LIMIT", "OPT_FAULT_INJECT", "OPT_STREAMK_ORDER", "OPT_DMA_EDGE", "OPT_STREAMK_DELEGATIONS", "OPT_RIM", "OPT_STREAMK_CHAIN", "OPT_PERSIST", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
+           "OPT_SPLITK", "OPT_HOST_PANELS", "OPT_STREAMK_SPIN_LIMIT", "OPT_FAULT_INJECT", "OPT_STREAMK_ORDER", "OPT_DMA_EDGE", "OPT_STREAMK_DELEGATIONS", "OPT_RIM", "OPT_STREAMK_CHAIN", "OPT_PERSIST", "OPT_RIM5", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
            "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OPT_IGEMM_MODE", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",
            "ERR_UNSUPPORTED", "ERR_ALLOC", "ERR_COMM"]

@@ -36,7 +36,7 @@ def _stale(target: str, srcs: list[str]) -> bool:
 def library_sources() -> list[str]:
     out = [os.path.join(REPO, "include", "mmult_hip.h")]
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".hpp", ".map")):
+        if f.endswith((".hip", ".hpp", ".inc", ".map")):
             out.append(os.path.join(CSRC, f))
     return out
 
@@ -50,7 +50,7 @@ def _build_shared(target: str, defines: list[str], objdir: str, force: bool, ver
     then link them into `target`.  Objects live under build/<objdir>/ (git-ignored) and are reused while
     neither their .hip nor any header has changed."""
     from concurrent.futures import ThreadPoolExecutor
-    headers = [s for s in library_sources() if s.endswith((".hpp", ".h"))]
+    headers = [s for s in library_sources() if s.endswith((".hpp", ".h", ".inc"))]
     odir = os.path.join(PKG_DIR, "build", objdir)
     os.makedirs(odir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + defines

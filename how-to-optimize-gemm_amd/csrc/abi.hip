@@ -148,6 +148,12 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       if (value < 0 || value > 1) return MMH_ERR_INVALID_ARG;
       h->persist = value;
       return MMH_OK;
+    case MMH_OPT_RIM5:   // (tools build: the fused rim; the product accepts "off" only)
+#ifndef MMH_AB_BUILD
+      if (value != 0) return MMH_ERR_INVALID_ARG;
+#endif
+      h->rim5 = value ? 1 : 0;
+      return MMH_OK;
 #ifdef MMH_AB_BUILD
     case 100:   // A/B: pin the residency of persistent launches by their LDS request (default on)
       h->pin = value ? 1 : 0;
@@ -188,6 +194,7 @@ int mmh_get_option(mmh_handle_t h, int option, int *value) {
     case MMH_OPT_RIM: *value = h->rim; return MMH_OK;
     case MMH_OPT_STREAMK_CHAIN: *value = h->sk_chain; return MMH_OK;
     case MMH_OPT_PERSIST: *value = h->persist; return MMH_OK;
+    case MMH_OPT_RIM5: *value = h->rim5; return MMH_OK;
     case MMH_OPT_STREAMK_TIMEOUTS: {
       // synchronises, then reads the sticky word: how many hand-off waits have timed out on this
       // handle since it was last cleared

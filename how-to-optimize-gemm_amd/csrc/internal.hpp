@@ -138,6 +138,7 @@ struct mmh_context {
   int dma_edge = 1;            // ragged / 4-byte-aligned shapes may run the guarded LDS-DMA tiles (MMH_OPT_DMA_EDGE)
   int dma_dword_rows = 1;      // ... including operands whose rows are only 4-byte aligned (odd lda / ldb / base)
   int sk_chain = 1;            // stream-K launches of the K2M tiles run a range's parts as one stream of slices (MMH_OPT_STREAMK_CHAIN)
+  int rim5 = 0;                // tools build only (MMH_OPT_RIM5): the RIM launch of the 64x64 K2W tile -- measured, it loses
   int ab_nodefer = 0;          // tools build only (option 102): stream-K heads publish on the spot (no deferred publish)
   int ab_group_m = 0;          // tools build only (option 101): raster group height of the plain K2W launch, 0 = GROUP_M
   int persist = 0;             // whole rounds of the persistent grid run persistent too (MMH_OPT_PERSIST)
@@ -226,6 +227,15 @@ int warm_dma(mmh_context *ctx, float *scratch, hipStream_t s);
 int launch_dma32(mmh_context *ctx, int kernel, const GemmArgs &g);
 bool dma32_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g);
 int warm_dma32(mmh_context *ctx, float *scratch, hipStream_t s);
+// The RIM launch of the 64x64 K2W tile (sgemm_dma5.hpp, rim_wave): m and / or n ONE element past a multiple of 64, at
+// least one whole tile each way.  *r_m / *r_n: rim rows / columns (0 or 1).
+inline bool dma5_rim_dims(int m, int n, int *r_m, int *r_n) {
+  const int rm = m % 64, rn = n % 64;
+  const int a = (rm == 1 && m > 64) ? 1 : 0, b = (rn == 1 && n > 64) ? 1 : 0;
+  if (r_m) *r_m = a;
+  if (r_n) *r_n = b;
+  return a > 0 || b > 0;
+}
 // launch_dma5.hip: tile = MMH_KERNEL_MFMA_*_DMA5 (sgemm_dma5.hpp); returns 1 when the shape does not qualify
 int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g);
 bool dma5_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g);

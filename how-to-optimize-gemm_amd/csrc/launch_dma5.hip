@@ -27,6 +27,38 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
   if (form < 0) return 1;
   const bool edge = form == 1;
   char what[256];
+#ifdef MMH_AB_BUILD
+  if constexpr (BM == 64 && BN == 64 && NL == 2 && SK) {
+    // The RIM launch (tools build: measured slower than the thin edge tiles, sgemm_dma5.hpp rim_wave): one row and / or column past a 64-boundary rides on the trimmed shape's tiles (rim_wave,
+    // sgemm_dma5.hpp) -- where the caller (MMH_KERNEL_AUTO's table, or the forced kernel's own rule on the TRIMMED
+    // tile count) wants one workgroup per tile.
+    int r_m = 0, r_n = 0;
+    if (ctx && ctx->rim5 && edge && dma5_rim_dims(g.m, g.n, &r_m, &r_n)) {
+      const int nbm0 = (g.m - r_m) / 64 + ((g.m - r_m) % 64 ? 1 : 0), nbn0 = (g.n - r_n) / 64 + ((g.n - r_n) % 64 ? 1 : 0);
+      const long tiles0 = (long)nbm0 * nbn0;
+      bool plain = g.form == 1;
+      if (g.form == 0) {
+        auto occ = sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true, NL, D>;
+        plain = !ctx->streamk || streamk_wanted(ctx, tiles0, BM, BN, resident_per_cu(ctx, occ, T::THREADS, T::LDS_BYTES)) == 0;
+      }
+      if (plain) {
+        using SR = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, false, true, false, NL, D, true>;
+        auto kern = sgemm_mfma_dma5_rim_kernel<BM, BN, KB, WTM, WTN, NBUF, NL, D>;
+        const int ok = allow_big_lds(kern, SR::RIM_LDS_BYTES);
+        if (ok != MMH_OK) return ok;
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles0), dim3(T::THREADS + 64), SR::RIM_LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda, g.B,
+                           g.ldb, g.C, g.ldc, g.acc, nbm0, nbn0, r_m, r_n);
+        HIP_TRY(hipGetLastError());
+        snprintf(what, sizeof what,
+                 "sgemm_mfma_dma5_rim_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by %d loader waves' LDS-DMA, guarded, "
+                 "%ld workgroups of %d threads on %d x %d + a rim wave for %d row(s), %d column(s) (vector ALU, out of the tiles' LDS)",
+                 BM, BN, 16 * WTM, 16 * WTN, KB, NBUF, NL, tiles0, T::THREADS + 64, g.m - r_m, g.n - r_n, r_m, r_n);
+        set_last_launch(what);
+        return MMH_OK;
+      }
+    }
+  }
+#endif
   GemmArgs ga = g;
 #ifdef MMH_AB_BUILD   // A/B switches ride in the upper bits of `accumulate` (sgemm_dma5.hpp)
   if (ctx) ga.acc |= (ctx->ab_nodefer ? 2 : 0) | ((ctx->ab_group_m & 0xff) << 8);
@@ -140,6 +172,16 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
 
 int warm_dma5(mmh_context *ctx, float *scratch, hipStream_t s) {
   int rc;
+#ifdef MMH_AB_BUILD
+  {   // the RIM launch of the 64x64 tile: one tile + its rim (65 x 65 x 32 on scratch)
+    using SR = Dma5Segment<64, 64, 32, 2, 2, 3, false, true, false, 2, 2, true>;
+    auto kern = sgemm_mfma_dma5_rim_kernel<64, 64, 32, 2, 2, 3, 2, 2>;
+    if ((rc = allow_big_lds(kern, SR::RIM_LDS_BYTES)) != MMH_OK) return rc;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(448), SR::RIM_LDS_BYTES, s, 65, 65, 32, scratch, 32, scratch, 68, scratch + 65536, 68, 0, 1, 1,
+                       1, 1);
+    HIP_TRY(hipGetLastError());
+  }
+#endif
   if ((rc = warm_dma5_tile<64, 64, 2, 2, 3, 2, 2>(ctx, scratch, s)) != MMH_OK) return rc;
   if ((rc = warm_dma5_tile<128, 64, 4, 2, 3, 4, 2>(ctx, scratch, s)) != MMH_OK) return rc;
   if ((rc = warm_dma5_tile<128, 128, 4, 4, 3, 4, 2>(ctx, scratch, s)) != MMH_OK) return rc;

@@ -40,19 +40,28 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
   const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
   const double nk = (double)((g.k + kSliceK - 1) / kSliceK);
   Plan best;
+  long tiles_rim = 0;
   for (const Family &f : kFamilies) {
     // B beyond the Infinity Cache (K > 8192 on the config-4 panels): the big tile -- the small tiles' two slices of
     // look-ahead no longer cover their misses there (2048 .. 16384 x 16384 x 16384: 140-148 against 149.7-149.9,
     // profiles/r03_shard_dryrun.md); outside the fitted range, kept as a rule
     if (g.k > 8192 && f.kernel != MMH_KERNEL_MFMA_256X256) continue;
     if (f.kernel != MMH_KERNEL_MFMA_256X256 && !dma5_shape_ok(ctx, f.kernel, g)) continue;
-    const long tiles = (long)((g.m + f.bm - 1) / f.bm) * ((g.n + f.bn - 1) / f.bn);
+    long tiles = (long)((g.m + f.bm - 1) / f.bm) * ((g.n + f.bn - 1) / f.bn);
+    {   // the 64x64 tile's RIM launch: one or two rows / columns past a 64-boundary cost no tiles of their own (plain only)
+      int r_m = 0, r_n = 0;
+      if (f.kernel == MMH_KERNEL_MFMA_64X64_DMA5 && ctx && ctx->rim5 && dma5_rim_dims(g.m, g.n, &r_m, &r_n))
+        tiles_rim = (long)((g.m - r_m + 63) / 64) * ((g.n - r_n + 63) / 64);
+      else
+        tiles_rim = 0;
+    }
+    if (tiles_rim) tiles = tiles_rim;
     const long cmax = (tiles + cus - 1) / cus;
     const int occ = (int)std::min<long>(cmax, f.w);
     double t = f.fix_p + (double)cmax * nk * f.s_p[occ - 1];
     if (cmax > f.w && tiles % ((long)f.w * cus) != 0) t *= MMH_POLICY_MULTIROUND_MARGIN;   // a ragged last round
     if (best.kernel < 0 || t < best.us) best = Plan{f.kernel, 1, t};
-    if (f.has_sk && (!ctx || ctx->streamk)) {
+    if (f.has_sk && (!ctx || ctx->streamk) && !tiles_rim) {
       int wp = 0;
       for (int c = f.w; c >= 1; --c)
         if (tiles >= (long)c * cus) { wp = c; break; }

@@ -461,7 +461,7 @@ def test_the_host_plan_is_what_the_device_launches(mm):
         b = torch.rand((k, n), device="cuda")
         mm.matmul(a, b)
         text = H.last_launch()
-        g = re.match(r"sgemm_(\w+)_kernel<(\d+,\d+)>", text)
+        g = re.match(r"sgemm_(\w+?)(?:_rim)?_kernel<(\d+,\d+)>", text)
         sk = re.search(r"(\d+) tiles on (\d+) persistent", text)
         got = (fam[(g.group(1), g.group(2))],) + ((int(sk.group(1)), int(sk.group(2))) if sk else
                                                    (int(re.search(r"(\d+) workgroups", text).group(1)), 0))

@@ -106,6 +106,57 @@ print("tools-build ok")
 """
 
 
+_RIM5 = _HEAD + r"""
+RIM5_SHAPES = [(1025, 1025, 1025), (1024, 1025, 300), (1025, 1024, 77), (1025, 1090, 64), (2049, 2049, 129), (1030, 1025, 511),
+               (65, 65, 40), (129, 64, 33), (64, 129, 31), (3073, 1025, 96), (257, 4097, 200), (1025, 1281, 257)]
+mm = H.MMult(0, "mfma_64x64_dma5")
+assert mm.get_option(H.OPT_RIM5) == 0
+rims = 0
+for i, (m, n, k) in enumerate(RIM5_SHAPES):
+    a, b = oracle.harness_inputs(m, n, k, seed=m + 7 * n + k)
+    lda, ldb, ldc = k + (i % 3), n + (i % 2) * 3, n + ((i + 1) % 2) * 5
+    abuf = torch.full((m * lda + 9,), float("nan"), device="cuda")
+    bbuf = torch.full(((k + 3) * ldb + 9,), float("nan"), device="cuda")
+    cbuf = torch.full((m * ldc + 9,), float("nan"), device="cuda")
+    off = i % 2
+    av = abuf[off:off + m * lda].view(m, lda)
+    bv = bbuf[off:off + k * ldb].view(k, ldb)
+    cv = cbuf[off:off + m * ldc].view(m, ldc)
+    av[:, :k] = dev(a)
+    bv[:, :n] = dev(b)
+    c0 = np.random.default_rng(i).uniform(-1, 1, (m, n)).astype(np.float32)
+    for accumulate in (False, True):
+        want = oracle.ref_mmult(a, b, c0.copy() if accumulate else None, fma=True)
+        for rim in (1, 0):
+            mm.set_option(H.OPT_RIM5, rim)
+            mm.set_streamk(0)
+            cv[:, :n] = dev(c0)
+            mm.sgemm(m, n, k, av.data_ptr(), lda, bv.data_ptr(), ldb, cv.data_ptr(), ldc, accumulate,
+                     torch.cuda.current_stream().cuda_stream)
+            launched = H.last_launch()
+            assert ("rim wave" in launched) == (rim == 1), launched
+            rims += "rim wave" in launched
+            got = cv[:, :n].cpu().numpy()
+            assert np.array_equal(got, want), (m, n, k, accumulate, rim, launched)
+            if ldc > n:
+                assert torch.isnan(cv[:, n:]).all(), (m, n, k)
+            assert torch.isnan(cbuf[:off]).all() and torch.isnan(cbuf[off + m * ldc:]).all()
+assert rims == 2 * len(RIM5_SHAPES), rims
+mm.close()
+print("tools-build ok")
+"""
+
+
+@pytest.mark.gpu
+@needs_ab
+def test_the_fused_rim_keeps_the_tiles_bits():
+    """MMH_OPT_RIM5 (sgemm_dma5.hpp, rim_wave; round 4, tools build): m and / or n ONE past a multiple of 64 run the
+    64x64 K2W tiles of the TRIMMED shape; the last tile row / column's workgroups compute the rim in an extra wave on the
+    vector ALU out of the K-slices in LDS.  Measured 2.2x slower per edge tile than a whole tile (the f32 MFMA runs on the
+    vector ALU's FMA lanes) -- not shipped; the bits are the oracle's all the same."""
+    _run(_RIM5)
+
+
 @pytest.mark.gpu
 @needs_ab
 def test_the_rim_runs_on_the_vector_alu_with_the_tiles_bits():
@@ -137,6 +188,9 @@ def test_the_product_library_refuses_the_tools_builds_switches(mm):
     with pytest.raises(H.MMultError):
         mm.set_option(H.OPT_RIM, 8)
     mm.set_option(H.OPT_RIM, 0)
+    with pytest.raises(H.MMultError):
+        mm.set_option(H.OPT_RIM5, 1)
+    mm.set_option(H.OPT_RIM5, 0)
     with pytest.raises(H.MMultError):
         mm.set_igemm_mode(7)
     mm.set_igemm_mode(0)

@@ -43,6 +43,9 @@ for sh in args.shape:
     thin_row = 1 if nbm > 1 and m - (nbm - 1) * bm <= 16 else 0
     thin_col = 1 if nbn > 1 and n - (nbn - 1) * bn <= 16 else 0
     n_full = (nbm - thin_row) * (nbn - thin_col)
+    if "rim wave" in H.last_launch():          # the RIM launch: the trimmed grid; report its last tile row / column apart
+        nbm, nbn = (m - m % bm) // bm if m % bm == 1 else nbm, (n - n % bn) // bn if n % bn == 1 else nbn
+        n_full = nbm * nbn
     stamps = torch.zeros((1 << 16, 4), device="cuda", dtype=torch.int64)
     assert L.mmh_ab_set_stamps5(mm._h, stamps.data_ptr()) == 0
     acc = []

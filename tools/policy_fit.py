@@ -32,6 +32,7 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CUS = 256
+RIM5 = False     # MMH_OPT_RIM5 (tools build; measured, it loses): the fused rim launch of the 64x64 tile
 # family: (kernel short name, BM, BN, co-resident workgroups per CU, has a stream-K form)
 FAMILIES = {
     "t64": ("mfma_64x64_dma5", 64, 64, 3, True),
@@ -42,8 +43,21 @@ FAMILIES = {
 }
 
 
+def rim_dims(m, n):
+    """csrc/internal.hpp dma5_rim_dims: rim rows / columns of the 64x64 tile's RIM launch (0, 0: none)."""
+    rm, rn = m % 64, n % 64
+    a = 1 if rm == 1 and m > 64 else 0
+    b = 1 if rn == 1 and n > 64 else 0
+    return a, b
+
+
 def geometry(fam, m, n, k, cus=CUS):
     _, bm, bn, w, has_sk = FAMILIES[fam]
+    rim = False
+    if fam == "t64" and RIM5:
+        a, b = rim_dims(m, n)
+        if a or b:        # the rim costs no tiles of its own, and runs as a plain launch only
+            m, n, rim, has_sk = m - a, n - b, True, False
     nbm, nbn = -(-m // bm), -(-n // bn)
     tiles = nbm * nbn
     nk = -(-k // 32)
