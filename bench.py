@@ -9,8 +9,9 @@ already resident in HBM (the reference excludes H2D/D2H from its timed region
 too: cuda/test_MMult.cpp:85-98,121).
 
   N = 1  workload = BASELINE.json configs[2]: fp32 N=4096 square SGEMM on the
-         MFMA kernel (MMH_KERNEL_AUTO picks the 128x64 LDS-DMA tile of it at this
-         size: 2048 tiles = four whole rounds of two workgroups per CU) -- the
+         MFMA kernel (MMH_KERNEL_AUTO's cost table picks the 128x64 K2W tile -- LDS-DMA
+         by loader waves -- at this size: 2048 tiles = four whole rounds of two
+         workgroups per CU, a plain launch) -- the
          configuration the headline metric ("% of MI355X fp32 MFMA peak at
          N=4096") is quoted on.
   N > 1  workload = configs[3]: fp32 N=16384, C row panels sharded over the N
@@ -571,6 +572,25 @@ def main():
                     extras["int8_4096_tops"] = round(2.0 * 4096 ** 3 / (e0.elapsed_time(e1) / 200 * 1e-3) / 1e12, 1)
                     extras["probe_mfma_i8_tops_constant_operands"] = round(mm.probe_mfma_i8_sustained(False, 50.0), 1)
                     extras["probe_mfma_i8_tops_random_operands"] = round(mm.probe_mfma_i8_sustained(True, 50.0), 1)
+                    # the same at 8192^3, and what the GEMM makes of the pipe as the pipe measures on random operands
+                    del qa, qb, qc
+                    qa = torch.randint(-127, 128, (8192, 8192), device=dev, dtype=torch.int8, generator=gq)
+                    qb = torch.randint(-127, 128, (8192, 8192), device=dev, dtype=torch.int8, generator=gq)
+                    qc = torch.empty((8192, 8192), device=dev, dtype=torch.int32)
+                    for _ in range(40):
+                        mm.igemm_s8(qa, qb, out=qc)
+                    e0.record()
+                    for _ in range(25):
+                        mm.igemm_s8(qa, qb, out=qc)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    extras["int8_8192_tops"] = round(2.0 * 8192 ** 3 / (e0.elapsed_time(e1) / 25 * 1e-3) / 1e12, 1)
+                    if extras["probe_mfma_i8_tops_random_operands"]:
+                        extras["int8_frac_of_measured_pipe"] = {
+                            "4096": round(extras["int8_4096_tops"] / extras["probe_mfma_i8_tops_random_operands"], 3),
+                            "8192": round(extras["int8_8192_tops"] / extras["probe_mfma_i8_tops_random_operands"], 3),
+                            "what": "int8 GEMM end to end / MFMA-only loop on random operands at the power-managed clock; parity unpinned"}
+                    del qa, qb, qc
                 except H.MMultError:
                     pass
             except Exception as e:   # extras are optional: never let them cost the run its JSON line

@@ -15,7 +15,7 @@ constexpr int kSliceK = 32;   // K-slice depth of the MFMA tiles (sgemm_tile.hpp
 // Every candidate -- a tile family as a plain launch or as a persistent stream-K launch -- is priced in microseconds
 // from what the shape makes of it, per CU:
 //     plain:     t = fix_p + cmax * nk * s_p[min(cmax, w)]      cmax = ceil(tiles / CUs): the tiles of the fullest CU
-//     stream-K:  t = fix_s + (tiles * nk / CUs) * s_s[w']       w'   = persistent workgroups per CU
+//     stream-K:  t = fix_s[w'] + (tiles * nk / CUs) * s_s[w']   w'   = persistent workgroups per CU
 // nk = ceil(k / 32) K-slices per tile, w the family's co-residency; s_x[o] is what a CU takes per tile-slice with o
 // tiles co-resident, fix_x everything that does not scale with K (launch, pipeline fill, C store, hand-over).  The
 // numbers are FITTED (tools/policy_fit.py, least squares in relative error) to a measured set of shapes x candidates
@@ -25,7 +25,7 @@ constexpr int kSliceK = 32;   // K-slice depth of the MFMA tiles (sgemm_tile.hpp
 // on 500 held-out shapes.  tools/calibrate_policy.sh regenerates the table on another box.
 struct Family {
   int kernel, bm, bn, w, has_sk;
-  float fix_p, s_p[3], fix_s, s_s[3];
+  float fix_p, s_p[3], fix_s[3], s_s[3];
 };
 #include "policy_table.inc"
 const Family kFamilies[] = {MMH_POLICY_FAMILIES};
@@ -66,7 +66,7 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
       for (int c = f.w; c >= 1; --c)
         if (tiles >= (long)c * cus) { wp = c; break; }
       if (wp > 0 && tiles % ((long)wp * cus) != 0 && tiles <= (1L << 24)) {
-        const double ts = f.fix_s + (double)tiles * nk / (double)cus * f.s_s[wp - 1];
+        const double ts = f.fix_s[wp - 1] + (double)tiles * nk / (double)cus * f.s_s[wp - 1];
         if (ts < best.us) best = Plan{f.kernel, 2, ts};
       }
     }

@@ -9,7 +9,7 @@ forced as a plain launch (/sk0) and as a persistent stream-K launch (/sk2).  The
 (csrc/policy.hip, the same arithmetic as predict() below):
 
     plain:     t = fix_p + cmax * nk * s_p[min(cmax, w)]          cmax = ceil(tiles / CUs): tiles on the fullest CU
-    stream-K:  t = fix_s + (tiles * nk / CUs) * s_s[w']           w' = persistent workgroups per CU
+    stream-K:  t = fix_s[w'] + (tiles * nk / CUs) * s_s[w']       w' = persistent workgroups per CU
 
 with nk = ceil(k / 32) K-slices per tile and w the family's co-residency; a plain launch of more than one round of
 workgroups whose last round is not full (cmax > w, tiles not a multiple of w CUs) is priced `margin` times its prediction -- the 90th percentile of measured / predicted over the fit
@@ -116,38 +116,43 @@ def compact(dataset):
 def fit(rows):
     table = {}
     for fam, (_, bm, bn, w, has_sk) in FAMILIES.items():
-        entry = {"bm": bm, "bn": bn, "w": w, "fix_p": 0.0, "s_p": [0.0] * 3, "fix_s": 0.0, "s_s": [0.0] * 3, "n_p": 0, "n_s": 0,
+        entry = {"bm": bm, "bn": bn, "w": w, "fix_p": 0.0, "s_p": [0.0] * 3, "fix_s": [0.0] * 3, "s_s": [0.0] * 3, "n_p": 0, "n_s": 0,
                  "rms_p": 0.0, "rms_s": 0.0}
         for form in ("plain", "sk"):
             sel = [(s, us) for (f, fo, s, us) in rows if f == fam and fo == form]
             if len(sel) < 4:
                 continue
+            # columns: fixed cost (plain: one; stream-K: one per w' -- the hand-over of a persistent workgroup costs more
+            # the more of them share a CU), then the per-tile-slice time per occupancy
             X, y = [], []
             for (m, n, k), us in sel:
                 g = geometry(fam, m, n, k)
-                feat = [1.0, 0.0, 0.0, 0.0]
+                feat = [0.0] * 6
                 if form == "plain":
-                    feat[g["occ"]] = g["cmax"] * g["nk"]
+                    feat[0] = 1.0
+                    feat[3 + g["occ"] - 1] = g["cmax"] * g["nk"]
                 else:
-                    feat[g["wp"]] = g["tiles"] * g["nk"] / CUS
+                    feat[g["wp"] - 1] = 1.0
+                    feat[3 + g["wp"] - 1] = g["tiles"] * g["nk"] / CUS
                 X.append([f / us for f in feat])      # relative error
                 y.append(1.0)
             X, y = np.array(X), np.array(y)
-            used = [j for j in range(4) if np.any(X[:, j] != 0)]
+            used = [j for j in range(6) if np.any(X[:, j] != 0)]
             sol, *_ = np.linalg.lstsq(X[:, used], y, rcond=None)
-            coef = [0.0] * 4
+            coef = [0.0] * 6
             for j, v in zip(used, sol):
                 coef[j] = max(float(v), 0.0)
             # occupancies never observed inherit the nearest observed one
-            for j in (1, 2, 3):
-                if coef[j] == 0.0:
-                    near = [coef[i] for i in (j - 1, j + 1, j - 2, j + 2) if 1 <= i <= 3 and coef[i] > 0]
-                    coef[j] = near[0] if near else 0.0
+            for lo in (0, 3):
+                for j in range(lo, lo + 3):
+                    if coef[j] == 0.0 and not (lo == 0 and form == "plain"):
+                        near = [coef[i] for i in (j - 1, j + 1, j - 2, j + 2) if lo <= i < lo + 3 and coef[i] > 0]
+                        coef[j] = near[0] if near else 0.0
             res = X @ np.array(coef) - y
             if form == "plain":
-                entry.update(fix_p=coef[0], s_p=coef[1:], n_p=len(sel), rms_p=float(np.sqrt(np.mean(res ** 2))))
+                entry.update(fix_p=coef[0], s_p=coef[3:], n_p=len(sel), rms_p=float(np.sqrt(np.mean(res ** 2))))
             else:
-                entry.update(fix_s=coef[0], s_s=coef[1:], n_s=len(sel), rms_s=float(np.sqrt(np.mean(res ** 2))))
+                entry.update(fix_s=coef[:3], s_s=coef[3:], n_s=len(sel), rms_s=float(np.sqrt(np.mean(res ** 2))))
         table[fam] = entry
     # multi-round plain launches: their residuals are one-sided (the tail of the last round) -- price them at the 90th
     # percentile of measured / predicted
@@ -169,7 +174,7 @@ def predict(table, fam, form, m, n, k, cus=CUS):
         return t * table.get("_margin", 1.0) if g["cmax"] > g["w"] and g["tiles"] % (g["w"] * cus) != 0 else t
     if not g["sk_possible"] or e["n_s"] == 0:
         return math.inf
-    return e["fix_s"] + g["tiles"] * g["nk"] / cus * e["s_s"][g["wp"] - 1]
+    return e["fix_s"][g["wp"] - 1] + g["tiles"] * g["nk"] / cus * e["s_s"][g["wp"] - 1]
 
 
 def choose(table, m, n, k, cus=CUS):
@@ -214,7 +219,7 @@ def emit(table, path, source):
     with open(path, "w") as f:
         f.write("// policy_table.inc -- GENERATED by tools/policy_fit.py from " + source + "; do not edit by hand.\n")
         f.write("// Per tile family: co-residency w, then microseconds: plain launches t = fix_p + cmax * nk * s_p[min(cmax, w) - 1],\n")
-        f.write("// persistent stream-K launches t = fix_s + tiles * nk / CUs * s_s[w' - 1] (tools/policy_fit.py has the derivation;\n")
+        f.write("// persistent stream-K launches t = fix_s[w' - 1] + tiles * nk / CUs * s_s[w' - 1] (tools/policy_fit.py has the derivation;\n")
         f.write("// rows / rms relative residual of each fit behind it).\n")
         fams = {k: v for k, v in table.items() if not k.startswith("_")}
         for fam, e in fams.items():
@@ -226,7 +231,8 @@ def emit(table, path, source):
                     "t96": "MMH_KERNEL_MFMA_96X96_DMA5", "t256": "MMH_KERNEL_MFMA_256X256"}[fam]
             sp = ", ".join(f"{v:.6f}f" for v in e["s_p"])
             ss = ", ".join(f"{v:.6f}f" for v in e["s_s"])
-            f.write(f"  {{{kern}, {e['bm']}, {e['bn']}, {e['w']}, {1 if e['n_s'] else 0}, {e['fix_p']:.4f}f, {{{sp}}}, {e['fix_s']:.4f}f, {{{ss}}}}}, \\\n")
+            fs = ", ".join(f"{v:.4f}f" for v in e["fix_s"])
+            f.write(f"  {{{kern}, {e['bm']}, {e['bn']}, {e['w']}, {1 if e['n_s'] else 0}, {e['fix_p']:.4f}f, {{{sp}}}, {{{fs}}}, {{{ss}}}}}, \\\n")
         f.write("\n")
 
 
@@ -258,8 +264,9 @@ def main():
         rs = np.array([x["regret"] for x in rg])
         old = np.array([1.0 - (x["old_auto"] or 0.0) / x["best"] for x in rg])
         summary = (f"{label}: {len(rg)} shapes; regret of the table's choice against the best measured candidate: mean {rs.mean() * 100:.2f} %, "
-                   f"p90 {np.percentile(rs, 90) * 100:.2f} %, max {rs.max() * 100:.2f} %; the round-3 rules on the same rows (old `auto` column): "
-                   f"mean {old.mean() * 100:.2f} %, max {old.max() * 100:.2f} %")
+                   f"p90 {np.percentile(rs, 90) * 100:.2f} %, max {rs.max() * 100:.2f} %; the `auto` column of the same pass (MMH_KERNEL_AUTO as the library "
+                   f"stood when the set was measured -- round 3's rules in the first pass of round 4, the previous table in the second; it "
+                   f"carries its own measurement noise): mean {old.mean() * 100:.2f} %, max {old.max() * 100:.2f} %")
         print(summary)
         lines.append(summary)
         worst = sorted(rg, key=lambda x: -x["regret"])[:12]
