@@ -281,7 +281,11 @@ const char *mmh_kernel_name(int kernel) {
     case 58: return "abl32_64x64_no_a_reads";
     case 59: return "abl32_64x64_mfma_only";
     case 64: return "exp5_64x64_l1d2";
+    case 65: return "exp5_64x64_ring6";
+    case 66: return "exp5_64x64_ring4";
+    case 67: return "exp5_64x64_ring6_l4";
     case 68: return "exp5_128x64_l1d2";
+    case 69: return "exp5_128x64_ring4";
     case 72: return "exp5_128x128_l1d2";
     case 79: return "exp5_160x96_l1d2";
     case 80: return "exp5_160x160_l1d2";

@@ -94,6 +94,7 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB,
     grid = streamk_wanted(ctx, tiles, BM, BN, per_cu);
     if (grid == 0) return 1;
   }
+  if (tiles * (long)((g.k + KB - 1) / KB) >= (1L << 31)) return 1;   // the kernels split tiles x K-slices in 32-bit arithmetic
   int *flags = nullptr;
   float *parts = nullptr;   // one partial-tile slot per range
   int rc = workspace_for(ctx, g.s, tiles, (size_t)grid * BM * BN * sizeof(float), &flags, &parts);

@@ -159,7 +159,12 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
     // A/B (valid results): ONE loader wave (round 4's first form), and the 160-wide whole-round tiles that lost to the
     // chained stream-K launch of the 128-wide ones (N = 2560: 140.8 against 145.2; N = 1920 on 160x96: 130.9 against 137.5)
     case 64: return launch_dma5_tile<64, 64, 2, 2, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    // ring depth: one 64x64 workgroup per CU runs 0.43 us slices -- two slices of look-ahead are less than a DMA's latency
+    case 65: return launch_dma5_tile<64, 64, 2, 2, 6, 2, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 66: return launch_dma5_tile<64, 64, 2, 2, 4, 2, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 67: return launch_dma5_tile<64, 64, 2, 2, 6, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 68: return launch_dma5_tile<128, 64, 4, 2, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 69: return launch_dma5_tile<128, 64, 4, 2, 4, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 72: return launch_dma5_tile<128, 128, 4, 4, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 79: return launch_dma5_tile<160, 96, 5, 3, 3, 1, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 80: return launch_dma5_tile<160, 160, 5, 5, 3, 1, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
@@ -195,6 +200,13 @@ extern "C" int mmh_ab_set_stamps5(mmh_handle_t h, void *stamps) {
   if (!h) return MMH_ERR_INVALID_ARG;
   ENTER(h);
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dma_stamps), &stamps, sizeof(void *)));
+  return MMH_OK;
+}
+// 4 = the plain kernels' layout; 32 = the stream-K kernels' (sgemm_dma5.hpp, streamk5_body; tools/sk_timeline.py)
+extern "C" int mmh_ab_set_stamp_stride5(mmh_handle_t h, int stride) {
+  if (!h || (stride != 4 && stride != 32)) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dma_stamp_stride), &stride, sizeof(int)));
   return MMH_OK;
 }
 #endif

@@ -26,6 +26,8 @@ constexpr int kSliceK = 32;   // K-slice depth of the MFMA tiles (sgemm_tile.hpp
 struct Family {
   int kernel, bm, bn, w, has_sk;
   float fix_p, s_p[3], fix_s[3], s_s[3];
+  float fix_p_whole, fix_s_whole[3];   // the fixed costs of the whole-tile instantiation (no guards: fast_shape)
+  float tile_p[3], tile_s[3];          // per tile (on the fullest CU / per CU's share), by occupancy: pipeline fill, C store
 };
 #include "policy_table.inc"
 const Family kFamilies[] = {MMH_POLICY_FAMILIES};
@@ -58,7 +60,8 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
     if (tiles_rim) tiles = tiles_rim;
     const long cmax = (tiles + cus - 1) / cus;
     const int occ = (int)std::min<long>(cmax, f.w);
-    double t = f.fix_p + (double)cmax * nk * f.s_p[occ - 1];
+    const bool whole = fast_shape(f.bm, f.bn, kSliceK, g);
+    double t = (whole ? f.fix_p_whole : f.fix_p) + (double)cmax * (nk * f.s_p[occ - 1] + f.tile_p[occ - 1]);
     if (cmax > f.w && tiles % ((long)f.w * cus) != 0) t *= MMH_POLICY_MULTIROUND_MARGIN;   // a ragged last round
     if (best.kernel < 0 || t < best.us) best = Plan{f.kernel, 1, t};
     if (f.has_sk && (!ctx || ctx->streamk) && !tiles_rim) {
@@ -66,7 +69,8 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
       for (int c = f.w; c >= 1; --c)
         if (tiles >= (long)c * cus) { wp = c; break; }
       if (wp > 0 && tiles % ((long)wp * cus) != 0 && tiles <= (1L << 24)) {
-        const double ts = f.fix_s[wp - 1] + (double)tiles * nk / (double)cus * f.s_s[wp - 1];
+        const double ts = (whole ? f.fix_s_whole[wp - 1] : f.fix_s[wp - 1]) +
+                          (double)tiles / (double)cus * (nk * f.s_s[wp - 1] + f.tile_s[wp - 1]);
         if (ts < best.us) best = Plan{f.kernel, 2, ts};
       }
     }
@@ -223,7 +227,7 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return launch_dma(ctx, kernel, g);
     case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59:
       return launch_dma32(ctx, kernel, g);
-    case 64: case 68: case 72: case 79: case 80:
+    case 64: case 65: case 66: case 67: case 68: case 69: case 72: case 79: case 80:
       return launch_dma5(ctx, kernel, g);
 #endif
     default:

@@ -71,9 +71,14 @@ namespace mmh {
 // have completed.
 #ifdef MMH_DMA_TIMELINE
 __device__ unsigned long long *g_dma_stamps = nullptr;
-__device__ __forceinline__ void dma_stamp(int i) {
-  if (g_dma_stamps && threadIdx.x == 0) g_dma_stamps[(size_t)blockIdx.x * 4 + i] = wall_clock64();
+__device__ int g_dma_stamp_stride = 4;   // 32: the stream-K layout (tools/sk_timeline.py), four slots per part of a range
+__device__ __forceinline__ void dma_stamp_value(int i, unsigned long long v) {
+  if (g_dma_stamps && threadIdx.x == 0) {
+    const int stride = g_dma_stamp_stride;
+    g_dma_stamps[(size_t)blockIdx.x * stride + i] = v;
+  }
 }
+__device__ __forceinline__ void dma_stamp(int i) { dma_stamp_value(i, wall_clock64()); }
 __device__ __forceinline__ void dma_stamp_after_stores(int i) {
   if (g_dma_stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -83,6 +88,7 @@ __device__ __forceinline__ void dma_stamp_after_stores(int i) {
 #else
 __device__ __forceinline__ void dma_stamp(int) {}
 __device__ __forceinline__ void dma_stamp_after_stores(int) {}
+__device__ __forceinline__ void dma_stamp_value(int, unsigned long long) {}
 #endif
 
 // One 1 KiB LDS-DMA piece: lane L's 16 bytes land at dst + 16 L.  (A static member of a class, like

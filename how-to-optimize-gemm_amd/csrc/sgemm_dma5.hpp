@@ -142,6 +142,7 @@ struct Dma5Segment {
   struct Lane {
     int wave, wm, wn, li, kq, ld;
     bool loader, rim;
+    int stamp_base = 0;   // timeline build: the stream-K body moves it from part to part
     int a_off[8], b_off[BBLK ? WTN : 1];
     uint32_t voff_a, voff_b[T::PB];
     __device__ __forceinline__ void init(int lda, int ldb) {
@@ -507,7 +508,7 @@ struct Dma5Segment {
         frag_b(lds, d_c, fr.b[d]);
       });
     }
-    dma_stamp(1);
+    dma_stamp(L.stamp_base + 1);
 
     // One K-slice out of ring buffer `buf` (K2L's slice body without its DMA pieces): per k-step the fragment reads
     // for k-step ks + D (all of them, thin or not: the next segment of a chain may be a whole tile), then the MFMAs of
@@ -613,7 +614,7 @@ struct Dma5Segment {
         for (int t = 0; t < WTM; ++t) asm volatile("" ::"v"(fr.a[i][t]));
       }
     }
-    dma_stamp(2);
+    dma_stamp(L.stamp_base + 2);
     if constexpr (THIN) __builtin_amdgcn_s_setprio(0);
 
     auto out_vec = [&](int t, int r) {
@@ -788,11 +789,16 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
   // (readfirstlane: what is loaded from memory or passed through LDS is workgroup-uniform, but hipcc cannot know -- and a
   // descriptor, LDS address or slice offset it takes for lane-dependent puts every LDS-DMA instruction into a waterfall loop)
   const int q = __builtin_amdgcn_readfirstlane(order ? order[rho] : rho);
-  const long long total = (long long)Tn * nk;
-  const long long u0 = total * q / G, u1 = total * (q + 1) / G;
+  // range q of G over Tn x nk slices: [total q / G, total (q + 1) / G) -- in 32-bit arithmetic (the launcher keeps
+  // total < 2^31: launch_streamk): total q / G = (total / G) q + ((total % G) q) / G, and (total % G) q < G^2.  (The
+  // 64-bit divisions this replaces were a microsecond of scalar code in front of every workgroup's first DMA.)
+  const unsigned total = (unsigned)Tn * (unsigned)nk;
+  const unsigned per = total / (unsigned)G, rem = total % (unsigned)G;
+  const unsigned u0 = per * (unsigned)q + rem * (unsigned)q / (unsigned)G;
+  const unsigned u1 = per * (unsigned)(q + 1) + rem * (unsigned)(q + 1) / (unsigned)G;
   if (u1 <= u0) return;
-  const int t_first = (int)(u0 / nk), k_first = (int)(u0 % nk);
-  const int t_last = (int)((u1 - 1) / nk), k_last_end = (int)(u1 - (long long)t_last * nk);
+  const int t_first = (int)(u0 / (unsigned)nk), k_first = (int)(u0 - (unsigned)t_first * (unsigned)nk);
+  const int t_last = (int)((u1 - 1) / (unsigned)nk), k_last_end = (int)(u1 - (unsigned)t_last * (unsigned)nk);
   auto tile_of = [&](int t, int &tm, int &tn) {   // grouped raster, no XCD remap (the ranges are XCD-contiguous)
     const int tt = __builtin_amdgcn_readfirstlane(place ? place[t] : t);
     const int per_group = GMr * nbn;
@@ -825,6 +831,19 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
     return p;
   };
   float *my_slot = parts + (size_t)q * BM * BN;
+#ifdef MMH_DMA_TIMELINE   // tools/sk_timeline.py: slot 0 entry, 1 exit, 2 part count | kinds, 3 part lengths, 4 + 4 s ... part s
+  dma_stamp(0);
+  {
+    unsigned long long kinds = (unsigned long long)n_parts, lens = 0;
+    for (int s = 0; s < n_parts && s < 7; ++s) {
+      const Part p = part_at(s);
+      kinds |= (unsigned long long)p.kind << (8 + 2 * s);
+      lens |= (unsigned long long)min(p.ke - p.kb, 255) << (8 * s);
+    }
+    dma_stamp_value(2, kinds);
+    dma_stamp_value(3, lens);
+  }
+#endif
   typename S::Lane L;
   L.init(lda, ldb);
   typename S::Frags fr;
@@ -871,6 +890,10 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
       }
     }
     const float *part_in = nullptr;
+#ifdef MMH_DMA_TIMELINE
+    L.stamp_base = 4 + 4 * min(s, 6);
+    dma_stamp(L.stamp_base);
+#endif
     if (p.kind == TAIL) {
       int seen = SK_EMPTY;
       if (threadIdx.x == 0) {
@@ -938,7 +961,13 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
         publish_now();
       }
     }
+#ifdef MMH_DMA_TIMELINE
+    dma_stamp(L.stamp_base + 3);
+#endif
   }
+#ifdef MMH_DMA_TIMELINE
+  dma_stamp_after_stores(1);
+#endif
 }
 
 // CHAINED = false: every part of a range starts with an empty pipeline (the A/B baseline, tools build)

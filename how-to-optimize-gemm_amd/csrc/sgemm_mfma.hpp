@@ -599,12 +599,14 @@ __device__ __forceinline__ void streamk_body(float *lds, int m, int n, int k, co
   // rate of a stream-K launch is 22-35 % instead of 80 % (profiles/r02_streamk_l2.md).
   const int rho = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + local;
   const int q = order ? order[rho] : rho;
-  const long long total = (long long)T * nk;
-  auto range_start = [&](int r) { return total * r / G; };
-  const long long u0 = range_start(q), u1 = range_start(q + 1);
+  // 32-bit arithmetic (launch_streamk keeps total < 2^31): total r / G = (total / G) r + ((total % G) r) / G
+  const unsigned total = (unsigned)T * (unsigned)nk;
+  const unsigned per = total / (unsigned)G, rem = total % (unsigned)G;
+  auto range_start = [&](int r) { return per * (unsigned)r + rem * (unsigned)r / (unsigned)G; };
+  const unsigned u0 = range_start(q), u1 = range_start(q + 1);
   if (u1 <= u0) return;
-  const int t_first = (int)(u0 / nk), k_first = (int)(u0 % nk);
-  const int t_last = (int)((u1 - 1) / nk), k_last_end = (int)(u1 - (long long)t_last * nk);
+  const int t_first = (int)(u0 / (unsigned)nk), k_first = (int)(u0 - (unsigned)t_first * (unsigned)nk);
+  const int t_last = (int)((u1 - 1) / (unsigned)nk), k_last_end = (int)(u1 - (unsigned)t_last * (unsigned)nk);
   auto tile_of = [&](int t, int &tm, int &tn) {   // grouped raster, no XCD remap (ranges are)
     const int per_group = GROUP_M * nbn;
     const int group = t / per_group, first_m = group * GROUP_M;

@@ -124,4 +124,10 @@ if has tl5; then        # per-workgroup timeline of plain K2W launches (thin til
   timeout 600 python tools/dma5_timeline.py --kernel ${TL_KERNEL:-mfma_64x64_dma5} --shape ${TL_SHAPES:-1025,1025,1025 1024,1024,1024 1040,1040,1040} > $OUT/tl5_${TL_KERNEL:-mfma_64x64_dma5}.txt 2>&1
   cat $OUT/tl5_${TL_KERNEL:-mfma_64x64_dma5}.txt | grep -v amdgpu.ids
 fi
+if has sktl; then       # per-workgroup, per-part timeline of stream-K K2W launches
+  for kern in ${SKTL_KERNELS:-mfma_128x128_dma5 mfma_64x64_dma5}; do
+    timeout 600 python tools/sk_timeline.py --kernel $kern --shape ${SKTL_SHAPES:-2304,2304,2304 1152,1152,1152} > $OUT/sktl_$kern.txt 2>&1
+    grep -v amdgpu.ids $OUT/sktl_$kern.txt
+  done
+fi
 du -sh $OUT

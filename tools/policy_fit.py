@@ -8,14 +8,18 @@ The dataset (tools/tile_sweep.py over tools/policy_shapes_*.txt) holds, per shap
 forced as a plain launch (/sk0) and as a persistent stream-K launch (/sk2).  The model AUTO evaluates per candidate
 (csrc/policy.hip, the same arithmetic as predict() below):
 
-    plain:     t = fix_p + cmax * nk * s_p[min(cmax, w)]          cmax = ceil(tiles / CUs): tiles on the fullest CU
-    stream-K:  t = fix_s[w'] + (tiles * nk / CUs) * s_s[w']       w' = persistent workgroups per CU
+    plain:     t = fix_p + cmax * (nk * s_p[o] + tile_p[o])           cmax = ceil(tiles / CUs): tiles on the fullest CU, o = min(cmax, w)
+    stream-K:  t = fix_s[w'] + (tiles / CUs) * (nk * s_s[w'] + tile_s[w'])   w' = persistent workgroups per CU
 
-with nk = ceil(k / 32) K-slices per tile and w the family's co-residency; a plain launch of more than one round of
+with nk = ceil(k / 32) K-slices per tile and w the family's co-residency; fix_p and fix_s[w'] come in two flavours: the
+guarded instantiation's (any m, n, k) and the whole-tile one's (m, n multiples of the tile, k of 32, 16-byte rows:
+csrc/internal.hpp fast_shape) -- no bounds tests in front of the first DMA and around the C stores: 1-2 us less on a
+plain launch, 5-7 us less on a persistent one (N = 1152 / 1280: 8.5 us against the 13.4 of N = 1151 / 1279); a plain launch of more than one round of
 workgroups whose last round is not full (cmax > w, tiles not a multiple of w CUs) is priced `margin` times its prediction -- the 90th percentile of measured / predicted over the fit
 set's multi-round plain rows: which CU gets the last tiles, and when, is the dispatcher's business, and the residuals
 of those rows are one-sided.  s_x[o] is what a CU takes per tile-slice
-with o tiles co-resident, fix_x everything that does not scale with K (launch, pipeline fill, C store, hand-over).
+with o tiles co-resident, tile_x[o] what it takes per tile besides (pipeline fill, C store, a stream-K part's hand-over),
+fix_x what a launch costs whatever its size.
 All of it is per family, in microseconds, least squares in relative error over the fit set's rows of that family
 and form.  Everything is expressed per CU, so the table serves any CU count (partitioned devices).
 
@@ -68,7 +72,8 @@ def geometry(fam, m, n, k, cus=CUS):
             wp = cand
             break
     sk_possible = has_sk and wp > 0 and tiles % (wp * cus) != 0
-    return dict(tiles=tiles, nk=nk, cmax=cmax, occ=min(cmax, w), wp=wp, sk_possible=sk_possible, w=w)
+    whole = m % bm == 0 and n % bn == 0 and k % 32 == 0      # dense operands, 16-byte aligned bases (how the sets are measured)
+    return dict(tiles=tiles, nk=nk, cmax=cmax, occ=min(cmax, w), wp=wp, sk_possible=sk_possible, w=w, whole=whole)
 
 
 def rows_of(dataset):
@@ -116,43 +121,53 @@ def compact(dataset):
 def fit(rows):
     table = {}
     for fam, (_, bm, bn, w, has_sk) in FAMILIES.items():
-        entry = {"bm": bm, "bn": bn, "w": w, "fix_p": 0.0, "s_p": [0.0] * 3, "fix_s": [0.0] * 3, "s_s": [0.0] * 3, "n_p": 0, "n_s": 0,
-                 "rms_p": 0.0, "rms_s": 0.0}
+        entry = {"bm": bm, "bn": bn, "w": w, "fix_p": 0.0, "s_p": [0.0] * 3, "fix_s": [0.0] * 3, "s_s": [0.0] * 3,
+                 "fix_p_whole": 0.0, "fix_s_whole": [0.0] * 3, "tile_p": [0.0] * 3, "tile_s": [0.0] * 3,
+                 "n_p": 0, "n_s": 0, "rms_p": 0.0, "rms_s": 0.0}
         for form in ("plain", "sk"):
             sel = [(s, us) for (f, fo, s, us) in rows if f == fam and fo == form]
             if len(sel) < 4:
                 continue
-            # columns: fixed cost (plain: one; stream-K: one per w' -- the hand-over of a persistent workgroup costs more
-            # the more of them share a CU), then the per-tile-slice time per occupancy
+            # columns: fixed cost of the guarded instantiation (plain: one; stream-K: one per w' -- the hand-over of a
+            # persistent workgroup costs more the more of them share a CU), the same of the whole-tile instantiation,
+            # then the per-tile-slice time and the per-tile time per occupancy (shared by both instantiations)
             X, y = [], []
             for (m, n, k), us in sel:
                 g = geometry(fam, m, n, k)
-                feat = [0.0] * 6
+                feat = [0.0] * 12
+                lo = 3 if g["whole"] else 0
                 if form == "plain":
-                    feat[0] = 1.0
-                    feat[3 + g["occ"] - 1] = g["cmax"] * g["nk"]
+                    feat[lo] = 1.0
+                    feat[6 + g["occ"] - 1] = g["cmax"] * g["nk"]
+                    feat[9 + g["occ"] - 1] = g["cmax"]
                 else:
-                    feat[g["wp"] - 1] = 1.0
-                    feat[3 + g["wp"] - 1] = g["tiles"] * g["nk"] / CUS
+                    feat[lo + g["wp"] - 1] = 1.0
+                    feat[6 + g["wp"] - 1] = g["tiles"] * g["nk"] / CUS
+                    feat[9 + g["wp"] - 1] = g["tiles"] / CUS
                 X.append([f / us for f in feat])      # relative error
                 y.append(1.0)
             X, y = np.array(X), np.array(y)
-            used = [j for j in range(6) if np.any(X[:, j] != 0)]
+            used = [j for j in range(12) if np.any(X[:, j] != 0)]
             sol, *_ = np.linalg.lstsq(X[:, used], y, rcond=None)
-            coef = [0.0] * 6
+            coef = [0.0] * 12
             for j, v in zip(used, sol):
                 coef[j] = max(float(v), 0.0)
-            # occupancies never observed inherit the nearest observed one
-            for lo in (0, 3):
+            # occupancies never observed inherit the nearest observed one; a whole-tile cost never observed, the guarded one
+            for lo in (0, 3, 6, 9):
                 for j in range(lo, lo + 3):
-                    if coef[j] == 0.0 and not (lo == 0 and form == "plain"):
+                    if coef[j] == 0.0 and not (lo < 6 and form == "plain"):
                         near = [coef[i] for i in (j - 1, j + 1, j - 2, j + 2) if lo <= i < lo + 3 and coef[i] > 0]
                         coef[j] = near[0] if near else 0.0
+            for j in range(3):
+                if coef[3 + j] == 0.0:
+                    coef[3 + j] = coef[j]
             res = X @ np.array(coef) - y
             if form == "plain":
-                entry.update(fix_p=coef[0], s_p=coef[3:], n_p=len(sel), rms_p=float(np.sqrt(np.mean(res ** 2))))
+                entry.update(fix_p=coef[0], fix_p_whole=coef[3], s_p=coef[6:9], tile_p=coef[9:], n_p=len(sel),
+                             rms_p=float(np.sqrt(np.mean(res ** 2))))
             else:
-                entry.update(fix_s=coef[:3], s_s=coef[3:], n_s=len(sel), rms_s=float(np.sqrt(np.mean(res ** 2))))
+                entry.update(fix_s=coef[:3], fix_s_whole=coef[3:6], s_s=coef[6:9], tile_s=coef[9:], n_s=len(sel),
+                             rms_s=float(np.sqrt(np.mean(res ** 2))))
         table[fam] = entry
     # multi-round plain launches: their residuals are one-sided (the tail of the last round) -- price them at the 90th
     # percentile of measured / predicted
@@ -161,7 +176,8 @@ def fit(rows):
         g = geometry(f, m, n, k)
         if fo == "plain" and g["cmax"] > g["w"] and g["tiles"] % (g["w"] * CUS) != 0 and table[f]["n_p"]:
             e = table[f]
-            ratios.append(us / (e["fix_p"] + g["cmax"] * g["nk"] * e["s_p"][g["occ"] - 1]))
+            ratios.append(us / (e["fix_p_whole" if g["whole"] else "fix_p"] +
+                                g["cmax"] * (g["nk"] * e["s_p"][g["occ"] - 1] + e["tile_p"][g["occ"] - 1])))
     table["_margin"] = round(float(np.percentile(ratios, 90)), 3) if ratios else 1.0
     return table
 
@@ -170,11 +186,12 @@ def predict(table, fam, form, m, n, k, cus=CUS):
     e = table[fam]
     g = geometry(fam, m, n, k, cus)
     if form == "plain":
-        t = e["fix_p"] + g["cmax"] * g["nk"] * e["s_p"][g["occ"] - 1]
+        t = e["fix_p_whole" if g["whole"] else "fix_p"] + g["cmax"] * (g["nk"] * e["s_p"][g["occ"] - 1] + e["tile_p"][g["occ"] - 1])
         return t * table.get("_margin", 1.0) if g["cmax"] > g["w"] and g["tiles"] % (g["w"] * cus) != 0 else t
     if not g["sk_possible"] or e["n_s"] == 0:
         return math.inf
-    return e["fix_s"][g["wp"] - 1] + g["tiles"] * g["nk"] / cus * e["s_s"][g["wp"] - 1]
+    return (e["fix_s_whole" if g["whole"] else "fix_s"][g["wp"] - 1] +
+            g["tiles"] / cus * (g["nk"] * e["s_s"][g["wp"] - 1] + e["tile_s"][g["wp"] - 1]))
 
 
 def choose(table, m, n, k, cus=CUS):
@@ -218,9 +235,10 @@ def regret(table, dataset):
 def emit(table, path, source):
     with open(path, "w") as f:
         f.write("// policy_table.inc -- GENERATED by tools/policy_fit.py from " + source + "; do not edit by hand.\n")
-        f.write("// Per tile family: co-residency w, then microseconds: plain launches t = fix_p + cmax * nk * s_p[min(cmax, w) - 1],\n")
-        f.write("// persistent stream-K launches t = fix_s[w' - 1] + tiles * nk / CUs * s_s[w' - 1] (tools/policy_fit.py has the derivation;\n")
-        f.write("// rows / rms relative residual of each fit behind it).\n")
+        f.write("// Per tile family: co-residency w, then microseconds: plain launches t = fix_p + cmax * (nk * s_p[o] + tile_p[o]), o = min(cmax, w) - 1,\n")
+        f.write("// persistent stream-K launches t = fix_s[w' - 1] + tiles / CUs * (nk * s_s[w' - 1] + tile_s[w' - 1]) (tools/policy_fit.py has the derivation;\n")
+        f.write("// rows / rms relative residual of each fit behind it); then fix_p and fix_s of the whole-tile instantiation (shapes\n")
+        f.write("// csrc/internal.hpp fast_shape accepts for the family's tile), then tile_p and tile_s.\n")
         fams = {k: v for k, v in table.items() if not k.startswith("_")}
         for fam, e in fams.items():
             f.write(f"// {fam}: plain {e['n_p']} rows, rms {e['rms_p']:.3f}; stream-K {e['n_s']} rows, rms {e['rms_s']:.3f}\n")
@@ -232,7 +250,11 @@ def emit(table, path, source):
             sp = ", ".join(f"{v:.6f}f" for v in e["s_p"])
             ss = ", ".join(f"{v:.6f}f" for v in e["s_s"])
             fs = ", ".join(f"{v:.4f}f" for v in e["fix_s"])
-            f.write(f"  {{{kern}, {e['bm']}, {e['bn']}, {e['w']}, {1 if e['n_s'] else 0}, {e['fix_p']:.4f}f, {{{sp}}}, {{{fs}}}, {{{ss}}}}}, \\\n")
+            fw = ", ".join(f"{v:.4f}f" for v in e["fix_s_whole"])
+            tp = ", ".join(f"{v:.4f}f" for v in e["tile_p"])
+            ts = ", ".join(f"{v:.4f}f" for v in e["tile_s"])
+            f.write(f"  {{{kern}, {e['bm']}, {e['bn']}, {e['w']}, {1 if e['n_s'] else 0}, {e['fix_p']:.4f}f, {{{sp}}}, {{{fs}}}, {{{ss}}}, "
+                    f"{e['fix_p_whole']:.4f}f, {{{fw}}}, {{{tp}}}, {{{ts}}}}}, \\\n")
         f.write("\n")
 
 
