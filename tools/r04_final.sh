@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round-4 evidence pass (run ON THE GPU BOX from the repo root via gpurun).  Everything lands under gpurun_out/r04z/;
 # tools/r04_collect.py copies the summaries into profiles/.
-#   PARTS="tests sweeps nonsquare bench offgrid prof i8 shard misc"   (default: all)
+#   PARTS="tests sweeps nonsquare bench offgrid prof i8 shard misc regret sktl"   (default: all)
 set -u
 OUT=gpurun_out/r04z
 mkdir -p $OUT
 H=how-to-optimize-gemm_amd/harness
 export TMPDIR=/tmp
-PARTS=${PARTS:-"tests sweeps nonsquare bench offgrid prof i8 shard misc"}
+PARTS=${PARTS:-"tests sweeps nonsquare bench offgrid prof i8 shard misc regret sktl"}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 sweep() {   # name, extra env...
   local name=$1; shift
@@ -90,6 +90,8 @@ if has prof; then
   TAG=r04z/prof1152 KERNEL=auto BENCH_ARGS="--n 1152" PASSES="trace pmc1 pmc3 pmc4" bash tools/gpu_profile.sh > $OUT/prof1152.log 2>&1
   TAG=r04z/prof1024 KERNEL=auto BENCH_ARGS="--n 1024" PASSES="trace pmc1 pmc2" bash tools/gpu_profile.sh > $OUT/prof1024.log 2>&1
   TAG=r04z/prof1536 KERNEL=auto BENCH_ARGS="--n 1536" PASSES="trace pmc1 pmc2" bash tools/gpu_profile.sh > $OUT/prof1536.log 2>&1
+  TAG=r04z/prof_valu1024 KERNEL=valu BENCH_ARGS="--n 1024" PASSES="trace" bash tools/gpu_profile.sh > $OUT/prof_valu1024.log 2>&1
+  python tools/summarize_profile.py $OUT/prof_valu1024 "sgemm_valu_kernel" > $OUT/prof_valu1024_summary.json 2>> $OUT/prof_valu1024.log
   python tools/summarize_profile.py $OUT/prof4096 "sgemm_mfma_dma5_kernel" > $OUT/prof4096_summary.json 2>> $OUT/prof4096.log
   python tools/summarize_profile.py $OUT/prof2560 "sgemm_dma5_streamk_kernel" > $OUT/prof2560_summary.json 2>> $OUT/prof2560.log
   python tools/summarize_profile.py $OUT/prof1152 "sgemm_dma5_streamk_kernel" > $OUT/prof1152_summary.json 2>> $OUT/prof1152.log
@@ -105,6 +107,14 @@ fi
 if has misc; then
   timeout 200 python tools/create_time.py --runs 3 > $OUT/create_time.json 2>&1
   cat $OUT/create_time.json | tr -d '\n ' | cut -c1-400; echo
+fi
+if has regret; then   # the held-out shapes once more with the final table in the library: the `auto` column against the best forced candidate
+  TAG=r04z STEPS="dataset" DATASETS="heldout" bash tools/gpu_call.sh > $OUT/regret_pass.log 2>&1
+  python tools/policy_fit.py --fit profiles/r04_policy_dataset_fit.json --heldout $OUT/dataset_heldout.json 2>/dev/null | grep "^held-out" | cut -c1-600
+fi
+if has sktl; then     # where a persistent workgroup's time goes, part by part (timeline build)
+  TAG=r04z STEPS="sktl" SKTL_SHAPES="2304,2304,2304 2303,2303,2303 1152,1152,1152 1280,1280,1280" bash tools/gpu_call.sh > $OUT/sktl.log 2>&1
+  grep -c "part  kind" $OUT/sktl.log
 fi
 # keep what is merged back small: drop the raw per-dispatch CSVs, keep logs + summaries
 find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
