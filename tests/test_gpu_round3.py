@@ -346,8 +346,10 @@ def test_one_element_off_the_grid_is_not_a_cliff(mm, n0):
     ran the LDS-DMA tiles, everything else fell to kernels 25-35 % slower).  AUTO at N - 1 -- the same tile count, one
     ragged row / column of tiles, odd leading dimensions -- stays within 10 % of N.  N + 1 needs one more row AND column
     of tiles (6-13 % more tile work at these sizes): it must stay within 20 % of N wherever that does not also start
-    a new round of CUs (1025 does: 17 x 17 = 289 tiles of 64 x 64 for 256 CUs -- 80 TFLOP/s against hipBLASLt's 86 and
-    rocBLAS's 58 -- profiles/r03_offgrid_vs_vendor.md states that ceiling instead)."""
+    a new round of CUs.  1025 does (17 x 17 tiles of 64 x 64 for 256 CUs): round 4's thin edge tiles took it from 0.49 to
+    0.68 x N = 1024 (60 -> 83 TFLOP/s; hipBLASLt 86, rocBLAS 58) and it is held to 0.62 here; the rest is alignment, not
+    tiles -- rows of 1025 floats are only 4-byte aligned, every 16-byte DMA piece straddles two chunks, and 1024-wide data
+    with an odd leading dimension tops out at ~0.80 (profiles/r04_notes.md, r04_thin_tiles_edge.md)."""
     import torch
     mm.set_kernel("auto")
     rates = {}
@@ -362,8 +364,7 @@ def test_one_element_off_the_grid_is_not_a_cliff(mm, n0):
             best = min(best, ms)
         rates[n] = 2.0 * n ** 3 / (best * 1e-3) / 1e12
     assert rates[n0 - 1] >= 0.90 * rates[n0], rates
-    if n0 != 1024:
-        assert rates[n0 + 1] >= 0.80 * rates[n0], rates
+    assert rates[n0 + 1] >= (0.80 if n0 != 1024 else 0.62) * rates[n0], rates
     mm.set_kernel("mfma")
 
 

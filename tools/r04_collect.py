@@ -47,6 +47,56 @@ cp("prof1536_summary.json", "r04_sgemm1536_k2w96x96_rocprofv3.json")
 cp("i8_instr_ab.md", "r04_i8_instr_ab.md")
 cp("create_time.json", "r04_create_time.json")
 cp("pytest_gpu.log", "r04_pytest_gpu.log")
+cp("prof_valu1024_summary.json", "r04_sgemm1024_k1_valu64x64_rocprofv3.json")
+# the stream-K timeline (timeline build): both kernels' tables in one file
+parts = []
+for kern in ("mfma_128x128_dma5", "mfma_64x64_dma5"):
+    f = os.path.join(SRC, f"sktl_{kern}.txt")
+    if os.path.exists(f):
+        parts.append("".join(l for l in open(f) if "amdgpu.ids" not in l))
+if parts:
+    open(os.path.join(DST, "r04_sk_timeline.txt"), "w").write(
+        "# tools/sk_timeline.py (libmmult_hip_tl.so: the stamps cost ~0.5 us each, 4 per part; bursts of 150 launches):\n"
+        "# per part of a persistent workgroup's range -- HEAD (k from 0: done first, partial tile published), WHOLE tiles, TAIL\n"
+        "# (finishes the previous range's tile: done last) -- min/median/max over workgroups x launches, microseconds\n" + "\n".join(parts))
+    print("profiles/r04_sk_timeline.txt")
+# the held-out shapes measured once more with the final table in the library
+held = os.path.join(SRC, "dataset_heldout.json")
+if os.path.exists(held):
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import numpy as np
+    import policy_fit as P
+    table = P.fit(P.rows_of(json.load(open(os.path.join(DST, "r04_policy_dataset_fit.json")))))
+    rows = json.load(open(held))
+    same, ratio, reg_auto = 0, [], []
+    for r in rows:
+        (fam, form), _ = P.choose(table, r["m"], r["n"], r["k"])
+        la = r["launched"]["auto"]
+        ok = f"<{P.FAMILIES[fam][1]},{P.FAMILIES[fam][2]}>" in la and ("persistent" in la) == (form == "sk")
+        same += ok
+        forced = P.measured(r, fam, form)
+        if ok and forced:
+            ratio.append(r["auto"] / forced)
+        best = max(v for v in (P.measured(r, f, fo) for f in P.FAMILIES for fo in ("plain", "sk")) if v)
+        reg_auto.append(1.0 - r["auto"] / best)
+    rg = np.array([x["regret"] for x in P.regret(table, rows)])
+    worst = sorted(P.regret(table, rows), key=lambda x: -x["regret"])[:10]
+    with open(os.path.join(DST, "r04_auto_regret_confirmation_pass.md"), "w") as f:
+        f.write("# The 500 held-out shapes measured again with the FINAL table in the library (tools/r04_final.sh, part `regret`)\n\n"
+                "The table was fitted on profiles/r04_policy_dataset_fit.json; this pass (another gpurun call, another box)\n"
+                "took no part in it.\n\n"
+                f"* MMH_KERNEL_AUTO launched the tile family and launch form tools/policy_fit.py::choose names on **{same} of {len(rows)}** shapes\n"
+                "  (the launch strings of the `auto` column against the Python evaluation of the committed table).\n"
+                f"* Regret of those choices against the best FORCED candidate measured in this pass: **mean {rg.mean() * 100:.2f} %, "
+                f"p90 {np.percentile(rg, 90) * 100:.2f} %, max {rg.max() * 100:.2f} %**.\n"
+                f"* The `auto` column itself reads lower than the same kernel forced a few bursts later in the same rotation (median "
+                f"{np.median(ratio):.3f}, mean {np.mean(ratio):.3f} of it): `auto` is the first variant measured after every change of shape, and the\n"
+                "  dataset protocol warms each variant for 10 ms only -- taken at face value that column gives mean "
+                f"{np.mean(reg_auto) * 100:.2f} %, max {max(reg_auto) * 100:.2f} %; it measures the rotation, not the choice.\n\n"
+                "Worst ten choices:\n\n```\n" +
+                "\n".join(f"{x['shape']}: chose {x['chosen']} {x['tf']} TF, best {x['best_is'][0]}/{x['best_is'][1]} {x['best']} ({x['regret'] * 100:.1f} %)" for x in worst) +
+                "\n```\n")
+    print("profiles/r04_auto_regret_confirmation_pass.md")
 # pieces of the other calls of the round that the notes cite
 for src, dst in (("r04/exp1_small.md", "r04_k2w_variants_small.md"), ("r04/exp1_mid.md", "r04_k2w_variants_mid.md"),
                  ("r04/exp1_big.md", "r04_persistent_vs_plain.md"), ("r04/exp1_pmc.json", "r04_persistent_traffic.json"),
