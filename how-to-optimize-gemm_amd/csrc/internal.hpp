@@ -153,7 +153,7 @@ struct mmh_context {
     unsigned long stamp = 0;
     bool pinned = false;       // a captured graph points at buf: never evicted
     bool uploaded = false;
-    hipStream_t upload_stream = nullptr;   // the stream whose order the last upload sits in
+    std::vector<hipStream_t> upload_streams;   // the streams in whose order an upload of these bytes already sits
   };
   std::vector<SkTable *> sk_tables;
   unsigned long sk_stamp = 0;

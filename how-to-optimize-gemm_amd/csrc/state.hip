@@ -229,12 +229,18 @@ int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s,
     if (t->tiles == tiles && t->nk == nk && t->grid == grid && t->uploaded) {
       t->stamp = ++ctx->sk_stamp;
       if (cap) t->pinned = true;   // the entry must outlive the graph
-      if (cap || t->upload_stream != s) {
-        // a graph must carry its own upload (the eager one is not ordered against the replay), and a launch on
-        // another stream than the last upload's is not ordered behind that upload either: upload again, in THIS
-        // stream's order (the same bytes to the same place: harmless beside a launch that is reading them)
+      const bool seen = std::find(t->upload_streams.begin(), t->upload_streams.end(), s) != t->upload_streams.end();
+      if (cap || !seen) {
+        // a graph must carry its own upload (the eager one is not ordered against the replay), and a launch on a
+        // stream that has no upload of these tables in its own order is not ordered behind anybody else's either:
+        // upload again, in THIS stream's order (the same bytes to the same place: harmless beside a launch that is
+        // reading them).  Streams that have had theirs are remembered -- two streams alternating on one shape upload
+        // once each, not once per call (round 3 remembered the last stream only).
         HIP_TRY(hipMemcpyAsync(t->buf.p, t->host, ((size_t)grid + (size_t)tiles) * sizeof(int), hipMemcpyHostToDevice, s));
-        if (!cap) t->upload_stream = s;
+        if (!cap) {
+          if (t->upload_streams.size() >= 16) t->upload_streams.clear();   // (handle values get recycled: keep the list short)
+          t->upload_streams.push_back(s);
+        }
       }
       *order = static_cast<const int *>(t->buf.p);
       *place = *order + grid;
@@ -247,8 +253,15 @@ int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s,
   // entries pinned ones only make the cache grow
   mmh_context::SkTable *slot = nullptr;
   size_t unpinned = 0;
-  for (auto *t : ctx->sk_tables) unpinned += t->pinned ? 0 : 1;
-  if (unpinned < 32) {
+  for (auto *t : ctx->sk_tables) {
+    unpinned += t->pinned ? 0 : 1;
+    // an entry whose build failed (no pinned memory, a shape the builder declines) holds nothing and nobody reads it:
+    // it is the first to be reused -- round 3 left such entries in the list, counted against the 32
+    if (!t->pinned && !t->uploaded && !slot) slot = t;
+  }
+  if (slot) {
+    // reuse the dead entry as it is
+  } else if (unpinned < 32) {
     slot = new (std::nothrow) mmh_context::SkTable;
     if (!slot) return MMH_ERR_ALLOC;
     ctx->sk_tables.push_back(slot);
@@ -290,7 +303,8 @@ int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s,
   slot->grid = grid;
   slot->stamp = ++ctx->sk_stamp;
   slot->uploaded = true;
-  slot->upload_stream = cap ? nullptr : s;
+  slot->upload_streams.clear();
+  if (!cap) slot->upload_streams.push_back(s);
   slot->pinned = cap;
   *order = static_cast<const int *>(slot->buf.p);
   *place = *order + grid;
