@@ -44,10 +44,10 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
   Plan best;
   long tiles_rim = 0;
   for (const Family &f : kFamilies) {
-    // B beyond the Infinity Cache (K > 8192 on the config-4 panels): the big tile -- the small tiles' two slices of
-    // look-ahead no longer cover their misses there (2048 .. 16384 x 16384 x 16384: 140-148 against 149.7-149.9,
-    // profiles/r03_shard_dryrun.md); outside the fitted range, kept as a rule
-    if (g.k > 8192 && f.kernel != MMH_KERNEL_MFMA_256X256) continue;
+    // (Rounds 2-3 kept K > 8192 -- B beyond the Infinity Cache, the config-4 panels -- on the 256x256 tile: K2L's small tiles
+    // lost 1-6 % there.  K2W's do not: 2048 .. 4096 x 16384 x 16384 run 152.4-153.2 TFLOP/s on the 128x64 tile against
+    // 150.2-150.3, and 2048 x 4096 x 16384 -- half a round of 256x256 tiles -- 151.5 against 74.8: the fence is gone, the
+    // table decides; profiles/r04_big_k.md.)
     if (f.kernel != MMH_KERNEL_MFMA_256X256 && !dma5_shape_ok(ctx, f.kernel, g)) continue;
     long tiles = (long)((g.m + f.bm - 1) / f.bm) * ((g.n + f.bn - 1) / f.bn);
     {   // the 64x64 tile's RIM launch: one or two rows / columns past a 64-boundary cost no tiles of their own (plain only)

@@ -68,10 +68,11 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_ERR_COMM (-6)        /* RCCL call failed                             */
 
 /* kernel variants (the reference's "NEW := MMult_xxx" ladder, MI355X edition) */
-#define MMH_KERNEL_AUTO 0        /* 64x64 / 128x64 / 128x128 (LDS-DMA or register-staged) / 256x256 tiles chosen by how
-                                    the shape fills the chip */
-#define MMH_KERNEL_VALU 1        /* K1: LDS-tiled, VALU fma only: 128x128 tile (8x8 per thread) from one
-                                    tile per CU up, the 64x64 tile (4x4 per thread) below         */
+#define MMH_KERNEL_AUTO 0        /* the K2W tiles (64x64 / 96x96 / 128x64 / 128x128) or the 256x256 tile, plain or
+                                    stream-K: whichever a cost table fitted to measurements prices lowest for
+                                    the shape (csrc/policy.hip, mmh_auto_plan) */
+#define MMH_KERNEL_VALU 1        /* K1: LDS-tiled, VALU fma only: the 128x128 tile (8x8 per thread) or the 64x64 tile
+                                    (4x4 per thread), whichever has the cheaper rounds                  */
 #define MMH_KERNEL_VALU_128X128 13 /* K1 with the 128x128 tile always (the rung BASELINE config 2 names) */
 #define MMH_KERNEL_VALU_64X64 14   /* K1 with the 64x64 tile always                                      */
 #define MMH_KERNEL_MFMA 2        /* K2: 128x128 block tile on v_mfma_f32_16x16x4_f32; K-slice
@@ -91,9 +92,9 @@ typedef struct mmh_context *mmh_handle_t;
 /* K2L (sgemm_dma.hpp): tiles fed entirely by LDS-DMA (buffer_load ... lds for both operands, a ring of
  * three 32-deep K-slice buffers = 48 / 72 / 96 KiB, i.e. 3 / 2 / 1 workgroups per CU, counted vmcnt waits,
  * no registers -> LDS stores at all) -- the register-staged
- * packing stage is what bounds the small tiles.  Same chain, same bits; what MMH_KERNEL_AUTO runs on
- * whole-tile 16-byte-aligned shapes below one 256x256 tile per CU (stream-K for ragged tile counts);
- * anything else runs the register-staged kernel of the same tile. */
+ * packing stage is what bounds the small tiles.  Same chain, same bits; any shape and 4-byte alignment (guarded
+ * instantiations, round 3); what MMH_KERNEL_AUTO ran in round 3 -- since round 4 it runs K2W, these stay as forced
+ * kernels / ladder rungs. */
 #define MMH_KERNEL_MFMA_64X64_DMA 25
 #define MMH_KERNEL_MFMA_128X64_DMA 27
 #define MMH_KERNEL_MFMA_128X128_DMA 28

@@ -385,7 +385,8 @@ def test_auto_on_large_ragged_shapes_uses_the_big_tile_and_keeps_the_bits(mm, or
     """AUTO on large ragged shapes (whatever the cost table picks -- tests/test_auto_plan.py and
     test_the_host_plan_is_what_the_device_launches pin the choice; round 3's rules ran the guarded 256x256 tile at
     4000 x 4000 and the guarded 64x64 tile at 5000 x 5000): a guarded launch, the same bits as one workgroup per
-    128x128 tile and as the oracle; and with K = 16384 (B beyond the Infinity Cache) the 256x256 tile."""
+    128x128 tile and as the oracle; and with K = 16384 (B beyond the Infinity Cache: rounds 2-3 fenced that off for the
+    256x256 tile) whatever the table says, the bits of the 256x256 tile's launch."""
     import torch
     import how_to_optimize_gemm_amd as H
     for (m, n, k) in [(4000, 4000, 40), (5000, 5000, 72), (4000, 4000, 1000)]:
@@ -401,8 +402,12 @@ def test_auto_on_large_ragged_shapes_uses_the_big_tile_and_keeps_the_bits(mm, or
     mm.set_kernel("auto")
     x = torch.rand((512, 16384), device="cuda")
     y = torch.rand((16384, 4096), device="cuda")
-    mm.matmul(x, y)
-    assert "sgemm_mfma_kernel<256,256>" in H.last_launch() or "mfma_streamk_kernel<256,256>" in H.last_launch(), H.last_launch()
+    got = mm.matmul(x, y)
+    name, tiles, grid = H.auto_plan(512, 4096, 16384)
+    assert f"<{name.split('_')[1].replace('x', ',')}>" in H.last_launch(), (name, H.last_launch())
+    mm.set_kernel("mfma_256x256")
+    assert torch.equal(got, mm.matmul(x, y))
+    mm.set_kernel("auto")
 
 
 @pytest.mark.parametrize("kernel", ["mfma", "mfma_256x256", "mfma_128x64", "mfma_64x64", "valu"])

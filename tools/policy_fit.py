@@ -197,8 +197,6 @@ def predict(table, fam, form, m, n, k, cus=CUS):
 def choose(table, m, n, k, cus=CUS):
     best, best_t = None, math.inf
     for fam in FAMILIES:
-        if k > 8192 and fam != "t256":
-            continue          # B beyond the Infinity Cache: the big tile, not part of the fit
         for form in ("plain", "sk"):
             t = predict(table, fam, form, m, n, k, cus)
             if t < best_t:
