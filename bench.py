@@ -495,7 +495,7 @@ def main():
                 out["single_gpu_value"] = round(v1, 1)          # the whole problem on rank 0's GPU, same process group
                 out["single_gpu_ms"] = round(single_ms, 4)
                 out["scaling_efficiency"] = round(gflops / (world * v1), 4)
-            # what the committed one-GPU dry run (profiles/r03_shard_dryrun.md) predicts for this line: every rank's
+            # what the committed one-GPU dry run (profiles/r04_shard_dryrun.md) predicts for this line: every rank's
             # panel at the single-GPU rate, the broadcast at one xGMI link (153 GB/s) flat or over all links
             # (scatter + all-gather), the streamed form hiding all but one chunk of it
             link = 153e9

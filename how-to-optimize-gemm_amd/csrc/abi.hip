@@ -289,6 +289,8 @@ const char *mmh_kernel_name(int kernel) {
     case 72: return "exp5_128x128_l1d2";
     case 79: return "exp5_160x96_l1d2";
     case 80: return "exp5_160x160_l1d2";
+    case 81: return "exp5_160x160_l4";
+    case 82: return "exp5_160x160_l2";
 #endif
     default: return nullptr;
   }

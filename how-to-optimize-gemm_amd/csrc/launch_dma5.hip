@@ -168,6 +168,11 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
     case 72: return launch_dma5_tile<128, 128, 4, 4, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 79: return launch_dma5_tile<160, 96, 5, 3, 3, 1, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 80: return launch_dma5_tile<160, 160, 5, 5, 3, 1, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    // (the 160x160 tile's loss is not its one loader: 1 / 2 / 4 loaders at N = 2560 -- 256 tiles, one whole round -- 139.9 /
+    // 139.8 / 140.6 against the 128x128 tile's chained stream-K 144.6; four whole rounds at N = 5120: 143.9 against 150.2.
+    // Five column-blocked B fragments of single floats per k-step and 100 accumulator registers: the loop itself is slower.)
+    case 81: return launch_dma5_tile<160, 160, 5, 5, 3, 4, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 82: return launch_dma5_tile<160, 160, 5, 5, 3, 2, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
 #endif
     default:
       set_last_error("unknown kernel variant");

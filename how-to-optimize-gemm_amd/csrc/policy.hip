@@ -227,7 +227,7 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return launch_dma(ctx, kernel, g);
     case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59:
       return launch_dma32(ctx, kernel, g);
-    case 64: case 65: case 66: case 67: case 68: case 69: case 72: case 79: case 80:
+    case 64: case 65: case 66: case 67: case 68: case 69: case 72: case 79: case 80: case 81: case 82:
       return launch_dma5(ctx, kernel, g);
 #endif
     default:
