@@ -19,7 +19,9 @@ rng = np.random.default_rng(seed)
 mm = H.MMult(0)
 stream = torch.cuda.current_stream().cuda_stream
 VARIANTS = ["auto", "mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "mfma_pipe", "mfma_simple", "valu",
-            "valu_64x64", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma"]
+            "valu_64x64", "valu_128x128", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma",
+            "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5",          # K2W (round 4)
+            "mfma_64x64_dma5/sk2", "mfma_128x64_dma5/sk2", "mfma_128x128_dma5/sk2"]                  # ... stream-K whenever ragged
 
 
 def strided(rows, cols, ld, off, fill=None):
@@ -32,7 +34,7 @@ def strided(rows, cols, ld, off, fill=None):
 
 bad = 0
 for case in range(cases):
-    kind = rng.integers(0, 5)
+    kind = rng.integers(0, 7)
     aligned = kind == 4
     if kind == 4:      # whole tiles, 16-byte aligned bases and leading dimensions: what the LDS-DMA tiles take
         m, n = (int(rng.integers(1, 12)) * 128 for _ in range(2))
@@ -43,6 +45,12 @@ for case in range(cases):
         m, n, k = (int(rng.integers(1, 400)) for _ in range(3))
     elif kind == 2:    # ragged around tile edges
         m, n, k = (int(rng.integers(1, 6)) * 128 + int(rng.integers(-3, 4)) for _ in range(3))
+    elif kind == 5:    # a few rows / columns past a 64-boundary: the K2W kernels' thin edge tiles
+        m, n = (int(rng.integers(1, 20)) * 64 + int(rng.integers(0, 18)) for _ in range(2))
+        k = int(rng.integers(1, 900))
+    elif kind == 6:    # enough tiles for multi-part stream-K ranges, ragged
+        m, n = (int(rng.integers(1100, 2600)) for _ in range(2))
+        k = int(rng.integers(33, 700))
     else:              # thin
         m, n, k = int(rng.integers(1, 40)), int(rng.integers(1, 2000)), int(rng.integers(1, 1500))
     lda, ldb, ldc = k + int(rng.integers(0, 9)), n + int(rng.integers(0, 9)), n + int(rng.integers(0, 9))
@@ -58,7 +66,8 @@ for case in range(cases):
     _, bv = strided(k, n, ldb, offs[1], b)
     results = {}
     for kern in ["naive"] + VARIANTS:
-        mm.set_kernel(kern)
+        mm.set_kernel(kern.split("/")[0])
+        mm.set_streamk(2 if kern.endswith("/sk2") else 1)
         cflat, cv = strided(m, n, ldc, offs[2], c0)
         mm.sgemm(m, n, k, av.data_ptr(), lda, bv.data_ptr(), ldb, cv.data_ptr(), ldc, acc, stream)
         torch.cuda.synchronize()
@@ -73,6 +82,7 @@ for case in range(cases):
             d = (results[kern] - results["naive"]).abs().max().item()
             print(f"case {case} {kern}: != naive (max diff {d})  m,n,k={m},{n},{k} ld={lda},{ldb},{ldc} "
                   f"off={offs} acc={acc}")
+mm.set_streamk(1)
 print(f"fuzz: {cases} cases x {len(VARIANTS)} variants, {bad} failures")
 
 # stream-K stress
@@ -83,8 +93,9 @@ for n in (1152, 1536, 1792, 2176, 2432, 2944, 3072, 3456, 3712, 4352, 4608, 2049
     mm.set_kernel("mfma_tiles")
     ref = mm.matmul(a, b)
     # "auto": the LDS-DMA tiles under stream-K below 4096, the 256x256 tile above; "mfma": the register-staged 128x128 tile
-    for kern in ("auto", "mfma"):
-        mm.set_kernel(kern)
+    for kern in ("auto", "mfma", "mfma_128x128_dma5/sk2", "mfma_64x64_dma5/sk2"):
+        mm.set_kernel(kern.split("/")[0])
+        mm.set_streamk(2 if kern.endswith("/sk2") else 1)
         c = torch.empty_like(ref)
         for rep in range(stress):
             c.fill_(float("nan"))
@@ -95,5 +106,6 @@ for n in (1152, 1536, 1792, 2176, 2432, 2944, 3072, 3456, 3712, 4352, 4608, 2049
         if mm.streamk_timeouts():
             sk_bad += 1
             print(f"stream-K {kern} N={n}: hand-off timeouts reported")
+mm.set_streamk(1)
 print(f"stream-K stress: {sk_bad} failures")
 sys.exit(1 if bad or sk_bad else 0)
