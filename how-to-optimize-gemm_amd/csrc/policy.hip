@@ -251,8 +251,12 @@ int auto_plan(int m, int n, int k, int lda, int ldb, int ldc, int base_align, in
   const int kern = plan.kernel >= 0 ? plan.kernel : fallback_kernel(&ctx, g);
   int bm = 0, bn = 0, per_cu = 0;
   switch (kern) {
-    case MMH_KERNEL_MFMA_64X64_DMA5: bm = 64; bn = 64; per_cu = 3; break;     // 48 KiB ring
-    case MMH_KERNEL_MFMA_128X64_DMA5: bm = 128; bn = 64; per_cu = 2; break;   // 72 KiB
+    // (stream-K residency: the tile's guarded chained stream-K instantiation -- the one launch_dma5.hip bounds every
+    // stream-K grid of the tile by -- needs 116 registers: four waves per SIMD, 16 per CU = TWO workgroups of six waves, though
+    // three 48 KiB rings fit; tools/kernel_resources.py.  The table's third stream-K bucket, "768 tiles or more", describes
+    // launches on 512 workgroups: what was measured is what is priced, and what is reported here is what is launched.)
+    case MMH_KERNEL_MFMA_64X64_DMA5: bm = 64; bn = 64; per_cu = 2; break;
+    case MMH_KERNEL_MFMA_128X64_DMA5: bm = 128; bn = 64; per_cu = 1; break;   // (likewise: 165 registers, 12 waves per CU = ONE workgroup of eight)
     case MMH_KERNEL_MFMA_128X128_DMA5: bm = 128; bn = 128; per_cu = 1; break; // 96 KiB
     case MMH_KERNEL_MFMA_96X96_DMA5: bm = 96; bn = 96; per_cu = 2; break;     // 72 KiB
     case MMH_KERNEL_MFMA_256X256: bm = 256; bn = 256; per_cu = 1; break;      // 128 KiB
@@ -268,7 +272,10 @@ int auto_plan(int m, int n, int k, int lda, int ldb, int ldc, int base_align, in
     *streamk_grid = -1;
     if (plan.kernel >= 0) {
       *streamk_grid = 0;
-      if (plan.form == 2) *streamk_grid = mmh::streamk_grid(t, ctx.cu_count, per_cu);
+      if (plan.form == 2) {
+        const int grid = mmh::streamk_grid(t, ctx.cu_count, per_cu);
+        *streamk_grid = (grid > 0 && t % grid != 0) ? grid : 0;   // (launch_streamk: a count the grid divides runs plain)
+      }
     }
   }
   return MMH_OK;

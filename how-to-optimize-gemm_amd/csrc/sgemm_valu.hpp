@@ -26,7 +26,7 @@ namespace mmh {
 //
 // NBUF = 2: two LDS slices, one barrier per slice (64 KiB for either tile: two workgroups per CU).  NBUF = 1: one
 // slice, the next one parked in registers across "barrier, store, barrier" (32 KiB: the register file becomes the
-// limit -- two waves per SIMD for the 128x128 tile at ~190 registers, four for the 64x64 tile); a workgroup's barrier
+// limit -- two waves per SIMD for the 128x128 tile at ~190 registers, three for the 64x64 tile at 132-142); a workgroup's barrier
 // gap is filled by the CU's other workgroups.
 // Round 4: the K-slice is fully unrolled with the fragments of k-step kk + P requested before the FMAs of k-step kk
 // (registers, not another wave, cover the LDS round trip), and the accumulators are pairs so that every FMA is a

@@ -1,0 +1,100 @@
+"""Registers, spills and scratch of the kernels in the built product library, read from its embedded code objects on the
+CPU (tools/kernel_resources.py): a hot kernel that starts to spill, or outgrows the register budget its co-residency
+needs, is a slow number on the GPU box and nothing else -- round 4's VALU rung went to 512 registers and 139 spilled
+ones on the way to its final form.  (The reference has no analogue: nvcc's -Xptxas -v output is not checked anywhere.)"""
+import os
+import re
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+LIB = os.path.join(REPO, "how-to-optimize-gemm_amd", "libmmult_hip.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="libmmult_hip.so has not been built")
+
+
+def _rows():
+    import kernel_resources as K
+    return K.resources(LIB)
+
+
+def _alloc(vgpr):
+    return (vgpr + 7) // 8 * 8          # gfx950 allocates vector registers in blocks of eight
+
+
+def _workgroups_per_cu(vgpr, threads):
+    """By registers alone: 512 per SIMD lane, at most 8 waves per SIMD, a workgroup's waves dealt over the four SIMDs."""
+    per_simd = min(8, 512 // max(_alloc(vgpr), 1))
+    return (4 * per_simd) // (threads // 64)
+
+
+def test_every_code_object_is_readable_and_gfx950_only():
+    rows = _rows()
+    assert len(rows) >= 80, len(rows)
+    names = {r["kernel"].split("<")[0] for r in rows}
+    for want in ("sgemm_mfma_dma5_kernel", "sgemm_dma5_streamk_kernel", "sgemm_mfma_kernel", "sgemm_valu_kernel", "sgemm_naive_kernel"):
+        assert want in names, want
+
+
+def test_no_fp32_gemm_kernel_spills_except_the_known_256x256_forms():
+    """The guarded and the stream-K instantiations of the 256x256 register-staged tile live at the 256-register cap of a
+    512-thread workgroup and spill a few dozen registers around their epilogues (rounds 2-3, measured: not in the loop);
+    everything else -- K1, K2, K2L, K2W in every instantiation -- holds its state in registers."""
+    known = re.compile(r"sgemm_mfma(_streamk)?_kernel<256,256,")
+    for r in _rows():
+        if not r["kernel"].startswith("sgemm_"):
+            continue
+        if known.match(r["kernel"]):
+            assert r["vgpr_spill"] <= 200 and r["scratch"] <= 320, r
+            continue
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0, r
+        # scalars parked in a vector register's lanes (a v_readlane to get one back): none in any one-workgroup-per-tile
+        # kernel; the persistent stream-K bodies carry a range's bookkeeping beside a segment's -- 2 to 49 as the round
+        # ends (outside the K loop; a lever nobody has pulled yet)
+        assert r["sgpr_spill"] <= (64 if "streamk" in r["kernel"] else 0), r
+
+
+def test_the_k2w_tiles_fit_the_co_residency_their_launches_count_on():
+    """Plain launches: three 64x64 workgroups per CU, two 128x64 / 96x96, one 128x128 (csrc/policy_table.inc's w).
+    Stream-K grids are bounded, for every launch of a tile, by its GUARDED CHAINED instantiation (csrc/launch_dma5.hip):
+    116 registers on the 64x64 tile = TWO workgroups per CU where three rings fit, 165 on the 128x64 tile = ONE where two
+    fit (mmh_auto_plan reports grids accordingly).  The whole-tile instantiations (77 / 117 registers) would run three and
+    two: bounding a whole-tile launch by its own instantiation is a lever the round found on the CPU, at its end, and
+    left for the next one."""
+    rows = {r["kernel"]: r for r in _rows()}
+    plain = {"64,64,32,2,2,3": 3, "128,64,32,4,2,3": 2, "128,128,32,4,4,3": 1, "96,96,32,3,3,3": 2}
+    seen = 0
+    for name, r in rows.items():
+        m = re.match(r"sgemm_mfma_dma5_kernel<(\d+,\d+,32,\d,\d,3),", name)
+        if m:
+            assert _workgroups_per_cu(r["vgpr"], r["threads"]) >= plain[m.group(1)], r
+            seen += 1
+    assert seen == 8, seen
+    guarded = {"64,64,32,2,2,3": 2, "128,64,32,4,2,3": 1, "128,128,32,4,4,3": 1}
+    whole = {"64,64,32,2,2,3": 3, "128,64,32,4,2,3": 2, "128,128,32,4,4,3": 1}
+    for tile in guarded:
+        g = rows[f"sgemm_dma5_streamk_kernel<{tile},true,true,{'2,2' if tile.startswith('64') else '4,2'}>"]
+        w = rows[f"sgemm_dma5_streamk_kernel<{tile},false,true,{'2,2' if tile.startswith('64') else '4,2'}>"]
+        assert _workgroups_per_cu(g["vgpr"], g["threads"]) == guarded[tile], g
+        assert _workgroups_per_cu(w["vgpr"], w["threads"]) >= whole[tile], w
+    # ... and what mmh_auto_plan reports for a persistent launch is a grid the launcher can have
+    import how_to_optimize_gemm_amd as H
+    for (m, n, k) in [(3329, 3329, 3329), (2303, 2303, 2303), (1664, 1664, 1664), (3000, 3000, 3000), (1792, 1792, 1792), (5000, 3000, 777)]:
+        name, tiles, grid = H.auto_plan(m, n, k)
+        if grid > 0 and name in ("mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5"):
+            assert grid // 256 <= {"mfma_64x64_dma5": 2, "mfma_128x64_dma5": 1, "mfma_128x128_dma5": 1}[name], (m, n, k, name, grid)
+
+
+def test_the_valu_rung_keeps_its_waves():
+    """K1: three waves per SIMD for the 64x64 tile (at most 168 registers; 132-142 with four k-steps of look-ahead), two
+    for the 128x128 tile (at most 256), no accumulator registers and no spills in any look-ahead instantiation."""
+    n = 0
+    for r in _rows():
+        m = re.match(r"sgemm_valu_kernel<(\d+),(\d+),", r["kernel"])
+        if not m:
+            continue
+        n += 1
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["agpr"] == 0, r
+        assert _alloc(r["vgpr"]) <= (168 if m.group(1) == "64" else 256), r
+    assert n >= 12, n
