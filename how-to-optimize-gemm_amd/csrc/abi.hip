@@ -165,6 +165,10 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
     case 102:   // A/B: chained stream-K heads publish on the spot instead of on the next part's first slice
       h->ab_nodefer = value ? 1 : 0;
       return MMH_OK;
+    case 103:   // A/B (prepared at the end of round 4, not yet measured): whole-tile stream-K launches of the K2W tiles bounded by
+                // their own instantiation's residency (77 / 117 registers: three / two workgroups per CU) instead of the guarded one's
+      h->ab_own_occ = value ? 1 : 0;
+      return MMH_OK;
 #endif
     default:
       return MMH_ERR_INVALID_ARG;

@@ -72,6 +72,9 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
       auto kern_edge = chained ? sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true, NL, D>
                                : sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, false, NL, D>;
       auto occ = sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true, NL, D>;
+#ifdef MMH_AB_BUILD   // option 103: the residency of the instantiation that is launched (found on the CPU)
+      if (ctx->ab_own_occ && !edge) occ = kern;
+#endif
       snprintf(what, sizeof what,
                "sgemm_dma5_streamk_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by %d loader wave%s' LDS-DMA, fragments %d "
                "k-steps ahead%s%s",

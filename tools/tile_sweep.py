@@ -7,7 +7,8 @@ rules are read off (round 4; the reference's `NEW := MMult_xxx` switch, cuda/mak
 
 A variant is a kernel's short name (mmh_kernel_id) optionally followed by /sk0 (MMH_OPT_STREAMK = 0: one
 workgroup per tile), /sk1 (the library's own policy, the default) or /sk2 (stream-K whenever the tile count is
-ragged), /p1 (MMH_OPT_PERSIST = 1: whole rounds of the persistent grid run persistent too), and /nc (MMH_OPT_STREAMK_CHAIN = 0: the K2M tiles' stream-K parts unchained); `rocblas` / `hipblaslt` are the vendor comparators.  Protocol as tools/offgrid_sweep.py: every burst
+ragged), with --ab also /gN, /nd and /oo (tools build switches: raster group height, no deferred publish, a whole-tile
+stream-K launch bounded by its own instantiation's residency), /p1 (MMH_OPT_PERSIST = 1: whole rounds of the persistent grid run persistent too), and /nc (MMH_OPT_STREAMK_CHAIN = 0: the K2M tiles' stream-K parts unchained); `rocblas` / `hipblaslt` are the vendor comparators.  Protocol as tools/offgrid_sweep.py: every burst
 through the C ABI after ~--warm-ms of untimed launches of its own variant, --rounds interleaved rounds, medians.
 --check compares every variant's C with the first variant's, bit for bit.  Needs a GPU."""
 from __future__ import annotations
@@ -72,6 +73,7 @@ def main():
             gm = [x for x in parts[1:] if x.startswith("g") and x[1:].isdigit()]
             mm.set_option(101, int(gm[0][1:]) if gm else 0)
             mm.set_option(102, 1 if "nd" in parts[1:] else 0)
+            mm.set_option(103, 1 if "oo" in parts[1:] else 0)   # whole-tile stream-K launches bounded by their own residency
 
     for (m, n, k) in shapes:
         need = m * k + k * n + m * n
