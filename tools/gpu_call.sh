@@ -7,7 +7,7 @@ TAG=${TAG:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-STEPS=${STEPS:-"k32tests sweep"}
+STEPS=${STEPS:-"k32tests sweep"}   # k32tests tests hsweep sweep abl pmc exp1 exp2 ab3 dataset edge2 tl5 oo sktl
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 if has k32tests; then   # the parity tests of the 32x32x2 LDS-DMA tiles only
   ( time timeout 600 python -m pytest tests -m gpu -x -q -k "${K32_FILTER:-mfma32 or dma5}" ) > $OUT/pytest_k32.log 2>&1
@@ -123,6 +123,12 @@ fi
 if has tl5; then        # per-workgroup timeline of plain K2W launches (thin tiles last)
   timeout 600 python tools/dma5_timeline.py --kernel ${TL_KERNEL:-mfma_64x64_dma5} --shape ${TL_SHAPES:-1025,1025,1025 1024,1024,1024 1040,1040,1040} > $OUT/tl5_${TL_KERNEL:-mfma_64x64_dma5}.txt 2>&1
   cat $OUT/tl5_${TL_KERNEL:-mfma_64x64_dma5}.txt | grep -v amdgpu.ids
+fi
+if has oo; then         # prepared at the end of round 4, never run: whole-tile K2W stream-K launches bounded by their OWN instantiation's
+                        # residency (three 64x64 / two 128x64 workgroups per CU instead of two / one) -- tools build, option 103
+  timeout 500 python tools/tile_sweep.py --ab --check --rounds 3 --sizes ${OO_SIZES:-1152:4096:128} \
+    --variants "auto,mfma_128x64_dma5/sk2,mfma_128x64_dma5/sk2/oo,mfma_64x64_dma5/sk2,mfma_64x64_dma5/sk2/oo,mfma_128x128_dma5/sk2,hipblaslt" \
+    --out $OUT/own_occ > $OUT/own_occ.log 2>&1; grep "^{" $OUT/own_occ.log | cut -c1-330
 fi
 if has sktl; then       # per-workgroup, per-part timeline of stream-K K2W launches
   for kern in ${SKTL_KERNELS:-mfma_128x128_dma5 mfma_64x64_dma5}; do
