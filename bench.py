@@ -384,8 +384,18 @@ def main():
                 try:
                     a1 = torch.rand((m, n), device=dev) * 2 - 1
                     c1 = torch.empty((m, n), device=dev)
-                    single_ms = mm.time_sgemm(m, n, n, a1.data_ptr(), n, b.data_ptr(), n, c1.data_ptr(), n, warmup=1,
-                                              reps=max(2, min(args.steps, 5)), stream=stream)
+                    # the ranks' own protocol (warmup = 1, reps <= 5 read the one-rank line's
+                    # efficiency as 1.0487): W warm-up steps, then K timed steps between two device syncs on the host's clock
+                    def whole():
+                        mm.sgemm(m, n, n, a1.data_ptr(), n, b.data_ptr(), n, c1.data_ptr(), n, False, stream)
+                    for _ in range(args.warmup):
+                        whole()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        whole()
+                    torch.cuda.synchronize()
+                    single_ms = (time.perf_counter() - t1) * 1e3 / args.steps
                     del a1, c1
                 except Exception:      # (out of memory beside the panel buffers: report none rather than fail the run)
                     single_ms = None
@@ -492,7 +502,7 @@ def main():
             out["gemm_ms"] = max(per_rank_ms) if per_rank_ms else None
             if single_ms:
                 v1 = 2.0 * m * n * n * 1e-9 / (single_ms * 1e-3)
-                out["single_gpu_value"] = round(v1, 1)          # the whole problem on rank 0's GPU, same process group
+                out["single_gpu_value"] = round(v1, 1)          # the whole problem on rank 0's GPU, same process group, same W / K / clock as `value`
                 out["single_gpu_ms"] = round(single_ms, 4)
                 out["scaling_efficiency"] = round(gflops / (world * v1), 4)
             # what the committed one-GPU dry run (profiles/r04_shard_dryrun.md) predicts for this line: every rank's

@@ -53,7 +53,7 @@ EXPORTS = [
     "mmh_set_option", "mmh_get_option",
     "mmh_sgemm", "mmh_sgemm_host", "mmh_sgemm_host_timed", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
     "mmh_sgemm_rocblas", "mmh_sgemm_hipblaslt", "mmh_shard_rows",
-    "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm", "mmh_shard_pin",
+    "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm", "mmh_shard_sgemm_streamed", "mmh_shard_pin",
     "mmh_shard_unpin",
     "mmh_rccl_version",
     "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_time_comparator", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
@@ -190,6 +190,7 @@ def lib() -> C.CDLL:
     L.mmh_shard_set_kernel.argtypes = [vp, C.c_int]
     L.mmh_shard_info.argtypes = [vp, ip, ip]
     L.mmh_shard_sgemm.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, fp]
+    L.mmh_shard_sgemm_streamed.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, fp]
     L.mmh_shard_pin.argtypes = [vp, vp, C.c_size_t]
     L.mmh_shard_unpin.argtypes = [vp, vp]
     L.mmh_rccl_version.argtypes = [ip]
@@ -641,8 +642,10 @@ class ShardedMMult:
     def unpin(self, x: np.ndarray) -> None:
         _check(lib().mmh_shard_unpin(self._h, _np_ptr(x)), "mmh_shard_unpin")
 
-    def sgemm(self, a: np.ndarray, b: np.ndarray, c: Optional[np.ndarray] = None, gemm_reps: int = 1):
-        """C = A @ B on host arrays.  Returns (C, {"h2d","bcast","gemm","d2h"} ms; gemm is per rep)."""
+    def sgemm(self, a: np.ndarray, b: np.ndarray, c: Optional[np.ndarray] = None, gemm_reps: int = 1, b_chunks: int = 1):
+        """C = A @ B on host arrays.  Returns (C, {"h2d","bcast","gemm","d2h"} ms; gemm is per rep); with b_chunks > 1
+        (mmh_shard_sgemm_streamed: B broadcast in K-chunks under the GEMMs that consume them) also "overlapped",
+        "chunks", "first_pass", "wall"."""
         m, k = a.shape
         k2, n = b.shape
         if k != k2:
@@ -653,6 +656,11 @@ class ShardedMMult:
             c = np.zeros((m, n), dtype=np.float32)
         elif c.dtype != np.float32 or not c.flags["C_CONTIGUOUS"] or c.shape != (m, n):
             raise MMultError(ERR_INVALID_ARG, "ShardedMMult.sgemm", "c must be C-contiguous float32 (m,n)")
+        if b_chunks > 1:
+            t = (C.c_float * 8)()
+            _check(lib().mmh_shard_sgemm_streamed(self._h, m, n, k, _np_ptr(a), max(k, 1), _np_ptr(b), max(n, 1), _np_ptr(c),
+                                                  max(n, 1), gemm_reps, b_chunks, t), "mmh_shard_sgemm_streamed")
+            return c, dict(zip(("h2d", "bcast", "gemm", "d2h", "overlapped", "chunks", "first_pass", "wall"), list(t)))
         t = (C.c_float * 4)()
         _check(lib().mmh_shard_sgemm(self._h, m, n, k, _np_ptr(a), max(k, 1), _np_ptr(b), max(n, 1), _np_ptr(c),
                                      max(n, 1), gemm_reps, t), "mmh_shard_sgemm")

@@ -169,6 +169,10 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
                 // their own instantiation's residency (77 / 117 registers: three / two workgroups per CU) instead of the guarded one's
       h->ab_own_occ = value ? 1 : 0;
       return MMH_OK;
+    case 104:   // A/B: phase-ordered stream-K tables from this many tiles per workgroup, in tenths (product: 18)
+      if (value < 10 || value > 1000) return MMH_ERR_INVALID_ARG;
+      h->sk_order_min10 = value;
+      return MMH_OK;
 #endif
     default:
       return MMH_ERR_INVALID_ARG;
@@ -295,6 +299,9 @@ const char *mmh_kernel_name(int kernel) {
     case 80: return "exp5_160x160_l1d2";
     case 81: return "exp5_160x160_l4";
     case 82: return "exp5_160x160_l2";
+    case 83: return "exp5_96x64_l4";
+    case 84: return "exp5_96x64_l2";
+    case 85: return "exp5_64x96_l2";
 #endif
     default: return nullptr;
   }

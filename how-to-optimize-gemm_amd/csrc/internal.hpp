@@ -135,6 +135,7 @@ struct mmh_context {
   int fault = 0;               // MMH_OPT_FAULT_INJECT
   int pin = 1;                 // persistent launches ask for 160 KiB / w of LDS so that exactly w workgroups fit a CU
   int sk_order = 1;            // stream-K launches get the phase-ordered range / tile tables
+  int sk_order_min10 = 18;     // ... from this many tiles per workgroup, in tenths (tools build: option 104)
   int dma_edge = 1;            // ragged / 4-byte-aligned shapes may run the guarded LDS-DMA tiles (MMH_OPT_DMA_EDGE)
   int dma_dword_rows = 1;      // ... including operands whose rows are only 4-byte aligned (odd lda / ldb / base)
   int sk_chain = 1;            // stream-K launches of the K2M tiles run a range's parts as one stream of slices (MMH_OPT_STREAMK_CHAIN)
@@ -208,7 +209,7 @@ int workspace_for(mmh_context *ctx, hipStream_t s, long tiles, size_t parts_byte
 int reserve_stream(mmh_context *ctx, hipStream_t s, int m, int n, int k);   // mmh_reserve_stream
 void workspaces_suspect(mmh_context *ctx);   // a launch may have died half-way: every set is memset before its next use
 bool build_sk_tables(long tiles, int nk, int grid, int *order, int *place);
-int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place);
+int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place, int min10 = 0);
 
 // ---- the kernel families (each returns MMH_OK, an error, or 1 = "this shape does not qualify") ----
 int auto_plan(int m, int n, int k, int lda, int ldb, int ldc, int base_align, int cu_count, int *kernel, long *tiles,

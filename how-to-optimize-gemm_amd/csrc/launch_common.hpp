@@ -58,7 +58,7 @@ inline int streamk_wanted(const mmh_context *ctx, long tiles, int BM, int BN, in
   // (Balance is a matter of CUs, not of workgroup slots: co-resident workgroups share their CU's matrix pipe.)
   // (The 128x64 tile counts as a big one once the launch is phase-ordered -- >= 1.8 tiles per workgroup,
   // sk_tables_for -- N = 3968: 147.7 under stream-K, 141.9 plain.)
-  const bool ordered = ctx->sk_order && tiles * 10 >= (long)grid * 18;
+  const bool ordered = ctx->sk_order && tiles * 10 >= (long)grid * ctx->sk_order_min10;
   if (ctx->streamk != 2 && BM * BN < 128 * 128 && !(ordered && BM * BN >= 128 * 64)) {   // MMH_OPT_STREAMK = 2: whenever ragged
     const long rounds = (tiles + cus - 1) / cus;
     if (tiles * 100 >= rounds * cus * 93) return 0;
@@ -72,7 +72,7 @@ inline int streamk_wanted(const mmh_context *ctx, long tiles, int BM, int BN, in
 // even when the policy below prefers the plain launch (warm-up, tools).
 template <typename K>
 int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB, int threads, size_t lds, const char *what,
-                   const GemmArgs &g, long decide_tiles = 0) {
+                   const GemmArgs &g, long decide_tiles = 0, int order_min10 = 0) {
   const int nbm = (g.m + BM - 1) / BM, nbn = (g.n + BN - 1) / BN;
   const long tiles = (long)nbm * nbn;
   const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
@@ -111,7 +111,7 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB,
     if (ok != MMH_OK) return ok;
   }
   const int *order = nullptr, *place = nullptr;
-  if ((rc = sk_tables_for(ctx, tiles, (g.k + KB - 1) / KB, grid, g.s, &order, &place)) != MMH_OK) return rc;
+  if ((rc = sk_tables_for(ctx, tiles, (g.k + KB - 1) / KB, grid, g.s, &order, &place, order_min10)) != MMH_OK) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds_launch, g.s, g.m, g.n, g.k, g.A, g.lda, g.B, g.ldb, g.C,
                      g.ldc, g.acc, nbm, nbn, flags, parts, order, place, ctx->sk_stats);
   HIP_TRY(hipGetLastError());

@@ -87,7 +87,8 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
         const int thin_row = (nbm > 1 && g.m - (nbm - 1) * BM <= 16) ? 1 : 0, thin_col = (nbn > 1 && g.n - (nbn - 1) * BN <= 16) ? 1 : 0;
         if (thin_row || thin_col) decide = (long)(nbm - thin_row) * (nbn - thin_col);
       }
-      const int sk = launch_streamk(ctx, edge ? kern_edge : kern, occ, BM, BN, KB, T::THREADS, T::LDS_BYTES, what, ga, decide);
+      const int sk = launch_streamk(ctx, edge ? kern_edge : kern, occ, BM, BN, KB, T::THREADS, T::LDS_BYTES, what, ga, decide,
+                                     (BM == 128 && BN == 128) ? 10 : 0);   // (phase-ordered tables from one 128x128 tile per workgroup)
       if (sk <= 0) return sk;
     }
   }
@@ -176,6 +177,10 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
     // Five column-blocked B fragments of single floats per k-step and 100 accumulator registers: the loop itself is slower.)
     case 81: return launch_dma5_tile<160, 160, 5, 5, 3, 4, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 82: return launch_dma5_tile<160, 160, 5, 5, 3, 2, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    // round 5: 96x64 / 64x96 (N = 1152: 216 tiles -- one round of 256 CUs at 84 % -- instead of 324 tiles of 64x64 under stream-K)
+    case 83: return launch_dma5_tile<96, 64, 3, 2, 3, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 84: return launch_dma5_tile<96, 64, 3, 2, 3, 2, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 85: return launch_dma5_tile<64, 96, 2, 3, 3, 2, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
 #endif
     default:
       set_last_error("unknown kernel variant");

@@ -43,12 +43,16 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
   const double nk = (double)((g.k + kSliceK - 1) / kSliceK);
   Plan best;
   long tiles_rim = 0;
+  bool any_dma5 = false;   // did any LDS-DMA family take the shape?
   for (const Family &f : kFamilies) {
     // (Rounds 2-3 kept K > 8192 -- B beyond the Infinity Cache, the config-4 panels -- on the 256x256 tile: K2L's small tiles
     // lost 1-6 % there.  K2W's do not: 2048 .. 4096 x 16384 x 16384 run 152.4-153.2 TFLOP/s on the 128x64 tile against
     // 150.2-150.3, and 2048 x 4096 x 16384 -- half a round of 256x256 tiles -- 151.5 against 74.8: the fence is gone, the
     // table decides; profiles/r04_big_k.md.)
-    if (f.kernel != MMH_KERNEL_MFMA_256X256 && !dma5_shape_ok(ctx, f.kernel, g)) continue;
+    if (f.kernel != MMH_KERNEL_MFMA_256X256) {
+      if (!dma5_shape_ok(ctx, f.kernel, g)) continue;
+      any_dma5 = true;
+    }
     long tiles = (long)((g.m + f.bm - 1) / f.bm) * ((g.n + f.bn - 1) / f.bn);
     {   // the 64x64 tile's RIM launch: one or two rows / columns past a 64-boundary cost no tiles of their own (plain only)
       int r_m = 0, r_n = 0;
@@ -75,6 +79,11 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
       }
     }
   }
+  // No LDS-DMA family takes the shape (operands beyond the 2 GiB descriptor window; MMH_OPT_DMA_EDGE = 0 on a ragged or
+  // unaligned shape): the table's one remaining row -- the 256x256 tile, priced without rivals -- is not a choice.
+  // fallback_kernel picks among the register-staged tiles by tile count (round 4 launched 16 workgroups of 256x256
+  // for 1000^3 here).
+  if (!any_dma5) return Plan{};
   return best;
 }
 
@@ -227,7 +236,7 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return launch_dma(ctx, kernel, g);
     case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59:
       return launch_dma32(ctx, kernel, g);
-    case 64: case 65: case 66: case 67: case 68: case 69: case 72: case 79: case 80: case 81: case 82:
+    case 64: case 65: case 66: case 67: case 68: case 69: case 72: case 79: case 80: case 81: case 82: case 83: case 84: case 85:
       return launch_dma5(ctx, kernel, g);
 #endif
     default:

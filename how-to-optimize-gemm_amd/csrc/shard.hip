@@ -18,12 +18,19 @@ struct mmh_shard {
   std::vector<int> devices;
   std::vector<mmh_context *> ctx;     // one product handle per device (stream-K workspaces etc.)
   std::vector<hipStream_t> streams;
+  std::vector<hipStream_t> bstreams;  // per device: the stream B's broadcast travels on (high priority; chunk c + 1 while chunk c is consumed)
+  // per device: timing events [0] broadcast start, [1] broadcast end, [2] first GEMM pass start, [3] its end,
+  // [4] / [5] around the gemm_reps loop; then kMaxChunks ordering events (chunk c has landed)
+  std::vector<std::vector<hipEvent_t>> events;
   std::vector<DevBuf> a, b, c;        // per device: A panel, B, C panel
   std::vector<void *> comms;
   bool shared_device = false;         // test mode: several logical ranks on one device, B replicated by device copies
-  bool lazy = false;                  // the per-device product handles are created without the warm-up (one-shot form)
   std::vector<std::pair<void *, size_t>> pinned;   // host ranges mmh_shard_pin registered
 };
+
+namespace {
+constexpr int kMaxChunks = 64, kTimingEvents = 6;
+}
 
 extern "C" {
 
@@ -55,6 +62,10 @@ int mmh_shard_destroy(mmh_shard_t sh) {
     (void)hipSetDevice(sh->devices[d]);
     if (d < (int)sh->comms.size() && sh->comms[d]) rccl_api().comm_destroy(sh->comms[d]);
     if (d < (int)sh->a.size()) { sh->a[d].release(); sh->b[d].release(); sh->c[d].release(); }
+    if (d < (int)sh->events.size())
+      for (hipEvent_t e : sh->events[d])
+        if (e) (void)hipEventDestroy(e);
+    if (d < (int)sh->bstreams.size() && sh->bstreams[d]) (void)hipStreamDestroy(sh->bstreams[d]);
     if (d < (int)sh->streams.size() && sh->streams[d]) (void)hipStreamDestroy(sh->streams[d]);
     if (d < (int)sh->ctx.size()) destroy_context(sh->ctx[d]);
   }
@@ -147,6 +158,8 @@ static int shard_create(mmh_shard_t *out, int ngpus, const int *devices, bool la
   (void)hipGetDevice(&prev);
   sh->ctx.assign(ngpus, nullptr);
   sh->streams.assign(ngpus, nullptr);
+  sh->bstreams.assign(ngpus, nullptr);
+  sh->events.assign(ngpus, std::vector<hipEvent_t>(kTimingEvents + kMaxChunks, nullptr));
   sh->a.resize(ngpus);
   sh->b.resize(ngpus);
   sh->c.resize(ngpus);
@@ -158,7 +171,22 @@ static int shard_create(mmh_shard_t *out, int ngpus, const int *devices, bool la
     if (hipSetDevice(sh->devices[d]) != hipSuccess || hipStreamCreate(&sh->streams[d]) != hipSuccess) {
       set_last_error("hipStreamCreate failed");
       rc = MMH_ERR_HIP;
+      break;
     }
+    // the broadcast's stream outranks the GEMM's: a chunk's collective kernel takes the first workgroup slots that
+    // come free under the previous chunk's GEMM instead of queueing behind its remaining tiles
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&sh->bstreams[d], hipStreamNonBlocking, hi) != hipSuccess) {
+      set_last_error("hipStreamCreateWithPriority failed");
+      rc = MMH_ERR_HIP;
+      break;
+    }
+    for (int e = 0; e < kTimingEvents + kMaxChunks && rc == MMH_OK; ++e)
+      if (hipEventCreateWithFlags(&sh->events[d][e], e < kTimingEvents ? hipEventDefault : hipEventDisableTiming) != hipSuccess) {
+        set_last_error("hipEventCreate failed");
+        rc = MMH_ERR_HIP;
+      }
   }
   if (rc == MMH_OK && ((ngpus > 1 && !shared) || force_rccl)) {
     // ONE communicator for the life of the handle (creating it costs far more than any GEMM here)
@@ -192,14 +220,26 @@ int mmh_shard_info(mmh_shard_t sh, int *ngpus, int *rccl_ranks) {
   return MMH_OK;
 }
 
-int mmh_shard_sgemm(mmh_shard_t sh, int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
-                    int ldc, int gemm_reps, float *timings_ms) {
+// K-chunk boundaries of the streamed broadcast: `chunks` near-equal runs of whole 128-deep K blocks (a chunk's A columns
+// and B rows then start 512 bytes into a row / at a whole row: every LDS-DMA alignment class of the unchunked launch)
+static int chunk_bounds(int k, int chunks, int *k0) {
+  const int blocks = (k + 127) / 128;
+  if (chunks > blocks) chunks = blocks;
+  if (chunks > kMaxChunks) chunks = kMaxChunks;
+  if (chunks < 1) chunks = 1;
+  for (int c = 0; c <= chunks; ++c) k0[c] = (int)std::min<long>((long)k, ((long)blocks * c / chunks) * 128);
+  return chunks;
+}
+
+int mmh_shard_sgemm_streamed(mmh_shard_t sh, int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
+                             int ldc, int gemm_reps, int b_chunks, float *timings_ms) {
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point t) { return std::chrono::duration<float, std::milli>(clk::now() - t).count(); };
-  if (!sh || gemm_reps < 1) return MMH_ERR_INVALID_ARG;
+  if (!sh || gemm_reps < 1 || b_chunks < 0) return MMH_ERR_INVALID_ARG;
   int rc = check_gemm_args(m, n, k, A, lda, B, ldb, C, ldc);
   if (rc != MMH_OK) return rc;
-  if (timings_ms) timings_ms[0] = timings_ms[1] = timings_ms[2] = timings_ms[3] = 0.f;
+  if (timings_ms)
+    for (int i = 0; i < 8; ++i) timings_ms[i] = 0.f;
   if (m == 0 || n == 0) return MMH_OK;
   const int G = sh->ngpus;
   for (int d = 0; d < G; ++d)
@@ -254,46 +294,123 @@ int mmh_shard_sgemm(mmh_shard_t sh, int m, int n, int k, const float *A, int lda
     if (rc != MMH_OK) return rc;
   }
   if (timings_ms) timings_ms[0] = ms_since(t);
-  // ---- the one collective: broadcast B from device 0 over xGMI ----
-  t = clk::now();
-  if (G > 1 && k > 0 && sh->shared_device) {
-    HIP_TRY(hipStreamSynchronize(sh->streams[0]));
-    for (int d = 1; d < G; ++d)
-      HIP_TRY(hipMemcpyAsync(sh->b[d].p, sh->b[0].p, (size_t)k * n * sizeof(float), hipMemcpyDeviceToDevice, sh->streams[d]));
-    for (int d = 1; d < G; ++d) HIP_TRY(hipStreamSynchronize(sh->streams[d]));
-  } else if ((G > 1 || sh->rccl_ranks > 0) && k > 0) {
-    RcclApi &api = rccl_api();
-    bool bad = api.group_start() != 0;
-    for (int d = 0; d < G && !bad; ++d) {
-      constexpr int nccl_float = 7;
-      bad = api.broadcast(sh->b[0].p, sh->b[d].p, (size_t)k * n, nccl_float, 0, sh->comms[d], sh->streams[d]) != 0;
-    }
-    if (api.group_end() != 0) bad = true;
-    if (bad) {
-      set_last_error("ncclBroadcast failed");
-      return MMH_ERR_COMM;
-    }
-    for (int d = 0; d < G; ++d) {
-      HIP_TRY(hipSetDevice(sh->devices[d]));
-      HIP_TRY(hipStreamSynchronize(sh->streams[d]));
-    }
-  }
-  if (timings_ms) timings_ms[1] = ((G > 1 || sh->rccl_ranks > 0) && k > 0) ? ms_since(t) : 0.f;
-  // ---- independent row-panel GEMMs (gemm_reps back-to-back launches per device: phase time / reps) ----
-  t = clk::now();
-  for (int rep = 0; rep < gemm_reps; ++rep)
-    for (int d = 0; d < G; ++d) {
-      if (rows[d] == 0) continue;
-      HIP_TRY(hipSetDevice(sh->devices[d]));
-      rc = sgemm_on(sh->ctx[d], sh->kernel, rows[d], n, k, static_cast<float *>(sh->a[d].p), k,
-                    static_cast<float *>(sh->b[d].p), n, static_cast<float *>(sh->c[d].p), n, 0, sh->streams[d]);
-      if (rc != MMH_OK) return rc;
-    }
+  // ---- the one collective, and the first pass of the row-panel GEMMs ----
+  // B leaves device 0 over xGMI in `chunks` runs of K (ONE ncclBroadcast when chunks == 1) on the devices' broadcast
+  // streams; every device's GEMM stream waits for chunk c's event and consumes it -- C = A[:, chunk c] B[chunk c, :] + C,
+  // C's value the first term of each element's chain (mmh_sgemm's `accumulate`): the single launch's chain, cut and
+  // resumed, the same bits -- while chunk c + 1 is in flight.  Everything is enqueued from this one thread without a host
+  // synchronisation in between; the phases are timed PER DEVICE with events on the device's own streams (round 4 timed
+  // the broadcast with a serial host loop of stream syncs).
+  const bool with_bcast = (G > 1 || sh->rccl_ranks > 0) && k > 0;
+  int k0[kMaxChunks + 1];
+  const int chunks = chunk_bounds(k, (with_bcast && b_chunks > 1) ? b_chunks : 1, k0);
+  auto tb = clk::now();
   for (int d = 0; d < G; ++d) {
     HIP_TRY(hipSetDevice(sh->devices[d]));
+    HIP_TRY(hipEventRecord(sh->events[d][0], sh->bstreams[d]));
+  }
+  if (with_bcast) {
+    for (int c = 0; c < chunks; ++c) {
+      const size_t off = (size_t)k0[c] * n, count = (size_t)(k0[c + 1] - k0[c]) * n;
+      if (sh->shared_device) {
+        for (int d = 1; d < G; ++d) {
+          HIP_TRY(hipSetDevice(sh->devices[d]));
+          HIP_TRY(hipMemcpyAsync(static_cast<float *>(sh->b[d].p) + off, static_cast<float *>(sh->b[0].p) + off, count * sizeof(float),
+                                 hipMemcpyDeviceToDevice, sh->bstreams[d]));
+        }
+      } else {
+        RcclApi &api = rccl_api();
+        bool bad = api.group_start() != 0;
+        for (int d = 0; d < G && !bad; ++d) {
+          constexpr int nccl_float = 7;
+          bad = api.broadcast(static_cast<float *>(sh->b[0].p) + off, static_cast<float *>(sh->b[d].p) + off, count, nccl_float, 0,
+                              sh->comms[d], sh->bstreams[d]) != 0;
+        }
+        if (api.group_end() != 0) bad = true;
+        if (bad) {
+          set_last_error("ncclBroadcast failed");
+          return MMH_ERR_COMM;
+        }
+      }
+      for (int d = 0; d < G; ++d) {
+        HIP_TRY(hipSetDevice(sh->devices[d]));
+        HIP_TRY(hipEventRecord(sh->events[d][kTimingEvents + c], sh->bstreams[d]));
+      }
+    }
+  }
+  for (int d = 0; d < G; ++d) {
+    HIP_TRY(hipSetDevice(sh->devices[d]));
+    HIP_TRY(hipEventRecord(sh->events[d][1], sh->bstreams[d]));
+  }
+  for (int d = 0; d < G; ++d) {
+    HIP_TRY(hipSetDevice(sh->devices[d]));
+    if (with_bcast) HIP_TRY(hipStreamWaitEvent(sh->streams[d], sh->events[d][kTimingEvents], 0));   // (the timed pass starts with chunk 0 landed)
+    HIP_TRY(hipEventRecord(sh->events[d][2], sh->streams[d]));
+    for (int c = 0; c < chunks && rows[d] > 0; ++c) {
+      if (with_bcast && c > 0) HIP_TRY(hipStreamWaitEvent(sh->streams[d], sh->events[d][kTimingEvents + c], 0));
+      const int kc = k0[c + 1] - k0[c];
+      if (kc == 0 && c > 0) continue;
+      rc = sgemm_on(sh->ctx[d], sh->kernel, rows[d], n, kc, static_cast<float *>(sh->a[d].p) + k0[c], k,
+                    static_cast<float *>(sh->b[d].p) + (size_t)k0[c] * n, n, static_cast<float *>(sh->c[d].p), n, c > 0 ? 1 : 0,
+                    sh->streams[d]);
+      if (rc != MMH_OK) return rc;
+    }
+    if (with_bcast) HIP_TRY(hipStreamWaitEvent(sh->streams[d], sh->events[d][1], 0));   // (a device without rows still ends after its broadcast)
+    HIP_TRY(hipEventRecord(sh->events[d][3], sh->streams[d]));
+  }
+  // ---- gemm_reps back-to-back full-K launches per device (the harness's NREPEATS loop: phase time / reps); with ONE
+  // repetition and an unchunked broadcast the pass above is that launch ----
+  const bool rep_loop = gemm_reps > 1 || chunks > 1;
+  if (rep_loop) {
+    for (int d = 0; d < G; ++d) {
+      HIP_TRY(hipSetDevice(sh->devices[d]));
+      HIP_TRY(hipEventRecord(sh->events[d][4], sh->streams[d]));
+    }
+    for (int rep = 0; rep < gemm_reps; ++rep)
+      for (int d = 0; d < G; ++d) {
+        if (rows[d] == 0) continue;
+        HIP_TRY(hipSetDevice(sh->devices[d]));
+        rc = sgemm_on(sh->ctx[d], sh->kernel, rows[d], n, k, static_cast<float *>(sh->a[d].p), k,
+                      static_cast<float *>(sh->b[d].p), n, static_cast<float *>(sh->c[d].p), n, 0, sh->streams[d]);
+        if (rc != MMH_OK) return rc;
+      }
+    for (int d = 0; d < G; ++d) {
+      HIP_TRY(hipSetDevice(sh->devices[d]));
+      HIP_TRY(hipEventRecord(sh->events[d][5], sh->streams[d]));
+    }
+  }
+  for (int d = 0; d < G; ++d) {
+    HIP_TRY(hipSetDevice(sh->devices[d]));
+    HIP_TRY(hipStreamSynchronize(sh->bstreams[d]));
     HIP_TRY(hipStreamSynchronize(sh->streams[d]));
   }
-  if (timings_ms) timings_ms[2] = ms_since(t) / gemm_reps;
+  const float wall = ms_since(tb);
+  if (timings_ms) {
+    // the slowest device sets each figure (the ranks run concurrently)
+    float bcast = 0.f, pass = 0.f, overlapped = 0.f, reps = 0.f;
+    for (int d = 0; d < G; ++d) {
+      HIP_TRY(hipSetDevice(sh->devices[d]));
+      float v = 0.f;
+      if (with_bcast) {
+        HIP_TRY(hipEventElapsedTime(&v, sh->events[d][0], sh->events[d][1]));
+        bcast = std::max(bcast, v);
+      }
+      HIP_TRY(hipEventElapsedTime(&v, sh->events[d][2], sh->events[d][3]));
+      pass = std::max(pass, v);
+      HIP_TRY(hipEventElapsedTime(&v, sh->events[d][0], sh->events[d][3]));
+      overlapped = std::max(overlapped, v);
+      if (rep_loop) {
+        HIP_TRY(hipEventElapsedTime(&v, sh->events[d][4], sh->events[d][5]));
+        reps = std::max(reps, v / gemm_reps);
+      }
+    }
+    timings_ms[1] = bcast;                      // broadcast, first chunk's start to last chunk's end, slowest device
+    timings_ms[2] = rep_loop ? reps : pass;     // GEMM per full-K launch
+    timings_ms[4] = overlapped;                 // broadcast start to the end of the first GEMM pass: what a caller who has to pay for B waits
+    timings_ms[5] = (float)chunks;
+    timings_ms[6] = pass;                       // the first GEMM pass alone (chunk 0 landed -> last chunk consumed)
+    timings_ms[7] = wall;                       // host clock around everything enqueued above (cross-check)
+  }
   for (int d = 0; d < G; ++d)
     if ((rc = check_sticky(sh->ctx[d])) != MMH_OK) return rc;
   // ---- device -> host: disjoint C panels ----
@@ -306,6 +423,16 @@ int mmh_shard_sgemm(mmh_shard_t sh, int m, int n, int k, const float *A, int lda
   if (rc != MMH_OK) return rc;
   if (timings_ms) timings_ms[3] = ms_since(t);
   return MMH_OK;
+}
+
+// the round-1 entry point: ONE broadcast, then the GEMMs (timings_ms: four floats)
+int mmh_shard_sgemm(mmh_shard_t sh, int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
+                    int ldc, int gemm_reps, float *timings_ms) {
+  float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int rc = mmh_shard_sgemm_streamed(sh, m, n, k, A, lda, B, ldb, C, ldc, gemm_reps, 1, timings_ms ? t8 : nullptr);
+  if (timings_ms)
+    for (int i = 0; i < 4; ++i) timings_ms[i] = t8[i];
+  return rc;
 }
 
 // one-shot convenience form: create, run once, destroy (what the round-1 entry point did on every call)

@@ -217,13 +217,18 @@ bool build_sk_tables(long tiles, int nk, int grid, int *order, int *place) {
 // copy on the launch's own stream: no host synchronisation, and a launch that is being captured into a
 // hipGraph records the same copy as a node of the graph -- its entry is then pinned in the cache (never
 // evicted or rewritten), so a replay finds staging, tables and kernel arguments as they were captured.
-int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place) {
+int sk_tables_for(mmh_context *ctx, long tiles, int nk, int grid, hipStream_t s, const int **order, const int **place, int min10) {
   *order = *place = nullptr;
   // Worth it from ~1.8 tiles per workgroup (measured): phase order puts the two workgroups that share a
   // tile on different XCDs, so the partial tile crosses the fabric instead of being an L2 hit -- with one
   // tile per workgroup that hand-over is a tenth of the launch (N = 2176 on 128x64 tiles: 139.5 -> 125.0),
   // with two or more the restored L2 reuse wins (N = 3584 on 64x64 tiles: 138.5 -> 146.0).
-  if (!ctx->sk_order || tiles > (1L << 20) || tiles * 10 < (long)grid * 18) return MMH_OK;
+  // (min10: a tile code's own threshold in tenths of a tile per workgroup.  Round 5, K2W's 128x128 tile: ordered from ONE
+  // tile per workgroup -- N = 2560, 400 tiles on 256 workgroups: L2 hit rate 0.40 -> 0.75, 629 -> 227 MB over the fabric
+  // per launch (2.9 x the algorithmic bytes), time unchanged, 144.8 / 144.4 TFLOP/s; 2176 .. 2816 within +-0.3 %:
+  // profiles/r05_notes.md.  The smaller tiles keep 1.8: 64x64 at N = 1152 loses 3 %, 128x64 at 1536 loses 3 %.)
+  if (min10 <= 0 || ctx->sk_order_min10 != 18) min10 = ctx->sk_order_min10;   // (tools build, option 104: one threshold for all)
+  if (!ctx->sk_order || tiles > (1L << 20) || tiles * 10 < (long)grid * min10) return MMH_OK;
   const bool cap = capturing(s);
   for (auto *t : ctx->sk_tables)
     if (t->tiles == tiles && t->nk == nk && t->grid == grid && t->uploaded) {

@@ -33,7 +33,10 @@
 //                                        handle for the whole sweep: communicator, streams and
 //                                        buffers persist), B by one ncclBroadcast (BASELINE.json
 //                                        config 4); GFLOPS from the GEMM phase (NREPEATS launches
-//                                        per device), EXTENDED adds h2d/bcast/gemm/d2h ms
+//                                        per device), EXTENDED adds h2d/bcast/gemm/d2h ms and -- with
+//                                        B_CHUNKS=<c> > 1: B travels in c K-chunks under the GEMMs that
+//                                        consume them, mmh_shard_sgemm_streamed -- the overlapped
+//                                        broadcast + first-GEMM-pass ms and the chunk count
 //   INPUT=drand48|seed:<n>|mod3|mod2|ones           (cuda/random_matrix.cpp:9-15 variants)
 //   REF=threads|serial|blas|skip  how cref is produced: the triple loop split over host threads
 //                                (default), the literal serial loop, the host BLAS's cblas_sgemm
@@ -81,7 +84,7 @@ struct Options {
   int m = sweep_defaults::kM, n = sweep_defaults::kN, k = sweep_defaults::kK;
   int nrepeats = sweep_defaults::kRepeats;
   int lda = sweep_defaults::kLda, ldb = sweep_defaults::kLdb, ldc = sweep_defaults::kLdc;
-  int warmup = 0, warmup_ms = 0, extended = 0, ngpus = 1, splitk = 0, trials = 1, probes = 0;
+  int warmup = 0, warmup_ms = 0, extended = 0, ngpus = 1, splitk = 0, trials = 1, probes = 0, b_chunks = 1;
   std::string json;
   std::string kernel = "auto", flavour = "device", input = "drand48", ref = "threads";
 };
@@ -137,6 +140,7 @@ int main(int argc, char **argv) {
   opt_str(argc, argv, "JSON", o.json);
   if (o.trials < 1) o.trials = 1;
   opt_int(argc, argv, "NGPUS", o.ngpus);
+  opt_int(argc, argv, "B_CHUNKS", o.b_chunks);
   opt_int(argc, argv, "SPLITK", o.splitk);
   opt_str(argc, argv, "KERNEL", o.kernel);  opt_str(argc, argv, "FLAVOUR", o.flavour);
   opt_str(argc, argv, "INPUT", o.input);    opt_str(argc, argv, "REF", o.ref);
@@ -233,7 +237,7 @@ int main(int argc, char **argv) {
     }
 
     double seconds = 0.0;
-    float phase_ms[4] = {0, 0, 0, 0};
+    float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (sharded) {
       // one call = h2d, ONE broadcast, NREPEATS back-to-back GEMM launches per device, d2h; the GEMM
       // phase is reported per launch (the reference times NREPEATS launches, cuda/test_MMult.cpp:98-118)
@@ -244,7 +248,8 @@ int main(int argc, char **argv) {
                           mmh_shard_pin(shard, cold.data(), cold.size() * sizeof(float)) == MMH_OK;
       for (int rep = 0; rep < o.warmup; ++rep)
         MMH_CHECK(mmh_shard_sgemm(shard, m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc, 1, nullptr));
-      MMH_CHECK(mmh_shard_sgemm(shard, m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc, o.nrepeats, phase_ms));
+      MMH_CHECK(mmh_shard_sgemm_streamed(shard, m, n, k, a.data(), lda, b.data(), ldb, cold.data(), ldc, o.nrepeats, o.b_chunks,
+                                         phase_ms));
       seconds = phase_ms[2] * 1e-3;
       (void)pinned;
       (void)mmh_shard_unpin(shard, a.data());
@@ -338,9 +343,9 @@ int main(int argc, char **argv) {
       }
     }
     if (o.extended && sharded)
-      std::printf("%d %.2f %le %.2f %.3f %.3f %.3f %.3f \n", p, gflops, diff,
+      std::printf("%d %.2f %le %.2f %.3f %.3f %.3f %.3f %.3f %d \n", p, gflops, diff,
                   100.0 * gflops / (o.ngpus * kPeakTflops * 1e3), phase_ms[0], phase_ms[1], phase_ms[2],
-                  phase_ms[3]);
+                  phase_ms[3], phase_ms[4], (int)phase_ms[5]);
     else if (o.extended)
       std::printf("%d %.2f %le %.2f %.3f %d \n", p, gflops, diff,
                   100.0 * gflops / (kPeakTflops * 1e3), ref_gflops, ref_cores);

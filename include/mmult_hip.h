@@ -357,6 +357,15 @@ int mmh_shard_rows(int m, int nranks, int rank, int *row0, int *rows);
  *            visible (never a silent fallback to fewer), MMH_ERR_UNSUPPORTED without librccl (ngpus > 1).
  *   mmh_shard_sgemm: gemm_reps >= 1 back-to-back GEMM launches per device (the reference harness's
  *            NREPEATS loop); timings_ms (may be NULL) receives {h2d, bcast, gemm per rep, d2h}.
+ *   mmh_shard_sgemm_streamed (round 5): the same with B travelling in `b_chunks` runs of K (whole 128-deep blocks; 0 or
+ *            1 = ONE broadcast, at most 64) on a second, higher-priority stream per device while the chunks already
+ *            landed are consumed -- C = A[:, chunk] B[chunk, :] + C with C's value as the first term of each chain, i.e.
+ *            the unchunked launch's bits -- followed, when b_chunks > 1 or gemm_reps > 1, by gemm_reps full-K launches.
+ *            timings_ms (may be NULL) receives EIGHT floats, every device phase taken with events on that device's own
+ *            streams, the slowest device reported: {h2d (host clock), broadcast (first chunk out .. last chunk landed),
+ *            gemm per full-K launch, d2h (host clock), OVERLAPPED (broadcast start .. end of the first GEMM pass: what
+ *            a caller who has to pay for B waits), chunks used, the first GEMM pass alone, host clock around the
+ *            device phases}.  mmh_shard_sgemm is this with b_chunks = 1 and the first four figures.
  *   mmh_shard_info: rccl_ranks = ranks of the communicator (0 for ngpus == 1, where RCCL is not used). */
 typedef struct mmh_shard *mmh_shard_t;
 int mmh_shard_create(mmh_shard_t *shard, int ngpus, const int *devices);
@@ -365,6 +374,8 @@ int mmh_shard_set_kernel(mmh_shard_t shard, int kernel);
 int mmh_shard_info(mmh_shard_t shard, int *ngpus, int *rccl_ranks);
 int mmh_shard_sgemm(mmh_shard_t shard, int m, int n, int k, const float *A, int lda, const float *B,
                     int ldb, float *C, int ldc, int gemm_reps, float *timings_ms);
+int mmh_shard_sgemm_streamed(mmh_shard_t shard, int m, int n, int k, const float *A, int lda, const float *B,
+                             int ldb, float *C, int ldc, int gemm_reps, int b_chunks, float *timings_ms);
 /* Page-lock (hipHostRegister) a host range that is about to be passed to mmh_shard_sgemm more than once -- A, B
  * and C of one sweep size: copies from / to pageable memory run at a fraction of the PCIe rate.  Unpin before
  * the memory is freed; mmh_shard_destroy unpins whatever is left.

@@ -1,0 +1,133 @@
+"""Round-5 GPU tests: MMH_KERNEL_AUTO's fall-back when no LDS-DMA family takes a shape, the phase-ordered tables of the
+128x128 K2W tile from one tile per workgroup, and what else the round added.  All call through the C ABI (api.py is ctypes)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def test_auto_without_the_guarded_lds_dma_tiles_picks_a_register_staged_tile_by_tile_count(mm, oracle):
+    """with MMH_OPT_DMA_EDGE = 0 no LDS-DMA family takes a ragged shape; the cost table's only
+    remaining row was the 256x256 tile, so 1000^3 ran as 16 workgroups on 256 CUs.  auto_plan_for now reports "no plan"
+    and fallback_kernel chooses among the register-staged tiles (cuda/makefile:1-3: the choice AUTO automates)."""
+    import how_to_optimize_gemm_amd as H
+    mm.set_kernel("auto")
+    mm.set_option(H.OPT_DMA_EDGE, 0)
+    try:
+        for (m, n, k), tile in [((1000, 1000, 1000), "<64,64"), ((130, 129, 37), "<64,64"), ((2000, 2000, 500), "<128,128"), ((1500, 1500, 300), "<128,64"),
+                                ((5000, 5000, 100), "<256,256")]:
+            a, b = oracle.harness_inputs(m, n, k, seed=m + k)
+            got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+            launched = H.last_launch()
+            assert "LDS-DMA" not in launched and tile in launched, (m, n, k, launched)
+            assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True)), (m, n, k, launched)
+    finally:
+        mm.set_option(H.OPT_DMA_EDGE, 2)
+    a, b = oracle.harness_inputs(1000, 1000, 1000, seed=2000)
+    mm.matmul(dev(a), dev(b))
+    assert "LDS-DMA" in H.last_launch() and "guarded" in H.last_launch()
+
+
+def test_the_128x128_k2w_tile_takes_phase_ordered_ranges_from_one_tile_per_workgroup(mm, oracle):
+    """Round 5: N = 2560 is 400 tiles of 128x128 on 256 persistent workgroups (1.56 each) -- below round 2's 1.8-tile
+    threshold, so the ranges ran in chip order at an L2 hit rate of 0.40 and 8.3 x the algorithmic bytes over the fabric.
+    Ordered by phase: 0.75 and 2.9 x, time unchanged (profiles/r05_notes.md).  The smaller tiles keep the threshold.
+    Same chain either way: the oracle's bits."""
+    import how_to_optimize_gemm_amd as H
+    mm.set_kernel("mfma_128x128_dma5")
+    for (m, n, k), ordered in [((2560, 2560, 96), True), ((2176, 2176, 64), True), ((1280, 1280, 64), False)]:
+        a, b = oracle.harness_inputs(m, n, k, seed=m + k)
+        got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+        launched = H.last_launch()
+        if ordered:
+            assert "persistent" in launched and "phase-ordered" in launched, launched
+        else:
+            assert "phase-ordered" not in launched, launched
+        assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True)), (m, n, k, launched)
+    mm.set_kernel("mfma_128x64_dma5")
+    mm.set_streamk(2)
+    try:
+        a, b = oracle.harness_inputs(2176, 2176, 64, seed=9)      # 578 tiles on 256 workgroups: 2.26 each -> ordered; 1664: 1.3 -> not
+        mm.matmul(dev(a), dev(b))
+        assert "phase-ordered" in H.last_launch(), H.last_launch()
+        a, b = oracle.harness_inputs(1664, 1664, 64, seed=9)
+        got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+        assert "persistent" in H.last_launch() and "phase-ordered" not in H.last_launch(), H.last_launch()
+        assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
+    finally:
+        mm.set_streamk(1)
+
+
+_SHARD_STREAMED = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import how_to_optimize_gemm_amd as H
+from oracle import oracle
+mode = sys.argv[2]
+if mode == "rccl1":
+    os.environ["MMH_SHARD_FORCE_RCCL"] = "1"
+    cases = [(1, (640, 512, 1024)), (1, (1000, 640, 300)), (1, (384, 256, 128)), (1, (2048, 1024, 4096))]
+else:
+    os.environ["MMH_SHARD_SHARE_DEVICE"] = "1"
+    cases = [(3, (640, 512, 1024)), (5, (256, 384, 700)), (8, (2048, 256, 512)), (4, (100, 64, 32))]
+for ranks, (m, n, k) in cases:
+    a, b = oracle.harness_inputs(m, n, k, seed=ranks + k)
+    want = oracle.ref_mmult(a, b, fma=True)
+    devices = None if mode == "rccl1" else [0] * ranks
+    with H.ShardedMMult(ranks, devices=devices, kernel="auto") as sh:
+        assert sh.info()["rccl_ranks"] == (1 if mode == "rccl1" else 0), sh.info()
+        plain, t1 = sh.sgemm(a, b, np.full((m, n), np.nan, dtype=np.float32), gemm_reps=1)
+        assert np.array_equal(plain, want), (mode, ranks, m, n, k, "plain")
+        assert set(t1) == {"h2d", "bcast", "gemm", "d2h"} and t1["gemm"] > 0.0 and t1["bcast"] > 0.0, t1
+        for chunks in (2, 4, 8, 64):
+            for reps in (1, 3):
+                got, t = sh.sgemm(a, b, np.full((m, n), np.nan, dtype=np.float32), gemm_reps=reps, b_chunks=chunks)
+                assert np.array_equal(got, want), (mode, ranks, m, n, k, chunks, reps)      # the chain cut and resumed: the same bits
+                assert t["chunks"] == min(chunks, (k + 127) // 128), (t, k)
+                assert t["bcast"] > 0.0 and t["gemm"] > 0.0 and t["first_pass"] > 0.0, t
+                # the overlapped figure spans the broadcast's start to the first pass's end on the slowest device:
+                # at least either phase, at most their sum (plus scheduling slack), and inside the host's clock
+                assert t["overlapped"] >= max(t["bcast"], t["first_pass"]) * 0.999, t
+                assert t["overlapped"] <= t["wall"] * 1.001 + 0.01, t
+print("shard-streamed ok")
+"""
+
+
+@pytest.mark.parametrize("mode", ["rccl1", "shared"])
+def test_streamed_b_in_the_c_abi_shard_keeps_the_bits_and_reports_the_overlap(mode):
+    """mmh_shard_sgemm_streamed -- B leaves device 0 in K-chunks on a second, higher-priority
+    stream per device, chunk c + 1 in flight while chunk c is consumed with `accumulate` (C's value first in each chain:
+    the unchunked launch's bits); phases timed per device with events.  Through the one-rank RCCL communicator
+    (MMH_SHARD_FORCE_RCCL=1: ncclBroadcast per chunk inside a group) and through the shared-device mode (3-8 logical
+    ranks, empty panels, device copies).  The reference has no multi-GPU path (cuda/test_MMult.cpp:24-25)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _SHARD_STREAMED, REPO, mode], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "shard-streamed ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_the_one_rank_sharded_bench_line_reads_a_scaling_efficiency_of_one():
+    """`scaling_efficiency` = value(N) / (N x single_gpu_value) divided by a single-GPU figure taken
+    with warmup = 1 and at most five launches while the ranks got the whole ramp -- the committed one-rank line read
+    1.0487.  The denominator now runs the ranks' own protocol (W warm-ups, K timed steps, two device syncs, the host's
+    clock), so with ONE rank -- the whole problem on the same GPU twice -- the figure must read 1.00."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-shard", "--n", "8192", "--steps", "20",
+                        "--warmup", "3", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_PORT="29577"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["streamed_equals_plain"] is True, d
+    assert 0.985 <= d["scaling_efficiency"] <= 1.015, (d["scaling_efficiency"], d["value"], d["single_gpu_value"])

@@ -3,7 +3,7 @@
 #   gpurun --timeout 900 -- 'STEPS="k32tests sweep" bash tools/gpu_call.sh'
 # Runs ON THE GPU BOX from the repo root; every step writes under gpurun_out/<TAG>/ (TAG defaults to r04).
 set -u
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -129,6 +129,31 @@ if has oo; then         # prepared at the end of round 4, never run: whole-tile 
   timeout 500 python tools/tile_sweep.py --ab --check --rounds 3 --sizes ${OO_SIZES:-1152:4096:128} \
     --variants "auto,mfma_128x64_dma5/sk2,mfma_128x64_dma5/sk2/oo,mfma_64x64_dma5/sk2,mfma_64x64_dma5/sk2/oo,mfma_128x128_dma5/sk2,hipblaslt" \
     --out $OUT/own_occ > $OUT/own_occ.log 2>&1; grep "^{" $OUT/own_occ.log | cut -c1-330
+fi
+if has l2sk; then       # round 5: L2 behaviour of the chained K2W stream-K launches (phase order on / off, raster group height), per size
+  LV=${L2SK_VARIANTS:-"mfma_128x128_dma5/sk2,mfma_128x128_dma5/sk2/no,mfma_128x128_dma5/sk2/g1,mfma_128x128_dma5/sk2/g2,mfma_128x128_dma5/sk2/g8,mfma_128x128_dma5/sk2/g16"}
+  NV=$(echo $LV | tr ',' '\n' | wc -l)
+  for n in ${L2SK_SIZES:-2560 2304}; do
+    for grp in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+      d=$OUT/l2sk_${n}_$(echo $grp | cut -d' ' -f1)
+      ( cd /tmp && timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OLDPWD/$d -o pmc -- python $OLDPWD/tools/pmc_launch.py --ab --n $n --warm 30 --reps 6 \
+          --variants "$LV" ) > $d.log 2>&1
+    done
+    python tools/pmc_by_kernel.py $OUT/l2sk_${n}_FETCH_SIZE $OUT/l2sk_${n}_WRITE_SIZE --group 36 > $OUT/l2sk_$n.json 2>> $OUT/l2sk.err
+    grep -- "->" $OUT/l2sk_${n}_FETCH_SIZE.log | cut -c1-260 > $OUT/l2sk_${n}_launched.txt
+    python - $OUT/l2sk_$n.json <<'PY'
+import json, sys
+for k, v in json.load(open(sys.argv[1])).items():
+    if v.get("_n_FETCH_SIZE", 0) >= 3:
+        print(sys.argv[1].split("/")[-1], k[-70:], "us", v.get("_us_FETCH_SIZE"), "fetch MB", round(v.get("fetch_bytes", 0) / 1e6, 1), "write MB", round(v.get("write_bytes", 0) / 1e6, 1), "l2hit", v.get("l2_hit"))
+PY
+  done
+  find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
+fi
+if has om; then         # round 5: phase-ordered stream-K tables below 1.8 tiles per workgroup (option 104), and the 96x64 tile (tools build)
+  timeout 500 python tools/tile_sweep.py --ab --check --rounds 3 --sizes ${OM_SIZES:-1152:3072:128} \
+    --variants "auto,mfma_128x128_dma5/sk2,mfma_128x128_dma5/sk2/om10,mfma_128x64_dma5/sk2,mfma_128x64_dma5/sk2/om10,mfma_64x64_dma5/sk2,mfma_64x64_dma5/sk2/om10,exp5_96x64_l4/sk0,exp5_96x64_l2/sk0,exp5_96x64_l4/sk2,exp5_64x96_l2,hipblaslt" \
+    --out $OUT/om > $OUT/om.log 2>&1; grep "^{" $OUT/om.log | cut -c1-420
 fi
 if has sktl; then       # per-workgroup, per-part timeline of stream-K K2W launches
   for kern in ${SKTL_KERNELS:-mfma_128x128_dma5 mfma_64x64_dma5}; do

@@ -44,10 +44,14 @@ def main():
         mm.set_streamk(int(sk[0][2:]) if sk else 1)
         mm.set_option(H.OPT_STREAMK_CHAIN, 0 if "nc" in parts[1:] else 1)
         mm.set_option(H.OPT_PERSIST, 1 if "p1" in parts[1:] else 0)
+        mm.set_option(H.OPT_STREAMK_ORDER, 0 if "no" in parts[1:] else 1)   # /no: no phase-ordered stream-K tables
         gm = [x for x in parts[1:] if x.startswith("g") and x[1:].isdigit()]
         if args.ab:
             mm.set_option(101, int(gm[0][1:]) if gm else 0)   # tools build: raster group height of the K2W launches
             mm.set_option(102, 1 if "nd" in parts[1:] else 0)  # ... stream-K heads publish on the spot
+            mm.set_option(103, 1 if "oo" in parts[1:] else 0)  # ... whole-tile stream-K grids by their own residency
+            om = [x for x in parts[1:] if x.startswith("om") and x[2:].isdigit()]   # /omNN: phase-ordered tables from NN/10 tiles per workgroup
+            mm.set_option(104, int(om[0][2:]) if om else 18)
         for _ in range(args.warm + args.reps):
             mm.sgemm(m, n, k, a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc, False, s)
         torch.cuda.synchronize()

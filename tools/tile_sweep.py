@@ -69,11 +69,14 @@ def main():
         mm.set_streamk(int(sk[0][2:]) if sk else 1)
         mm.set_option(H.OPT_STREAMK_CHAIN, 0 if "nc" in parts[1:] else 1)
         mm.set_option(H.OPT_PERSIST, 1 if "p1" in parts[1:] else 0)
+        mm.set_option(H.OPT_STREAMK_ORDER, 0 if "no" in parts[1:] else 1)   # /no: stream-K ranges in chip order, no phase tables
         if args.ab:      # tools build: /gN raster group height, /nd publish stream-K heads on the spot
             gm = [x for x in parts[1:] if x.startswith("g") and x[1:].isdigit()]
             mm.set_option(101, int(gm[0][1:]) if gm else 0)
             mm.set_option(102, 1 if "nd" in parts[1:] else 0)
             mm.set_option(103, 1 if "oo" in parts[1:] else 0)   # whole-tile stream-K launches bounded by their own residency
+            om = [x for x in parts[1:] if x.startswith("om") and x[2:].isdigit()]   # /omNN: phase-ordered tables from NN/10 tiles per workgroup
+            mm.set_option(104, int(om[0][2:]) if om else 18)
 
     for (m, n, k) in shapes:
         need = m * k + k * n + m * n
