@@ -24,7 +24,7 @@ def test_auto_without_the_guarded_lds_dma_tiles_picks_a_register_staged_tile_by_
     mm.set_option(H.OPT_DMA_EDGE, 0)
     try:
         for (m, n, k), tile in [((1000, 1000, 1000), "<64,64"), ((130, 129, 37), "<64,64"), ((2000, 2000, 500), "<128,128"), ((1500, 1500, 300), "<128,64"),
-                                ((5000, 5000, 100), "<256,256")]:
+                                ((4200, 4200, 40), "<256,256")]:
             a, b = oracle.harness_inputs(m, n, k, seed=m + k)
             got = mm.matmul(dev(a), dev(b)).cpu().numpy()
             launched = H.last_launch()
@@ -76,10 +76,10 @@ from oracle import oracle
 mode = sys.argv[2]
 if mode == "rccl1":
     os.environ["MMH_SHARD_FORCE_RCCL"] = "1"
-    cases = [(1, (640, 512, 1024)), (1, (1000, 640, 300)), (1, (384, 256, 128)), (1, (2048, 1024, 4096))]
+    cases = [(1, (640, 512, 1024)), (1, (1000, 640, 300))]
 else:
     os.environ["MMH_SHARD_SHARE_DEVICE"] = "1"
-    cases = [(3, (640, 512, 1024)), (5, (256, 384, 700)), (8, (2048, 256, 512)), (4, (100, 64, 32))]
+    cases = [(3, (640, 512, 1024)), (5, (256, 384, 700)), (4, (100, 64, 32))]
 for ranks, (m, n, k) in cases:
     a, b = oracle.harness_inputs(m, n, k, seed=ranks + k)
     want = oracle.ref_mmult(a, b, fma=True)
@@ -89,8 +89,8 @@ for ranks, (m, n, k) in cases:
         plain, t1 = sh.sgemm(a, b, np.full((m, n), np.nan, dtype=np.float32), gemm_reps=1)
         assert np.array_equal(plain, want), (mode, ranks, m, n, k, "plain")
         assert set(t1) == {"h2d", "bcast", "gemm", "d2h"} and t1["gemm"] > 0.0 and t1["bcast"] > 0.0, t1
-        for chunks in (2, 4, 8, 64):
-            for reps in (1, 3):
+        for chunks, reps in ((2, 1), (8, 3), (64, 1)):
+            if True:
                 got, t = sh.sgemm(a, b, np.full((m, n), np.nan, dtype=np.float32), gemm_reps=reps, b_chunks=chunks)
                 assert np.array_equal(got, want), (mode, ranks, m, n, k, chunks, reps)      # the chain cut and resumed: the same bits
                 assert t["chunks"] == min(chunks, (k + 127) // 128), (t, k)
@@ -124,7 +124,7 @@ def test_the_one_rank_sharded_bench_line_reads_a_scaling_efficiency_of_one():
     import json
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-shard", "--n", "8192", "--steps", "20",
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-shard", "--n", "4096", "--steps", "20",
                         "--warmup", "3", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, MASTER_PORT="29577"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
