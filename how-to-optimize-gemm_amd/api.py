@@ -35,7 +35,7 @@ OPT_RIM5 = 14
 KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "mfma256": KERNEL_MFMA_256, "naive": KERNEL_NAIVE, "mfma_simple": KERNEL_MFMA_SIMPLE,
            "mfma_pipe": KERNEL_MFMA_PIPE, "mfma_tiles": 10, "mfma_128x64": 8, "mfma_64x64": 11, "mfma_256x256": 12,
-           "valu_128x128": 13, "valu_64x64": 14, "mfma_splitk": 15, "mfma_splitk_128x64": 20,
+           "valu_128x128": 13, "valu_64x64": 14, "valu_128x64": 9, "mfma_splitk": 15, "mfma_splitk_128x64": 20,
            "mfma_64x64_dma": 25, "mfma_128x64_dma": 27, "mfma_128x128_dma": 28,
            "mfma_64x64_dma5": 29, "mfma_128x64_dma5": 30, "mfma_128x128_dma5": 31,
            "mfma_96x96_dma5": 7,
@@ -56,7 +56,7 @@ EXPORTS = [
     "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm", "mmh_shard_sgemm_streamed", "mmh_shard_pin",
     "mmh_shard_unpin",
     "mmh_rccl_version",
-    "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_time_comparator", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_mfma_i8",
+    "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_time_comparator", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_valu_f32", "mmh_probe_mfma_i8",
     "mmh_probe_mfma_i8_sustained", "mmh_probe_hbm_copy", "mmh_probe_hbm_read", "mmh_probe_lds_read", "mmh_streamk_plan", "mmh_auto_plan",
 ]
 
@@ -202,6 +202,7 @@ def lib() -> C.CDLL:
     L.mmh_streamk_plan.argtypes = [C.c_long, C.c_int, C.c_int, ip, ip]
     L.mmh_auto_plan.argtypes = [C.c_int] * 8 + [ip, C.POINTER(C.c_long), ip]
     L.mmh_probe_mfma_f32.argtypes = [vp, fp]
+    L.mmh_probe_valu_f32.argtypes = [vp, C.c_int, C.c_int, fp]
     L.mmh_probe_mfma_i8.argtypes = [vp, fp]
     L.mmh_probe_mfma_i8_sustained.argtypes = [vp, C.c_int, C.c_float, fp]
     L.mmh_probe_hbm_copy.argtypes = [vp, C.c_size_t, fp]
@@ -564,6 +565,12 @@ class MMult:
     def probe_mfma_f32(self) -> float:
         v = C.c_float(0)
         _check(lib().mmh_probe_mfma_f32(self._h, C.byref(v)), "mmh_probe_mfma_f32")
+        return v.value
+
+    def probe_valu_f32(self, packed: bool = True, waves_per_simd: int = 2) -> float:
+        """TFLOP/s of a v_pk_fma_f32-only (packed) or v_fma_f32-only loop: the vector-ALU rung's measured roof."""
+        v = C.c_float(0)
+        _check(lib().mmh_probe_valu_f32(self._h, int(bool(packed)), int(waves_per_simd), C.byref(v)), "mmh_probe_valu_f32")
         return v.value
 
     def probe_mfma_i8(self) -> float:

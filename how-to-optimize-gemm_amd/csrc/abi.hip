@@ -169,6 +169,9 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
                 // their own instantiation's residency (77 / 117 registers: three / two workgroups per CU) instead of the guarded one's
       h->ab_own_occ = value ? 1 : 0;
       return MMH_OK;
+    case 105:   // A/B: the vector-ALU rung as it was before round 5 (register-staged K1) instead of K1W
+      h->ab_valu_old = value ? 1 : 0;
+      return MMH_OK;
     case 104:   // A/B: phase-ordered stream-K tables from this many tiles per workgroup, in tenths (product: 18)
       if (value < 10 || value > 1000) return MMH_ERR_INVALID_ARG;
       h->sk_order_min10 = value;
@@ -230,6 +233,7 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_VALU: return "MMult_hip_valu";
     case MMH_KERNEL_VALU_128X128: return "MMult_hip_valu_128x128";
     case MMH_KERNEL_VALU_64X64: return "MMult_hip_valu_64x64";
+    case MMH_KERNEL_VALU_128X64: return "MMult_hip_valu_128x64";
     case MMH_KERNEL_MFMA: return "MMult_hip_mfma";
     case MMH_KERNEL_MFMA_256: return "MMult_hip_mfma256";
     case MMH_KERNEL_NAIVE: return "MMult_hip_naive";
@@ -302,6 +306,12 @@ const char *mmh_kernel_name(int kernel) {
     case 83: return "exp5_96x64_l4";
     case 84: return "exp5_96x64_l2";
     case 85: return "exp5_64x96_l2";
+    case 87: return "k1w_128x128_b3l2a4";
+    case 89: return "k1w_64x64_a2";
+    case 91: return "k1w_64x128";
+    case 92: return "k1w_64x64_a4";
+    case 93: return "k1w_128x128_b2l4a2";
+    case 94: return "k1w_128x128_b2l1a2";
 #endif
     default: return nullptr;
   }

@@ -4,6 +4,7 @@
 
 #include "launch_common.hpp"
 #include "sgemm_valu.hpp"
+#include "sgemm_valu_dma5.hpp"
 
 namespace mmh {
 namespace {
@@ -28,25 +29,89 @@ int launch_valu_tile_p(const GemmArgs &g) {
   return MMH_OK;
 }
 
-int valu_prefetch(int def) {   // A/B switch while measuring: MMH_VALU_P=1|2|4
-  static const int v = [] { const char *e = std::getenv("MMH_VALU_P"); return e ? atoi(e) : 0; }();
-  return (v == 1 || v == 2 || v == 4) ? v : def;
+// K1W (sgemm_valu_dma5.hpp, round 5): the same rung with the staging done by loader waves' LDS-DMA.  Whole tiles only:
+// returns 1 when the shape is not one (the caller then launches K1's guarded instantiation).
+template <int BM, int BN, int NBUF, int NL, int P, int AK, int WPE>
+int launch_valu_w(const GemmArgs &g) {
+  using V = ValuDma5<BM, BN, NBUF, NL, P, AK>;
+  if (!fast_shape(BM, BN, 32, g) || !window_ok(BM, BN, g.k, g.lda, g.ldb)) return 1;
+  const int nbm = g.m / BM, nbn = g.n / BN;
+  auto kern = sgemm_valu_dma5_kernel<BM, BN, NBUF, NL, P, AK, WPE>;
+  const int ok = allow_big_lds(kern, V::LDS_BYTES);
+  if (ok != MMH_OK) return ok;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(V::THREADS), V::LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda, g.B, g.ldb, g.C,
+                     g.ldc, g.acc, nbm, nbn);
+  HIP_TRY(hipGetLastError());
+  char buf[224];
+  snprintf(buf, sizeof buf,
+           "sgemm_valu_dma5_kernel<%d,%d> thread tile %dx%d on v_pk_fma_f32, K-slice 32 x %d ring buffers by %d loader waves' LDS-DMA, "
+           "%d workgroups of %d threads", BM, BN, BM / 16, BN / 16, NBUF, NL, nbm * nbn, V::THREADS);
+  set_last_launch(buf);
+  return MMH_OK;
 }
 
-// fragment look-ahead: the 64x64 tile runs one wave per SIMD on its small shapes (32 cycles of FMAs per k-step against
-// an LDS round trip of > 100), the 128x128 tile two (128 cycles per k-step each)
-template <int BM, int BN, int KB, int NBUF>
-int launch_valu_tile(const GemmArgs &g) {
-  switch (valu_prefetch(BM == 64 ? 4 : 1)) {
-    case 1: return launch_valu_tile_p<BM, BN, KB, NBUF, 1>(g);
-    case 2: return launch_valu_tile_p<BM, BN, KB, NBUF, 2>(g);
-    default: return launch_valu_tile_p<BM, BN, KB, NBUF, 4>(g);
-  }
-}
-
-int valu_nbuf() {   // A/B switch while measuring: MMH_VALU_NBUF=2 -> the double-buffered form
-  static const int v = [] { const char *e = std::getenv("MMH_VALU_NBUF"); return e && *e == '2' ? 2 : 1; }();
+int valu_w() {   // MMH_VALU_W=0: K1 as it was before round 5 (register-staged), for A/B
+  static const int v = [] { const char *e = std::getenv("MMH_VALU_W"); return e && *e == '0' ? 0 : 1; }();
   return v;
+}
+
+// fragment look-ahead of the register-staged K1 (round 4, measured): the 64x64 tile runs one wave per SIMD on its small
+// shapes (32 cycles of FMAs per k-step against an LDS round trip of > 100): four k-steps; the 128x128 tile two waves (128
+// cycles per k-step each): one.  One LDS slice, the next one parked in registers (NBUF = 1).  (The P = 1 / 2 / 4 and
+// NBUF = 2 instantiations behind MMH_VALU_P / MMH_VALU_NBUF left with round 5: K1W is the whole-tile path now.)
+template <int BM, int BN, int KB>
+int launch_valu_tile(const GemmArgs &g) {
+  return launch_valu_tile_p<BM, BN, KB, 1, (BM == 64 ? 4 : 1)>(g);
+}
+
+// a K1 tile: K1W on whole-tile shapes, K1's own (guarded or not) instantiation otherwise
+int launch_k1_128(const mmh_context *ctx, const GemmArgs &g) {
+  const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
+  const long tiles = (long)((g.m + 127) / 128) * ((g.n + 127) / 128);
+  // (from four tiles per CU the register-staged K1 is 1-3 % ahead -- N = 4096 / 6144: 92.9 / 94.4 against 91.8 / 91.9:
+  // two loader waves per workgroup take issue slots from the FMA waves of two SIMDs and there is no round left to
+  // fill; below that K1W leads by 8 % (2048) to 17 % (1536): profiles/r05_notes.md)
+  if (valu_w() && !(ctx && ctx->ab_valu_old) && tiles < 4 * cus) {
+    const int w = launch_valu_w<128, 128, 2, 2, 2, 2, 3>(g);   // 64 KiB ring, 168 registers: two workgroups per CU
+    if (w <= 0) return w;
+  }
+  return launch_valu_tile<128, 128, 32>(g);
+}
+int launch_k1_128x64(const mmh_context *ctx, const GemmArgs &g) {   // (K1W only: 72 KiB ring, 128 registers: two per CU)
+  if (valu_w() && !(ctx && ctx->ab_valu_old)) {
+    const int w = launch_valu_w<128, 64, 3, 2, 2, 2, 3>(g);
+    if (w <= 0) return w;
+  }
+  return launch_k1_128(ctx, g);
+}
+int launch_k1_64(const mmh_context *ctx, const GemmArgs &g) {
+  if (valu_w() && !(ctx && ctx->ab_valu_old)) {
+    // 48 KiB ring, 76-84 registers: three workgroups per CU.  A read as ds_read_b64 (two k-steps) where a CU holds ONE
+    // workgroup -- one wave per SIMD: N = 1024 71.7 against 63.2 TFLOP/s -- as ds_read_b128 (four) otherwise (1536: 66.6
+    // against 63.0, 4096: 81.0 against 77.5)
+    const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
+    const long tiles = (long)((g.m + 63) / 64) * ((g.n + 63) / 64);
+    const int w = tiles <= cus ? launch_valu_w<64, 64, 3, 2, 2, 2, 5>(g) : launch_valu_w<64, 64, 3, 2, 2, 4, 5>(g);
+    if (w <= 0) return w;
+  }
+  return launch_valu_tile<64, 64, 64>(g);
+}
+
+// MMH_KERNEL_VALU's tile (round 5): a tile family runs at its chip-full rate R times the share of its last round that
+// is filled, counted per CU -- (tiles / CUs) / ceil(tiles / CUs): a lone workgroup has its CU's vector ALUs to itself
+// and runs about as fast as two sharing them, so what a ragged count costs is the CUs left idle while the fullest one
+// finishes.  R measured at whole-round sizes: 93 (128x128), 86 (128x64), 80 (64x64) TFLOP/s.  Picks the measured best
+// tile at 12 of 13 sizes of the sweep 1024 .. 4096 step 256 (3072: the 64x64 tile at 78 where 128x64 reaches 83.5).
+int k1_pick_tile(const mmh_context *ctx, const GemmArgs &g) {
+  const double cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
+  auto est = [&](int bm, int bn, double rate) {
+    const double per_cu = (double)((g.m + bm - 1) / bm) * ((g.n + bn - 1) / bn) / cus;
+    const double rounds = (double)(long)(per_cu + 0.999999);
+    return rate * per_cu / (rounds < 1.0 ? 1.0 : rounds);
+  };
+  const double e128 = est(128, 128, 93.0), e12864 = est(128, 64, 86.0), e64 = est(64, 64, 80.0);
+  if (e128 >= e12864 && e128 >= e64) return MMH_KERNEL_VALU_128X128;
+  return e12864 >= e64 ? MMH_KERNEL_VALU_128X64 : MMH_KERNEL_VALU_64X64;
 }
 
 int launch_naive(const GemmArgs &g) {
@@ -63,24 +128,35 @@ int launch_valu(mmh_context *ctx, int kernel, const GemmArgs &g) {
   const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
   const long tiles128 = (long)((g.m + 127) / 128) * ((g.n + 127) / 128);
   switch (kernel) {
-    case MMH_KERNEL_VALU:
-      // K1: the 128x128 rung, or the 64x64 tile where its rounds are cheaper -- a round of 64x64 tiles (one per CU;
-      // ~76 TFLOP/s when the chip is full) costs 0.31 of a round of 128x128 tiles (~92): measured round 4, N = 1024 ..
-      // 4096 step 256 (tools/tile_sweep.py --variants valu,valu_64x64,valu_128x128): 64x64 ahead at 1024 / 1280 / 1536 /
-      // 2304 / 3072 (58 / 61 / 60 / 68 / 78 against 22 / 35 / 50 / 65 / 74), 128x128 elsewhere
-      {
+    case MMH_KERNEL_VALU:   // K1: the tile by rounds (k1_pick_tile); whole-tile shapes on K1W, the others on K1's guarded kernels
+      switch (fast_shape(64, 64, 32, g) ? k1_pick_tile(ctx, g) : 0) {
+        case MMH_KERNEL_VALU_128X128: return launch_k1_128(ctx, g);
+        case MMH_KERNEL_VALU_128X64: return launch_k1_128x64(ctx, g);
+        case MMH_KERNEL_VALU_64X64: return launch_k1_64(ctx, g);
+        default: break;
+      }
+      {   // ragged / unaligned: K1's guarded tiles, the 64x64 one where its rounds are cheaper (round 4's rule)
         const long tiles64 = (long)((g.m + 63) / 64) * ((g.n + 63) / 64);
         const long rounds64 = (tiles64 + cus - 1) / cus, rounds128 = (tiles128 + cus - 1) / cus;
-        if (rounds64 * 10 < rounds128 * 32)
-          return valu_nbuf() == 2 ? launch_valu_tile<64, 64, 64, 2>(g) : launch_valu_tile<64, 64, 64, 1>(g);
+        if (rounds64 * 10 < rounds128 * 32) return launch_k1_64(ctx, g);
       }
-      return valu_nbuf() == 2 ? launch_valu_tile<128, 128, 32, 2>(g) : launch_valu_tile<128, 128, 32, 1>(g);
+      return launch_k1_128(ctx, g);
     case MMH_KERNEL_VALU_128X128:
-      return valu_nbuf() == 2 ? launch_valu_tile<128, 128, 32, 2>(g) : launch_valu_tile<128, 128, 32, 1>(g);
+      return launch_k1_128(ctx, g);
     case MMH_KERNEL_VALU_64X64:
-      return valu_nbuf() == 2 ? launch_valu_tile<64, 64, 64, 2>(g) : launch_valu_tile<64, 64, 64, 1>(g);
+      return launch_k1_64(ctx, g);
+    case MMH_KERNEL_VALU_128X64:
+      return launch_k1_128x64(ctx, g);
     case MMH_KERNEL_NAIVE:
       return launch_naive(g);
+#ifdef MMH_AB_BUILD   // K1W variants measured in round 5 (profiles/r05_notes.md): ring depth / loaders / A read width
+    case 87: return launch_valu_w<128, 128, 3, 2, 2, 4, 2>(g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;   // one workgroup per CU, 96 KiB ring
+    case 93: return launch_valu_w<128, 128, 2, 4, 2, 2, 3>(g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;   // four loaders
+    case 94: return launch_valu_w<128, 128, 2, 1, 2, 2, 3>(g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;   // one loader
+    case 89: return launch_valu_w<64, 64, 3, 2, 2, 2, 5>(g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;     // ds_read_b64 A reads whatever the tile count
+    case 92: return launch_valu_w<64, 64, 3, 2, 2, 4, 5>(g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;     // ds_read_b128 A reads ...
+    case 91: return launch_valu_w<64, 128, 3, 2, 2, 4, 3>(g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;    // 64x128: level with 128x64
+#endif
     default:
       set_last_error("unknown kernel variant");
       return MMH_ERR_INVALID_ARG;

@@ -165,6 +165,7 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
     case MMH_KERNEL_VALU:
     case MMH_KERNEL_VALU_128X128:
     case MMH_KERNEL_VALU_64X64:
+    case MMH_KERNEL_VALU_128X64:
     case MMH_KERNEL_NAIVE:
       return launch_valu(ctx, kernel, g);
     case MMH_KERNEL_MFMA_64X64_DMA: {   // K2L; shapes it does not take run the register-staged tile of the same size
@@ -238,6 +239,8 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return launch_dma32(ctx, kernel, g);
     case 64: case 65: case 66: case 67: case 68: case 69: case 72: case 79: case 80: case 81: case 82: case 83: case 84: case 85:
       return launch_dma5(ctx, kernel, g);
+    case 87: case 89: case 91: case 92: case 93: case 94:
+      return launch_valu(ctx, kernel, g);
 #endif
     default:
       return launch_reg(ctx, kernel, g);

@@ -54,6 +54,62 @@ int probe_mfma_f32(int cu_count, float *tflops) {
   return MMH_OK;
 }
 
+// The vector ALU's fp32 FMA rate and nothing else (round 5: the denominator of the K1 / K1W rung): 32 independent
+// accumulator pairs per lane, `waves` waves per SIMD, random-ish operands so that the power manager sees real toggling.
+// packed: v_pk_fma_f32 (two FMAs per lane and instruction); otherwise v_fma_f32.
+template <bool PACKED>
+__global__ void __launch_bounds__(1024) probe_valu_kernel(float *out, int iters, float seed) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = f32x2{seed * (float)(i + 1), seed * (float)(threadIdx.x + i)};
+  f32x2 a = {1.0f + seed * (float)threadIdx.x, 1.0f - seed * (float)threadIdx.x}, b = {seed, -seed};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if constexpr (PACKED) {
+        acc[i] = __builtin_elementwise_fma(a, b, acc[i]);
+      } else {
+        acc[i][0] = __builtin_fmaf(a[0], b[0], acc[i][0]);
+        acc[i][1] = __builtin_fmaf(a[1], b[1], acc[i][1]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; i += 2) asm volatile("" : "+v"(acc[i]), "+v"(acc[i + 1]));
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) s += acc[i][0] + acc[i][1];
+  if (s == 12345.678f) out[0] = s;
+}
+
+int probe_valu_f32(int cu_count, int packed, int waves_per_simd, float *tflops) {
+  if (cu_count <= 0) cu_count = 256;
+  float *d = nullptr;
+  MMH_HIP_TRY(hipMalloc(&d, 64));
+  const int iters = 20000, blocks = cu_count, threads = 256 * waves_per_simd;
+  hipEvent_t t0, t1;
+  MMH_HIP_TRY(hipEventCreate(&t0));
+  MMH_HIP_TRY(hipEventCreate(&t1));
+  auto launch = [&](int n) {
+    if (packed) hipLaunchKernelGGL(probe_valu_kernel<true>, dim3(blocks), dim3(threads), 0, 0, d, n, 0.001f);
+    else hipLaunchKernelGGL(probe_valu_kernel<false>, dim3(blocks), dim3(threads), 0, 0, d, n, 0.001f);
+  };
+  for (int w = 0; w < 3; ++w) launch(iters);      // ~10 ms: the power manager's sustained state
+  MMH_HIP_TRY(hipEventRecord(t0, 0));
+  launch(iters);
+  MMH_HIP_TRY(hipEventRecord(t1, 0));
+  MMH_HIP_TRY(hipEventSynchronize(t1));
+  float ms = 0.f;
+  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+  const double flops = (double)blocks * threads * iters * 64.0 * 2.0;
+  *tflops = (float)(flops / (ms * 1e-3) / 1e12);
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  (void)hipFree(d);
+  return MMH_OK;
+}
+
 // int8 twin: v_mfma_i32_16x16x64_i8 only (what K3 issues), 8 accumulators per wave
 typedef int pi32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -306,6 +362,12 @@ int mmh_probe_mfma_f32(mmh_handle_t h, float *tflops) {
   if (!h || !tflops) return MMH_ERR_INVALID_ARG;
   ENTER(h);
   return probe_mfma_f32(h->cu_count, tflops);
+}
+
+int mmh_probe_valu_f32(mmh_handle_t h, int packed, int waves_per_simd, float *tflops) {
+  if (!h || !tflops || waves_per_simd < 1 || waves_per_simd > 4) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  return probe_valu_f32(h->cu_count, packed, waves_per_simd, tflops);
 }
 
 int mmh_probe_mfma_i8(mmh_handle_t h, float *tops) {

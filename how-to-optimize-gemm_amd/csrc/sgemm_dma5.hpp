@@ -59,7 +59,7 @@ struct Dma5Tile {
   static_assert(KB == 32, "a K-slice row of A is 128 bytes: a piece of A is eight rows");
   static_assert(BM == 32 * WTM && BN == 32 * WTN, "four consumer waves as 2 x 2, wave tile 16 WTM x 16 WTN");
   static_assert(WTM >= 2 && WTM <= 6 && WTN >= 2 && WTN <= 6, "wave tile 32 .. 96 rows / columns");
-  static_assert(NBUF >= 3 && NBUF <= 6, "ring depth");
+  static_assert(NBUF >= 2 && NBUF <= 6, "ring depth (2: the next slice is requested after barrier kt - 1 and waited for before barrier kt -- K1W's two co-resident workgroups)");
   static_assert(NL == 1 || NL == 2 || NL == 4, "one, two or four loader waves");
   static constexpr int CONSUMERS = 4, LOADER = 4;   // wave index of the first loader
   static constexpr int WAVES_M = 2, WAVES_N = 2;

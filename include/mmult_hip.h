@@ -71,10 +71,13 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_AUTO 0        /* the K2W tiles (64x64 / 96x96 / 128x64 / 128x128) or the 256x256 tile, plain or
                                     stream-K: whichever a cost table fitted to measurements prices lowest for
                                     the shape (csrc/policy.hip, mmh_auto_plan) */
-#define MMH_KERNEL_VALU 1        /* K1: LDS-tiled, VALU fma only: the 128x128 tile (8x8 per thread) or the 64x64 tile
-                                    (4x4 per thread), whichever has the cheaper rounds                  */
+#define MMH_KERNEL_VALU 1        /* K1: LDS-tiled, VALU fma only: the 128x128 (8x8 outputs per thread), 128x64 or 64x64 (4x4)
+                                    tile, whichever fills its last round of CUs best.  Whole-tile shapes run K1W (round 5:
+                                    the staging done by loader waves' LDS-DMA, csrc/sgemm_valu_dma5.hpp), the others K1's
+                                    guarded register-staged kernels; the same chain, the same bits */
 #define MMH_KERNEL_VALU_128X128 13 /* K1 with the 128x128 tile always (the rung BASELINE config 2 names) */
 #define MMH_KERNEL_VALU_64X64 14   /* K1 with the 64x64 tile always                                      */
+#define MMH_KERNEL_VALU_128X64 9   /* K1W's 128x64 tile (8x4 outputs per thread; whole-tile shapes -- others run 128x128) */
 #define MMH_KERNEL_MFMA 2        /* K2: 128x128 block tile on v_mfma_f32_16x16x4_f32; K-slice
                                     hand-over pipelined across the barrier, staging ops dealt
                                     out between MFMAs, buffer-descriptor loads; tile counts
@@ -425,6 +428,9 @@ int mmh_trace_sgemm(mmh_handle_t handle, int m, int n, int k, const float *dA, i
  * non-temporal; read+write bytes) and HBM read GB/s (read-only twin, eight loads in flight). */
 int mmh_probe_mfma_f32(mmh_handle_t handle, float *tflops);
 int mmh_probe_mfma_i8(mmh_handle_t handle, float *tops);   /* v_mfma_i32_16x16x64_i8 only */
+/* The vector ALU's fp32 FMA rate: v_pk_fma_f32 (packed != 0) or v_fma_f32 only, 64 independent accumulators per lane,
+ * waves_per_simd (1..4) waves on every SIMD, no memory traffic -- the measured denominator of the K1 / K1W rung. */
+int mmh_probe_valu_f32(mmh_handle_t handle, int packed, int waves_per_simd, float *tflops);
 /* The same loop run back to back for at least `min_ms` (0..2000), reporting the last 2.3 ms launch:
  * random_operands != 0 gives every MFMA different pseudo-random inputs (the rate the power
  * manager sustains on real data), 0 keeps the constant operands of mmh_probe_mfma_i8. */

@@ -131,3 +131,48 @@ def test_the_one_rank_sharded_bench_line_reads_a_scaling_efficiency_of_one():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["streamed_equals_plain"] is True, d
     assert 0.985 <= d["scaling_efficiency"] <= 1.015, (d["scaling_efficiency"], d["value"], d["single_gpu_value"])
+
+
+@pytest.mark.parametrize("kernel,tile", [("valu_128x128", 128), ("valu_128x64", 128), ("valu_64x64", 64), ("valu", 0)])
+def test_k1w_the_vector_alu_rung_with_loader_waves_is_the_same_chain(mm, oracle, kernel, tile):
+    """K1W (csrc/sgemm_valu_dma5.hpp, round 5; BASELINE.json configs[1], the analogue of cuda/MMult_cuda_3.cu:10-53 ...
+    MMult_cuda_9.cu:30-125): the LDS-tiled no-MFMA rung with its global -> LDS staging done by loader waves' LDS-DMA
+    and consumers that issue ds_read + v_pk_fma_f32 only.  One fused multiply-add per element and k in ascending k: the
+    oracle's fused chain, bit for bit -- one slice, slice counts on every phase of the two- and three-deep rings,
+    overwrite and accumulate, leading dimensions larger than the rows.  Ragged shapes stay on K1's guarded kernel."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    mm.set_kernel(kernel)
+    t = tile or 64
+    shapes = [(t, t, 32), (t, 2 * t, 64), (2 * t, t, 96), (256, 384, 128), (128, 256, 160), (384, 128, 192), (256, 256, 224),
+              (512, 512, 512), (1024, 1024, 1024), (128 * 3, 128 * 5, 32 * 9)]
+    for (m, n, k) in shapes:
+        a, b = oracle.harness_inputs(m, n, k, seed=3 * m + 5 * n + k)
+        got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+        launched = H.last_launch()
+        assert "sgemm_valu_dma5_kernel" in launched, (m, n, k, launched)
+        want = oracle.ref_mmult(a, b, fma=True)
+        assert np.array_equal(got, want), (kernel, m, n, k, float(np.abs(got - want).max()), launched)
+        c0 = np.random.default_rng(k).uniform(-1, 1, (m, n)).astype(np.float32)
+        out = dev(c0)
+        mm.matmul(dev(a), dev(b), out=out, accumulate=True)
+        assert np.array_equal(out.cpu().numpy(), oracle.ref_mmult(a, b, c0.copy(), fma=True)), (kernel, m, n, k)
+    # padded leading dimensions (multiples of four floats), NaN in the padding and around C
+    m, n, k = 256, 384, 128
+    a, b = oracle.harness_inputs(m, n, k, seed=77)
+    abuf = torch.full((m, k + 8), float("nan"), device="cuda")
+    bbuf = torch.full((k, n + 4), float("nan"), device="cuda")
+    cbuf = torch.full((m, n + 12), float("nan"), device="cuda")
+    abuf[:, :k] = dev(a)
+    bbuf[:, :n] = dev(b)
+    mm.matmul(abuf[:, :k], bbuf[:, :n], out=cbuf[:, :n])
+    assert "sgemm_valu_dma5_kernel" in H.last_launch(), H.last_launch()
+    assert np.array_equal(cbuf[:, :n].cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
+    assert torch.isnan(cbuf[:, n:]).all()
+    # ragged: K1's guarded instantiation, the same bits
+    for (m, n, k) in [(130, 129, 37), (1000, 1000, 100)]:
+        a, b = oracle.harness_inputs(m, n, k, seed=m)
+        got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+        assert "sgemm_valu_kernel" in H.last_launch() and "guarded" in H.last_launch(), H.last_launch()
+        assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
+    mm.set_kernel("auto")

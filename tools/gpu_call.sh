@@ -155,6 +155,11 @@ if has om; then         # round 5: phase-ordered stream-K tables below 1.8 tiles
     --variants "auto,mfma_128x128_dma5/sk2,mfma_128x128_dma5/sk2/om10,mfma_128x64_dma5/sk2,mfma_128x64_dma5/sk2/om10,mfma_64x64_dma5/sk2,mfma_64x64_dma5/sk2/om10,exp5_96x64_l4/sk0,exp5_96x64_l2/sk0,exp5_96x64_l4/sk2,exp5_64x96_l2,hipblaslt" \
     --out $OUT/om > $OUT/om.log 2>&1; grep "^{" $OUT/om.log | cut -c1-420
 fi
+if has k1w; then        # round 5: K1W (the vector-ALU rung with loader waves) against K1, variants of ring depth / loaders / A read width / tile
+  timeout 600 python tools/tile_sweep.py --ab --check --rounds 3 --sizes ${K1W_SIZES:-1024:4096:256} \
+    --variants "valu/k1old,valu,valu_128x128/k1old,valu_128x128,valu_64x64/k1old,valu_64x64,k1w_128x128_b3l2a4,k1w_128x128_b3l4a4,k1w_128x128_b2l4a2,k1w_64x64_a2,k1w_128x64,k1w_64x128" \
+    --out $OUT/k1w > $OUT/k1w.log 2>&1; grep "^{" $OUT/k1w.log | cut -c1-520
+fi
 if has sktl; then       # per-workgroup, per-part timeline of stream-K K2W launches
   for kern in ${SKTL_KERNELS:-mfma_128x128_dma5 mfma_64x64_dma5}; do
     timeout 600 python tools/sk_timeline.py --kernel $kern --shape ${SKTL_SHAPES:-2304,2304,2304 1152,1152,1152} > $OUT/sktl_$kern.txt 2>&1

@@ -50,6 +50,7 @@ def main():
             mm.set_option(101, int(gm[0][1:]) if gm else 0)   # tools build: raster group height of the K2W launches
             mm.set_option(102, 1 if "nd" in parts[1:] else 0)  # ... stream-K heads publish on the spot
             mm.set_option(103, 1 if "oo" in parts[1:] else 0)  # ... whole-tile stream-K grids by their own residency
+            mm.set_option(105, 1 if "k1old" in parts[1:] else 0)   # /k1old: the register-staged K1 of rounds 1-4
             om = [x for x in parts[1:] if x.startswith("om") and x[2:].isdigit()]   # /omNN: phase-ordered tables from NN/10 tiles per workgroup
             mm.set_option(104, int(om[0][2:]) if om else 18)
         for _ in range(args.warm + args.reps):
