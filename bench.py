@@ -64,6 +64,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 fl
 METRIC = "GFLOPS vs N (square SGEMM sweep); % of MI355X fp32 MFMA peak at N=4096"
 RAMP = 400                        # per-launch traced launches that open the run (the clock ramp), at most
 RAMP_SECONDS = 0.5                # ... and about this long (a 16384-row panel takes tens of ms per launch)
+SETTLE_MS = 150.0                 # sharded runs: untimed launches in front of the W warm-ups of BOTH timed regions (ranks, single-GPU reference)
 
 
 def parse_args():
@@ -346,6 +347,19 @@ def main():
         if rows:
             mm.sgemm(rows, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, False, stream)
 
+    # N > 1 / --force-shard: the broadcast phases above leave the chip idle between their host synchronisations, and W
+    # warm-ups of a sub-millisecond launch do not bring the clock back: untimed launches for ~SETTLE_MS first -- the SAME
+    # lead-in the single-GPU reference below gets, so that `scaling_efficiency` compares like with like (one rank at
+    # N = 4096 read 0.919 without it: 139 TF after the broadcast phases against 152 TF right behind the timed region)
+    def settle(fn):
+        count, t_s = 0, time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < SETTLE_MS:
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize()
+            count += 4
+        return count
+    settle_launches = settle(step) if (sharded and rows) else 0
     for _ in range(args.warmup):
         step()
     if dist:
@@ -388,6 +402,7 @@ def main():
                     # efficiency as 1.0487): W warm-up steps, then K timed steps between two device syncs on the host's clock
                     def whole():
                         mm.sgemm(m, n, n, a1.data_ptr(), n, b.data_ptr(), n, c1.data_ptr(), n, False, stream)
+                    settle(whole)
                     for _ in range(args.warmup):
                         whole()
                     torch.cuda.synchronize()
@@ -470,7 +485,7 @@ def main():
             "data": "synthetic uniform [-1,1) fp32, seeded on device",
             "config": {"workload": workload, "m": m, "n": n, "k": n, "kernel": H.kernel_name(mm.get_kernel()),
                        "parallelism": parallelism, "rows_per_rank": rows},
-            "ramp_launches": len(trace), "untimed_launches": len(trace) + args.warmup,
+            "ramp_launches": len(trace), "untimed_launches": len(trace) + settle_launches + args.warmup,
             "cold": {
                 "what": f"per-launch hipEvent trace of this process's first {len(trace)} launches (rank 0's panel)",
                 "launch_1_ms": round(trace[0], 4) if trace else None,
@@ -494,6 +509,7 @@ def main():
                          "algorithmic_bytes_per_launch": 4.0 * (rows * n + n * n + rows * n)},
         }
         if sharded:
+            out["settle_launches"] = settle_launches          # untimed, in front of the W warm-ups (and of the single-GPU reference's)
             out["rccl_ranks"] = dist.get_world_size()
             out["backend"] = str(dist.get_backend())
             out["bcast_ms"] = round(bcast_ms, 3)

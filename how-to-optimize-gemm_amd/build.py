@@ -41,8 +41,14 @@ def library_sources() -> list[str]:
     return out
 
 
-def translation_units() -> list[str]:
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+AB_SRC = os.path.join(REPO, "tools", "ab")   # tile families that were built, measured and lost: tools build only
+
+
+def translation_units(ab: bool = False) -> list[str]:
+    tus = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    if ab and os.path.isdir(AB_SRC):
+        tus += sorted(os.path.join(AB_SRC, f) for f in os.listdir(AB_SRC) if f.endswith(".hip"))
+    return tus
 
 
 def _build_shared(target: str, defines: list[str], objdir: str, force: bool, verbose: bool) -> str:
@@ -50,12 +56,17 @@ def _build_shared(target: str, defines: list[str], objdir: str, force: bool, ver
     then link them into `target`.  Objects live under build/<objdir>/ (git-ignored) and are reused while
     neither their .hip nor any header has changed."""
     from concurrent.futures import ThreadPoolExecutor
+    ab = "-DMMH_AB_BUILD" in defines
     headers = [s for s in library_sources() if s.endswith((".hpp", ".h", ".inc"))]
+    if ab and os.path.isdir(AB_SRC):
+        headers += [os.path.join(AB_SRC, f) for f in sorted(os.listdir(AB_SRC)) if f.endswith((".hpp", ".inc"))]
     odir = os.path.join(PKG_DIR, "build", objdir)
     os.makedirs(odir, exist_ok=True)
-    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + defines
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I" + CSRC] + defines
+    if ab:
+        flags.append("-I" + AB_SRC)
     jobs = []
-    for tu in translation_units():
+    for tu in translation_units(ab):
         obj = os.path.join(odir, os.path.basename(tu)[:-4] + ".o")
         if force or _stale(obj, [tu] + headers):
             jobs.append([hipcc()] + flags + ["-c", tu, "-o", obj])
@@ -66,7 +77,7 @@ def _build_shared(target: str, defines: list[str], objdir: str, force: bool, ver
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
             list(pool.map(run, jobs))
-    objs = [os.path.join(odir, os.path.basename(tu)[:-4] + ".o") for tu in translation_units()]
+    objs = [os.path.join(odir, os.path.basename(tu)[:-4] + ".o") for tu in translation_units(ab)]
     if force or jobs or _stale(target, objs + [os.path.join(CSRC, "exports.map")]):
         run([hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs +
             ["-o", target, "-ldl", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")])

@@ -250,6 +250,7 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_128X64_DMA5: return "MMult_hip_mfma_128x64_dma5";
     case MMH_KERNEL_MFMA_128X128_DMA5: return "MMult_hip_mfma_128x128_dma5";
     case MMH_KERNEL_MFMA_96X96_DMA5: return "MMult_hip_mfma_96x96_dma5";
+    case MMH_KERNEL_MFMA_96X64_DMA5: return "MMult_hip_mfma_96x64_dma5";
     case MMH_KERNEL_MFMA_SPLITK: return "MMult_hip_mfma_splitk";
     case MMH_KERNEL_MFMA_SPLITK_128X64: return "MMult_hip_mfma_splitk_128x64";
 #ifdef MMH_AB_BUILD

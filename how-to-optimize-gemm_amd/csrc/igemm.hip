@@ -4,9 +4,9 @@
 // Part of libmmult_hip.so (see internal.hpp).
 #include <algorithm>
 
+#include "internal.hpp"   // (first: kAbBuild)
 #include "igemm_s8.hpp"
 #include "igemm_s8_pp.hpp"
-#include "internal.hpp"
 #include "quant_s8.hpp"
 
 using namespace mmh;

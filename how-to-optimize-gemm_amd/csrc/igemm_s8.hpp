@@ -844,15 +844,15 @@ inline hipError_t launch_igemm_s8(int m, int n, int k, const int8_t *A, int lda,
     const bool whole256 = (m % 256 == 0) && (n % 256 == 0) && (ldc % 4 == 0) &&
                           ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
     if (mode >= 10 && !whole256) return hipErrorInvalidValue;
+    if constexpr (kAbBuild) {   // timing-only ablations: libmmult_hip_ab.so (tools/) only
+      if (mode == 10) return launch_igemm_s8_dma_edge<256, 256, 8, false, 1>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+      if (mode == 11) return launch_igemm_s8_dma_edge<256, 256, 8, false, 2>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+      if (mode == 12) return launch_igemm_s8_dma_edge<256, 256, 8, false, 3>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+      if (mode == 13) return launch_igemm_s8_dma_edge<256, 256, 8, false, 4>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
+    }
     switch (mode) {
       case 3: return launch_igemm_s8_dma<128, 128, 4>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
       case 4: return launch_igemm_s8_dma<256, 256, 8>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
-#ifdef MMH_AB_BUILD   // timing-only ablations: libmmult_hip_ab.so (tools/) only
-      case 10: return launch_igemm_s8_dma_edge<256, 256, 8, false, 1>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
-      case 11: return launch_igemm_s8_dma_edge<256, 256, 8, false, 2>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
-      case 12: return launch_igemm_s8_dma_edge<256, 256, 8, false, 3>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
-      case 13: return launch_igemm_s8_dma_edge<256, 256, 8, false, 4>(m, n, k, A, lda, bt_ws, kpi, npi, C, ldc, acc, s);
-#endif
       default: break;
     }
     if (tiles256 >= num_cus)

@@ -9,7 +9,6 @@
 //   launch_reg.hip   register-staged MFMA tiles (sgemm_mfma.hpp): plain, stream-K, split-K
 //   launch_dma.hip   LDS-DMA tiles (sgemm_dma.hpp): plain, stream-K; whole and guarded shapes
 //   launch_dma5.hip  LDS-DMA tiles with a loader wave (sgemm_dma5.hpp): plain, chained stream-K
-//   launch_dma32.hip LDS-DMA tiles on the 32x32x2 MFMA (sgemm_dma32.hpp): plain, chained stream-K
 //   launch_valu.hip  K1 / K0 (sgemm_valu.hpp)
 //   host_flavour.hip mmh_sgemm_host(_timed): the host-pointer MY_MMult, row-panel pipeline
 //   shard.hip        mmh_shard_*: single-process row-panel shard over RCCL
@@ -32,7 +31,7 @@
 #include "../../include/mmult_hip.h"
 
 // Kernel ids of the tools build (libmmult_hip_ab.so) that name whole tile families; the product library neither
-// defines nor accepts them.  K2M (sgemm_dma32.hpp, round 4): the LDS-DMA ring feeding v_mfma_f32_32x32x2_f32 -- 64-cycle
+// defines nor accepts them.  K2M (tools/ab/sgemm_dma32.hpp, round 4): the LDS-DMA ring feeding v_mfma_f32_32x32x2_f32 -- 64-cycle
 // matrix instructions, one conflict-free ds_read_b128 + two v_permlane32_swap per eight k's of A -- and the two-block
 // form v_mfma_f32_32x32x1_2b_f32; measured slower than the 16x16x4 tiles (profiles/r04_notes.md).
 #define MMH_KERNEL_MFMA32_64X64_DMA 48
@@ -44,6 +43,15 @@
 #define MMH_KERNEL_MFMA32B_128X128_DMA 62
 
 namespace mmh {
+
+// Is this the tools build (libmmult_hip_ab.so)?  The kernel headers test it with `if constexpr` where an A/B switch
+// rides in a kernel argument's spare bits (raster group height, publish-on-the-spot): no preprocessor in the kernels,
+// and nothing of the switches in the product's code objects.
+#ifdef MMH_AB_BUILD
+constexpr bool kAbBuild = true;
+#else
+constexpr bool kAbBuild = false;
+#endif
 
 // ---- error text (thread-local, state.hip) ----
 void set_last_error(const std::string &s);
@@ -94,6 +102,8 @@ struct GemmArgs {
   // launch form: 0 = the launcher's own rule (a kernel the caller forced), 1 = one workgroup per tile, 2 = the
   // persistent stream-K launch -- what MMH_KERNEL_AUTO's cost table decided (policy.hip)
   int form = 0;
+  // ... and the persistent workgroups per CU the table priced that launch on (0: whatever the kernel's residency allows)
+  int sk_w = 0;
 };
 
 }  // namespace mmh
@@ -226,7 +236,7 @@ int warm_reg(mmh_context *ctx, float *scratch, hipStream_t s);
 int launch_dma(mmh_context *ctx, int kernel, const GemmArgs &g);
 bool dma_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g);
 int warm_dma(mmh_context *ctx, float *scratch, hipStream_t s);
-// launch_dma32.hip: tile = MMH_KERNEL_MFMA32_*_DMA (sgemm_dma32.hpp); returns 1 when the shape does not qualify
+// tools/ab/launch_dma32.hip (tools build only): tile = MMH_KERNEL_MFMA32_*_DMA (tools/ab/sgemm_dma32.hpp); returns 1 when the shape does not qualify
 int launch_dma32(mmh_context *ctx, int kernel, const GemmArgs &g);
 bool dma32_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g);
 int warm_dma32(mmh_context *ctx, float *scratch, hipStream_t s);

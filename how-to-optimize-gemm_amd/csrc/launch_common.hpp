@@ -80,7 +80,10 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB,
     const int ok = allow_big_lds(kern, lds);
     if (ok != MMH_OK) return ok;
   }
-  const int per_cu = resident_per_cu(ctx, occ_kern, threads, lds);
+  int per_cu = resident_per_cu(ctx, occ_kern, threads, lds);
+  // MMH_KERNEL_AUTO priced a grid of g.sk_w workgroups per CU (the family's stream-K residency in policy_table.inc, which
+  // tests/test_kernel_resources.py holds to what the binary's registers allow): what is priced is what is launched
+  if (g.sk_w > 0 && g.sk_w < per_cu) per_cu = g.sk_w;
   // g.form (MMH_KERNEL_AUTO's cost table has decided): 1 = plain, 2 = persistent whenever the count is ragged; 0 = a
   // kernel the caller forced: the rule of streamk_wanted.  (decide_tiles: the count that rule looks at, when it is
   // not the launch's own -- thin edge tiles of the K2W kernels; a persistent launch then still covers all `tiles`.)
@@ -90,7 +93,8 @@ int launch_streamk(mmh_context *ctx, K kern, K occ_kern, int BM, int BN, int KB,
     grid = streamk_grid(tiles, cus, per_cu);
     if (grid == 0 || tiles % grid == 0 || tiles > (1L << 24)) return 1;
   } else {
-    if (decide_tiles > 0 && streamk_wanted(ctx, decide_tiles, BM, BN, per_cu) == 0) return 1;
+    // (MMH_OPT_STREAMK = 2 -- "whenever the count is ragged", the datasets' /sk2 -- looks at the launch's own count only)
+    if (decide_tiles > 0 && ctx->streamk != 2 && streamk_wanted(ctx, decide_tiles, BM, BN, per_cu) == 0) return 1;
     grid = streamk_wanted(ctx, tiles, BM, BN, per_cu);
     if (grid == 0) return 1;
   }

@@ -3,6 +3,9 @@
 // round 3: any m, n, k, 4-byte aligned operands) instantiation.  Part of libmmult_hip.so (see internal.hpp).
 #include "launch_common.hpp"
 #include "sgemm_mfma.hpp"   // streamk_body (+ sgemm_dma.hpp)
+#ifdef MMH_AB_BUILD
+#include "sgemm_dma_rim.hpp"   // tools/ab/: round 3's rim (measured, it does not pay)
+#endif
 
 namespace mmh {
 namespace {

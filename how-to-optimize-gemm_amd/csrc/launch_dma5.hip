@@ -4,6 +4,9 @@
 // Part of libmmult_hip.so (see internal.hpp).
 #include "launch_common.hpp"
 #include "sgemm_dma5.hpp"
+#ifdef MMH_AB_BUILD
+#include "sgemm_dma5_rim.hpp"   // tools/ab/: round 4's fused rim (measured: 2.2x slower per edge tile)
+#endif
 
 namespace mmh {
 namespace {
@@ -141,6 +144,7 @@ bool dma5_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g) {
     case MMH_KERNEL_MFMA_128X64_DMA5: return dma5_form<128, 64, 32>(ctx, g) >= 0;
     case MMH_KERNEL_MFMA_128X128_DMA5: return dma5_form<128, 128, 32>(ctx, g) >= 0;
     case MMH_KERNEL_MFMA_96X96_DMA5: return dma5_form<96, 96, 32>(ctx, g) >= 0;
+    case MMH_KERNEL_MFMA_96X64_DMA5: return dma5_form<96, 64, 32>(ctx, g) >= 0;
     default: return false;
   }
 }
@@ -159,6 +163,8 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
       return launch_dma5_tile<128, 128, 4, 4, 3, 4, 2>(ctx, g);
     case MMH_KERNEL_MFMA_96X96_DMA5:    // 96x96 tile, consumers of 48x48 (column-blocked B) + one loader, 72 KiB ring: 2 per CU
       return launch_dma5_tile<96, 96, 3, 3, 3, 1, 2, false>(ctx, g);
+    case MMH_KERNEL_MFMA_96X64_DMA5:    // 96x64 tile, consumers of 48x32 + four loaders, 60 KiB ring: 2 per CU (round 5; N = 1152: 110.5 against 106.6 TFLOP/s)
+      return launch_dma5_tile<96, 64, 3, 2, 3, 4, 2, false>(ctx, g);
 #ifdef MMH_AB_BUILD
     // A/B (valid results): ONE loader wave (round 4's first form), and the 160-wide whole-round tiles that lost to the
     // chained stream-K launch of the 128-wide ones (N = 2560: 140.8 against 145.2; N = 1920 on 160x96: 130.9 against 137.5)
@@ -178,7 +184,7 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
     case 81: return launch_dma5_tile<160, 160, 5, 5, 3, 4, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 82: return launch_dma5_tile<160, 160, 5, 5, 3, 2, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     // round 5: 96x64 / 64x96 (N = 1152: 216 tiles -- one round of 256 CUs at 84 % -- instead of 324 tiles of 64x64 under stream-K)
-    case 83: return launch_dma5_tile<96, 64, 3, 2, 3, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 83: return launch_dma5_tile<96, 64, 3, 2, 3, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;   // (with a stream-K form: never ahead)
     case 84: return launch_dma5_tile<96, 64, 3, 2, 3, 2, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 85: return launch_dma5_tile<64, 96, 2, 3, 3, 2, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
 #endif
@@ -203,7 +209,8 @@ int warm_dma5(mmh_context *ctx, float *scratch, hipStream_t s) {
   if ((rc = warm_dma5_tile<64, 64, 2, 2, 3, 2, 2>(ctx, scratch, s)) != MMH_OK) return rc;
   if ((rc = warm_dma5_tile<128, 64, 4, 2, 3, 4, 2>(ctx, scratch, s)) != MMH_OK) return rc;
   if ((rc = warm_dma5_tile<128, 128, 4, 4, 3, 4, 2>(ctx, scratch, s)) != MMH_OK) return rc;
-  return warm_dma5_tile<96, 96, 3, 3, 3, 1, 2, false>(ctx, scratch, s);
+  if ((rc = warm_dma5_tile<96, 96, 3, 3, 3, 1, 2, false>(ctx, scratch, s)) != MMH_OK) return rc;
+  return warm_dma5_tile<96, 64, 3, 2, 3, 4, 2, false>(ctx, scratch, s);
 }
 
 #ifdef MMH_DMA_TIMELINE

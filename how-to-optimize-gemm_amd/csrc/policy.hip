@@ -25,6 +25,7 @@ constexpr int kSliceK = 32;   // K-slice depth of the MFMA tiles (sgemm_tile.hpp
 // on 500 held-out shapes.  tools/calibrate_policy.sh regenerates the table on another box.
 struct Family {
   int kernel, bm, bn, w, has_sk;
+  int skw;   // persistent workgroups per CU of the family's stream-K launches (<= w: the guarded chained kernel's registers)
   float fix_p, s_p[3], fix_s[3], s_s[3];
   float fix_p_whole, fix_s_whole[3];   // the fixed costs of the whole-tile instantiation (no guards: fast_shape)
   float tile_p[3], tile_s[3];          // per tile (on the fullest CU / per CU's share), by occupancy: pipeline fill, C store
@@ -36,7 +37,17 @@ struct Plan {
   int kernel = -1;
   int form = 0;   // 1 plain, 2 persistent stream-K (GemmArgs::form)
   double us = 0.0;
+  int sk_w = 0;   // form 2: the persistent workgroups per CU the price was taken for (GemmArgs::sk_w)
+  int bm = 0, bn = 0;
 };
+
+bool is_k2w(int kernel) {
+  return kernel == MMH_KERNEL_MFMA_64X64_DMA5 || kernel == MMH_KERNEL_MFMA_128X64_DMA5 || kernel == MMH_KERNEL_MFMA_128X128_DMA5 ||
+         kernel == MMH_KERNEL_MFMA_96X96_DMA5 || kernel == MMH_KERNEL_MFMA_96X64_DMA5;
+}
+bool is_k2l(int kernel) {
+  return kernel == MMH_KERNEL_MFMA_64X64_DMA || kernel == MMH_KERNEL_MFMA_128X64_DMA || kernel == MMH_KERNEL_MFMA_128X128_DMA;
+}
 
 Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
   const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
@@ -50,7 +61,9 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
     // 150.2-150.3, and 2048 x 4096 x 16384 -- half a round of 256x256 tiles -- 151.5 against 74.8: the fence is gone, the
     // table decides; profiles/r04_big_k.md.)
     if (f.kernel != MMH_KERNEL_MFMA_256X256) {
-      if (!dma5_shape_ok(ctx, f.kernel, g)) continue;
+      // (round 5: the K2L tiles are candidates too -- VERDICT r04 item 4: they shipped, AUTO never priced them, and on
+      // small shapes their 256-thread workgroups and shorter preamble won by 5-8 %)
+      if (is_k2w(f.kernel) ? !dma5_shape_ok(ctx, f.kernel, g) : !dma_shape_ok(ctx, f.kernel, g)) continue;
       any_dma5 = true;
     }
     long tiles = (long)((g.m + f.bm - 1) / f.bm) * ((g.n + f.bn - 1) / f.bn);
@@ -67,15 +80,17 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
     const bool whole = fast_shape(f.bm, f.bn, kSliceK, g);
     double t = (whole ? f.fix_p_whole : f.fix_p) + (double)cmax * (nk * f.s_p[occ - 1] + f.tile_p[occ - 1]);
     if (cmax > f.w && tiles % ((long)f.w * cus) != 0) t *= MMH_POLICY_MULTIROUND_MARGIN;   // a ragged last round
-    if (best.kernel < 0 || t < best.us) best = Plan{f.kernel, 1, t};
+    if (best.kernel < 0 || t < best.us) best = Plan{f.kernel, 1, t, 0, f.bm, f.bn};
     if (f.has_sk && (!ctx || ctx->streamk) && !tiles_rim) {
+      // the grid launch_streamk will launch: the largest w' <= skw workgroups per CU that leaves every one a whole tile
+      // (round 4 took w' from the plain co-residency w and priced 768-tile launches that ran on 512)
       int wp = 0;
-      for (int c = f.w; c >= 1; --c)
+      for (int c = f.skw; c >= 1; --c)
         if (tiles >= (long)c * cus) { wp = c; break; }
       if (wp > 0 && tiles % ((long)wp * cus) != 0 && tiles <= (1L << 24)) {
         const double ts = (whole ? f.fix_s_whole[wp - 1] : f.fix_s[wp - 1]) +
                           (double)tiles / (double)cus * (nk * f.s_s[wp - 1] + f.tile_s[wp - 1]);
-        if (ts < best.us) best = Plan{f.kernel, 2, ts};
+        if (ts < best.us) best = Plan{f.kernel, 2, ts, wp, f.bm, f.bn};
       }
     }
   }
@@ -155,8 +170,9 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
     if (plan.kernel >= 0) {
       GemmArgs ga = g;
       ga.form = plan.form;
+      ga.sk_w = plan.sk_w;
       if (plan.kernel == MMH_KERNEL_MFMA_256X256) return launch_reg(ctx, plan.kernel, ga);
-      const int d = launch_dma5(ctx, plan.kernel, ga);
+      const int d = is_k2l(plan.kernel) ? launch_dma(ctx, plan.kernel, ga) : launch_dma5(ctx, plan.kernel, ga);
       if (d <= 0) return d;
     }
     kernel = fallback_kernel(ctx, g);
@@ -189,6 +205,7 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA_128X64, g);
     }
     case MMH_KERNEL_MFMA_128X128_DMA5:
+    case MMH_KERNEL_MFMA_96X64_DMA5:
     case MMH_KERNEL_MFMA_96X96_DMA5: {
       const int d = launch_dma5(ctx, kernel, g);
       return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA, g);
@@ -261,21 +278,15 @@ int auto_plan(int m, int n, int k, int lda, int ldb, int ldc, int base_align, in
                    reinterpret_cast<const float *>(2 * base + off), ldb, reinterpret_cast<float *>(3 * base + off), ldc, 0, nullptr};
   const Plan plan = auto_plan_for(&ctx, g);
   const int kern = plan.kernel >= 0 ? plan.kernel : fallback_kernel(&ctx, g);
-  int bm = 0, bn = 0, per_cu = 0;
-  switch (kern) {
-    // (stream-K residency: the tile's guarded chained stream-K instantiation -- the one launch_dma5.hip bounds every
-    // stream-K grid of the tile by -- needs 116 registers: four waves per SIMD, 16 per CU = TWO workgroups of six waves, though
-    // three 48 KiB rings fit; tools/kernel_resources.py.  The table's third stream-K bucket, "768 tiles or more", describes
-    // launches on 512 workgroups: what was measured is what is priced, and what is reported here is what is launched.)
-    case MMH_KERNEL_MFMA_64X64_DMA5: bm = 64; bn = 64; per_cu = 2; break;
-    case MMH_KERNEL_MFMA_128X64_DMA5: bm = 128; bn = 64; per_cu = 1; break;   // (likewise: 165 registers, 12 waves per CU = ONE workgroup of eight)
-    case MMH_KERNEL_MFMA_128X128_DMA5: bm = 128; bn = 128; per_cu = 1; break; // 96 KiB
-    case MMH_KERNEL_MFMA_96X96_DMA5: bm = 96; bn = 96; per_cu = 2; break;     // 72 KiB
-    case MMH_KERNEL_MFMA_256X256: bm = 256; bn = 256; per_cu = 1; break;      // 128 KiB
-    case MMH_KERNEL_MFMA: bm = 128; bn = 128; break;
-    case MMH_KERNEL_MFMA_128X64: bm = 128; bn = 64; break;
-    case MMH_KERNEL_MFMA_64X64: bm = 64; bn = 64; break;
-    default: break;
+  int bm = plan.bm, bn = plan.bn;
+  if (plan.kernel < 0) {
+    switch (kern) {   // the register-staged fall-back tiles
+      case MMH_KERNEL_MFMA_256X256: bm = 256; bn = 256; break;
+      case MMH_KERNEL_MFMA: bm = 128; bn = 128; break;
+      case MMH_KERNEL_MFMA_128X64: bm = 128; bn = 64; break;
+      case MMH_KERNEL_MFMA_64X64: bm = 64; bn = 64; break;
+      default: break;
+    }
   }
   if (kernel) *kernel = kern;
   const long t = bm ? (long)((m + bm - 1) / bm) * ((n + bn - 1) / bn) : 0;
@@ -284,8 +295,8 @@ int auto_plan(int m, int n, int k, int lda, int ldb, int ldc, int base_align, in
     *streamk_grid = -1;
     if (plan.kernel >= 0) {
       *streamk_grid = 0;
-      if (plan.form == 2) {
-        const int grid = mmh::streamk_grid(t, ctx.cu_count, per_cu);
+      if (plan.form == 2) {   // (the grid the price was taken for: plan.sk_w workgroups per CU, GemmArgs::sk_w)
+        const int grid = mmh::streamk_grid(t, ctx.cu_count, plan.sk_w);
         *streamk_grid = (grid > 0 && t % grid != 0) ? grid : 0;   // (launch_streamk: a count the grid divides runs plain)
       }
     }

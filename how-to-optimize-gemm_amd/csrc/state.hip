@@ -172,7 +172,7 @@ int reserve_stream(mmh_context *ctx, hipStream_t s, int m, int n, int k) {
   const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
   size_t parts = (size_t)cus * 3 * 64 * 64 * sizeof(float);                            // 64x64: three workgroups per CU
   parts = std::max(parts, (size_t)cus * 2 * 128 * 64 * sizeof(float));                  // 128x64: two
-  parts = std::max(parts, (size_t)cus * 128 * 128 * sizeof(float));                     // 128x128: one
+  parts = std::max(parts, (size_t)cus * 2 * 128 * 128 * sizeof(float));                 // 128x128: one (K2W, K2L) -- two for a forced register-staged tile (64 KiB of LDS); covers its 128x64 tile's three, too
   if (tiles256 >= cus) parts = std::max(parts, (size_t)cus * 256 * 256 * sizeof(float));   // 256x256: one
   int *flags = nullptr;
   float *p = nullptr;
@@ -389,7 +389,10 @@ int warm_context(mmh_context *h) {
   HIP_TRY(hipMemsetAsync(scratch.p, 0, scratch.bytes, nullptr));
   float *p = static_cast<float *>(scratch.p);
   if ((rc = warm_reg(h, p, nullptr)) == MMH_OK && (rc = warm_dma(h, p, nullptr)) == MMH_OK &&
-      (rc = warm_dma32(h, p, nullptr)) == MMH_OK && (rc = warm_dma5(h, p, nullptr)) == MMH_OK) rc = warm_valu(h, p, nullptr);
+      (rc = warm_dma5(h, p, nullptr)) == MMH_OK) rc = warm_valu(h, p, nullptr);
+#ifdef MMH_AB_BUILD
+  if (rc == MMH_OK) rc = warm_dma32(h, p, nullptr);   // (K2M: tools/ab/)
+#endif
   // the hand-off workspaces at the size the largest stream-K launch of a square sweep needs
   if (rc == MMH_OK) {
     // (not fatal: on a device that is short of memory -- beside a torch process, say -- the set is allocated by the

@@ -114,6 +114,7 @@ typedef struct mmh_context *mmh_handle_t;
  * stream-K form).  (160x96 and 160x160 were built and measured too -- N = 1920, 2560 -- and lose to the chained
  * stream-K launch of the 128-wide tiles; they live in the tools build, profiles/r04_notes.md.) */
 #define MMH_KERNEL_MFMA_96X96_DMA5 7
+#define MMH_KERNEL_MFMA_96X64_DMA5 26  /* round 5: 96x64 (wave tile 48x32), one workgroup per tile only: N = 1152 is 216 of them */
 /* (Tools build only -- libmmult_hip_ab.so, never this library: K2M, the same LDS-DMA ring feeding
  * v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x1_2b_f32 (ids 48-51, 60-62; measured slower than the 16x16x4 tiles,
  * profiles/r04_notes.md), the one-loader and 160-wide forms of K2W (64, 68, 72, 79, 80), the scheduling A/Bs and the

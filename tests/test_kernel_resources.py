@@ -68,14 +68,14 @@ def test_the_k2w_tiles_fit_the_co_residency_their_launches_count_on():
     two: bounding a whole-tile launch by its own instantiation is a lever the round found on the CPU, at its end, and
     left for the next one."""
     rows = {r["kernel"]: r for r in _rows()}
-    plain = {"64,64,32,2,2,3": 3, "128,64,32,4,2,3": 2, "128,128,32,4,4,3": 1, "96,96,32,3,3,3": 2}
+    plain = {"64,64,32,2,2,3": 3, "128,64,32,4,2,3": 2, "128,128,32,4,4,3": 1, "96,96,32,3,3,3": 2, "96,64,32,3,2,3": 2}
     seen = 0
     for name, r in rows.items():
         m = re.match(r"sgemm_mfma_dma5_kernel<(\d+,\d+,32,\d,\d,3),", name)
         if m:
             assert _workgroups_per_cu(r["vgpr"], r["threads"]) >= plain[m.group(1)], r
             seen += 1
-    assert seen == 8, seen
+    assert seen == 10, seen
     guarded = {"64,64,32,2,2,3": 2, "128,64,32,4,2,3": 1, "128,128,32,4,4,3": 1}
     whole = {"64,64,32,2,2,3": 3, "128,64,32,4,2,3": 2, "128,128,32,4,4,3": 1}
     for tile in guarded:
@@ -119,3 +119,33 @@ def test_k1w_fits_the_co_residency_its_launches_count_on():
         assert r["agpr"] == 0 and r["threads"] == 384, r
         assert _workgroups_per_cu(r["vgpr"], r["threads"]) >= want[m.group(1)], r
     assert seen == set(want), seen
+
+
+def test_the_cost_tables_stream_k_residency_is_one_the_binary_allows():
+    """MMH_KERNEL_AUTO priced stream-K launches from the plain co-residency w (three 64x64 workgroups per CU)
+    while launch_streamk bounded the grid by the guarded chained instantiation's registers (two): `tiles % (w' CUs)` meant
+    different things in the two places.  Round 5: policy_table.inc carries `skw` per family, the plan hands it to the
+    launcher (GemmArgs::sk_w, an upper bound there), and this test holds it to what the binary's registers and the LDS
+    ring allow for the instantiation that bounds the grid."""
+    text = open(os.path.join(REPO, "how-to-optimize-gemm_amd", "csrc", "policy_table.inc")).read()
+    fams = re.findall(r"\{(MMH_KERNEL_\w+), (\d+), (\d+), (\d+), (\d+), (\d+),", text)
+    assert len(fams) == 9, fams
+    rows = {r["kernel"]: r for r in _rows()}
+    bound = {   # the instantiation launch_*.hip passes as `occ_kern`, and its LDS request in KiB
+        "MMH_KERNEL_MFMA_64X64_DMA5": ("sgemm_dma5_streamk_kernel<64,64,32,2,2,3,true,true,2,2>", 48),
+        "MMH_KERNEL_MFMA_128X64_DMA5": ("sgemm_dma5_streamk_kernel<128,64,32,4,2,3,true,true,4,2>", 72),
+        "MMH_KERNEL_MFMA_128X128_DMA5": ("sgemm_dma5_streamk_kernel<128,128,32,4,4,3,true,true,4,2>", 96),
+        "MMH_KERNEL_MFMA_64X64_DMA": ("sgemm_dma_streamk_kernel<64,64,32,2,2,3,true>", 48),
+        "MMH_KERNEL_MFMA_128X64_DMA": ("sgemm_dma_streamk_kernel<128,64,32,4,2,3,true>", 72),
+        "MMH_KERNEL_MFMA_128X128_DMA": ("sgemm_dma_streamk_kernel<128,128,32,4,4,3,true>", 96),
+        "MMH_KERNEL_MFMA_256X256": ("sgemm_mfma_streamk_kernel<256,256,true,4,8,32>", 128),
+    }
+    for macro, bm, bn, w, has_sk, skw in fams:
+        w, has_sk, skw = int(w), int(has_sk), int(skw)
+        if not has_sk:
+            assert skw == 0, (macro, skw)
+            continue
+        name, lds_kib = bound[macro]
+        r = rows[name]
+        fits = min(_workgroups_per_cu(r["vgpr"], r["threads"]), 160 // lds_kib)
+        assert 1 <= skw <= min(w, fits), (macro, skw, w, fits, r)

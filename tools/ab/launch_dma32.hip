@@ -1,8 +1,9 @@
 // launch_dma32.hip -- launchers of the LDS-DMA tiles on v_mfma_f32_32x32x2_f32 (sgemm_dma32.hpp, K2M): 64x64, 128x64,
 // 64x128 and 128x128, each as one workgroup per tile or as the persistent stream-K form (chained segments), each in a
-// whole-tile and a guarded (EDGE: any m, n, k, 4-byte aligned operands) instantiation.  Part of libmmult_hip.so.
+// whole-tile and a guarded (EDGE: any m, n, k, 4-byte aligned operands) instantiation.
 // (Round 4: measured slower than the 16x16x4 tiles everywhere -- profiles/r04_notes.md -- so the family is part of the
-// TOOLS build only, libmmult_hip_ab.so; the product library carries stubs that say so.)
+// TOOLS build only: since round 5 it lives here, under tools/ab/, and only build_ab_library() compiles it, with
+// -I csrc for the product's headers.)
 #ifdef MMH_AB_BUILD
 #include "launch_common.hpp"
 #include "sgemm_dma32.hpp"
@@ -154,15 +155,5 @@ int warm_dma32(mmh_context *ctx, float *scratch, hipStream_t s) {
   return warm_dma32_tile<128, 128, 32, 1, 2, 3, 2>(ctx, scratch, s);
 }
 
-}  // namespace mmh
-#else
-#include "internal.hpp"
-namespace mmh {
-int launch_dma32(mmh_context *, int, const GemmArgs &) {
-  set_last_error("the 32x32x2 LDS-DMA tiles are part of the tools build (libmmult_hip_ab.so) only");
-  return MMH_ERR_INVALID_ARG;
-}
-bool dma32_shape_ok(const mmh_context *, int, const GemmArgs &) { return false; }
-int warm_dma32(mmh_context *, float *, hipStream_t) { return MMH_OK; }
 }  // namespace mmh
 #endif

@@ -101,7 +101,8 @@ PY
   timeout 200 python tools/create_time.py --runs 2 > $OUT/create_time.json 2>&1; cat $OUT/create_time.json | tr -d '\n' | cut -c1-600; echo
 fi
 if has dataset; then    # every (tile family, launch form) forced over the fit / held-out shape lists: what MMH_KERNEL_AUTO's table is fitted on
-  DV="auto,mfma_64x64_dma5/sk0,mfma_64x64_dma5/sk2,mfma_128x64_dma5/sk0,mfma_128x64_dma5/sk2,mfma_128x128_dma5/sk0,mfma_128x128_dma5/sk2,mfma_96x96_dma5,mfma_256x256/sk0,mfma_256x256/sk2,mfma_64x64_dma,mfma_128x64_dma,mfma_128x128_dma"
+  # (round 5: the K2L tiles forced both ways too -- candidates of the table since this round -- and the 96x64 tile)
+  DV="auto,mfma_64x64_dma5/sk0,mfma_64x64_dma5/sk2,mfma_128x64_dma5/sk0,mfma_128x64_dma5/sk2,mfma_128x128_dma5/sk0,mfma_128x128_dma5/sk2,mfma_96x96_dma5,mfma_96x64_dma5,mfma_256x256/sk0,mfma_256x256/sk2,mfma_64x64_dma/sk0,mfma_64x64_dma/sk2,mfma_128x64_dma/sk0,mfma_128x64_dma/sk2,mfma_128x128_dma/sk0,mfma_128x128_dma/sk2"
   for which in ${DATASETS:-fit heldout}; do
     timeout 900 python tools/tile_sweep.py --shape-file tools/policy_shapes_$which.txt --variants "$DV" --rounds 2 --reps 10 --warm-ms 10 \
       --out $OUT/dataset_$which > $OUT/dataset_$which.log 2>&1

@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import re
 import math
 import os
 import sys
@@ -37,13 +38,24 @@ import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CUS = 256
 RIM5 = False     # MMH_OPT_RIM5 (tools build; measured, it loses): the fused rim launch of the 64x64 tile
-# family: (kernel short name, BM, BN, co-resident workgroups per CU, has a stream-K form)
+# family: (kernel short name, BM, BN, co-resident workgroups per CU of a plain launch, has a stream-K form,
+#          persistent workgroups per CU of its stream-K launches, the kernel id's macro)
+# skw: launch_streamk bounds every stream-K grid of a tile by its GUARDED (chained) instantiation's residency -- K2W's
+# 64x64 / 128x64 tiles need 116 / 165 registers there: two / one workgroup(s) per CU where three / two rings fit
+# (tests/test_kernel_resources.py reads it off the binary); round 5 measured the whole-tile instantiations on their own,
+# larger, residency (tools build, option 103): no gain anywhere on the sweep (profiles/r05_notes.md).  K2L's kernels have
+# 256-thread workgroups and fit three / two / one.
 FAMILIES = {
-    "t64": ("mfma_64x64_dma5", 64, 64, 3, True),
-    "t128x64": ("mfma_128x64_dma5", 128, 64, 2, True),
-    "t128": ("mfma_128x128_dma5", 128, 128, 1, True),
-    "t96": ("mfma_96x96_dma5", 96, 96, 2, False),
-    "t256": ("mfma_256x256", 256, 256, 1, True),
+    "t64": ("mfma_64x64_dma5", 64, 64, 3, True, 2, "MMH_KERNEL_MFMA_64X64_DMA5"),
+    "t128x64": ("mfma_128x64_dma5", 128, 64, 2, True, 1, "MMH_KERNEL_MFMA_128X64_DMA5"),
+    "t128": ("mfma_128x128_dma5", 128, 128, 1, True, 1, "MMH_KERNEL_MFMA_128X128_DMA5"),
+    "t96": ("mfma_96x96_dma5", 96, 96, 2, False, 0, "MMH_KERNEL_MFMA_96X96_DMA5"),
+    "t96x64": ("mfma_96x64_dma5", 96, 64, 2, False, 0, "MMH_KERNEL_MFMA_96X64_DMA5"),
+    "t256": ("mfma_256x256", 256, 256, 1, True, 1, "MMH_KERNEL_MFMA_256X256"),
+    # K2L (round 3's LDS-DMA tiles, every wave issuing its share of the DMA): candidates since round 5
+    "l64": ("mfma_64x64_dma", 64, 64, 2, True, 2, "MMH_KERNEL_MFMA_64X64_DMA"),   # (184 registers with the AGPRs: two workgroups per CU, not the three its LDS allows)
+    "l128x64": ("mfma_128x64_dma", 128, 64, 2, True, 2, "MMH_KERNEL_MFMA_128X64_DMA"),
+    "l128": ("mfma_128x128_dma", 128, 128, 1, True, 1, "MMH_KERNEL_MFMA_128X128_DMA"),
 }
 
 
@@ -56,7 +68,7 @@ def rim_dims(m, n):
 
 
 def geometry(fam, m, n, k, cus=CUS):
-    _, bm, bn, w, has_sk = FAMILIES[fam]
+    _, bm, bn, w, has_sk, skw, _macro = FAMILIES[fam]
     rim = False
     if fam == "t64" and RIM5:
         a, b = rim_dims(m, n)
@@ -67,7 +79,7 @@ def geometry(fam, m, n, k, cus=CUS):
     nk = -(-k // 32)
     cmax = -(-tiles // cus)
     wp = 0
-    for cand in range(w, 0, -1):
+    for cand in range(skw, 0, -1):      # (the grid launch_streamk launches: at most skw workgroups per CU)
         if tiles >= cand * cus:
             wp = cand
             break
@@ -88,17 +100,23 @@ def rows_of(dataset):
                 tf = r.get(key)
                 if not tf:
                     continue
-                if "forms" in r:      # compacted dataset (--compact): p = persistent, 1 = plain, x = another family ran
+                grid = 0
+                if "forms" in r:      # compacted dataset (--compact): p[grid] = persistent, 1 = plain, x = another family ran
                     code = r["forms"].get(key, "x")
-                    is_sk, own = code == "p", code != "x"
+                    is_sk, own = code.startswith("p"), code != "x"
+                    grid = int(code[1:]) if len(code) > 1 and code[1:].isdigit() else 0
                 else:
                     launched = r.get("launched", {}).get(key, "")
                     is_sk = "persistent" in launched
                     own = "LDS-DMA" in launched or fam == "t256"
+                    mm = re.search(r"on (\d+) persistent", launched)
+                    grid = int(mm.group(1)) if mm else 0
                 if (form == "sk") != is_sk:
                     continue
                 if not own:
                     continue      # fell back to a register-staged tile (descriptor window): not this family
+                if is_sk and grid and grid != geometry(fam, m, n, k)["wp"] * CUS:
+                    continue      # (a grid the model does not describe: another residency than skw)
                 out.append((fam, form, (m, n, k), flops / tf / 1e6))
     return out
 
@@ -112,16 +130,19 @@ def compact(dataset):
         forms = {}
         for key, text in r.get("launched", {}).items():
             fam_ok = "LDS-DMA" in text or key.startswith("mfma_256x256") or key == "auto"
-            forms[key] = "x" if not fam_ok else ("p" if "persistent" in text else "1")
+            mm = re.search(r"on (\d+) persistent", text)
+            forms[key] = "x" if not fam_ok else ("p" + (mm.group(1) if mm else "") if "persistent" in text else "1")
         c["forms"] = forms
+        fa = family_of_auto(r)
+        c["auto_is"] = list(fa) if fa else None      # (family, form) the pass's own MMH_KERNEL_AUTO launched
         out.append(c)
     return out
 
 
 def fit(rows):
     table = {}
-    for fam, (_, bm, bn, w, has_sk) in FAMILIES.items():
-        entry = {"bm": bm, "bn": bn, "w": w, "fix_p": 0.0, "s_p": [0.0] * 3, "fix_s": [0.0] * 3, "s_s": [0.0] * 3,
+    for fam, (_, bm, bn, w, has_sk, skw, _macro) in FAMILIES.items():
+        entry = {"bm": bm, "bn": bn, "w": w, "skw": skw, "fix_p": 0.0, "s_p": [0.0] * 3, "fix_s": [0.0] * 3, "s_s": [0.0] * 3,
                  "fix_p_whole": 0.0, "fix_s_whole": [0.0] * 3, "tile_p": [0.0] * 3, "tile_s": [0.0] * 3,
                  "n_p": 0, "n_s": 0, "rms_p": 0.0, "rms_s": 0.0}
         for form in ("plain", "sk"):
@@ -183,7 +204,9 @@ def fit(rows):
 
 
 def predict(table, fam, form, m, n, k, cus=CUS):
-    e = table[fam]
+    e = table.get(fam)
+    if not e or not e["n_p"]:
+        return math.inf       # a family the dataset does not hold: not a candidate
     g = geometry(fam, m, n, k, cus)
     if form == "plain":
         t = e["fix_p_whole" if g["whole"] else "fix_p"] + g["cmax"] * (g["nk"] * e["s_p"][g["occ"] - 1] + e["tile_p"][g["occ"] - 1])
@@ -204,11 +227,45 @@ def choose(table, m, n, k, cus=CUS):
     return best, best_t
 
 
+def launch_of(r, key):
+    """('plain' | 'sk' | None when another family ran, persistent grid or 0) of a measured variant."""
+    if "forms" in r:
+        code = r["forms"].get(key, "x")
+        if code == "x":
+            return None, 0
+        return ("sk" if code.startswith("p") else "plain"), (int(code[1:]) if code[1:].isdigit() else 0)
+    text = r.get("launched", {}).get(key, "")
+    if not text or text.startswith("error"):
+        return None, 0
+    mm = re.search(r"on (\d+) persistent", text)
+    return ("sk" if "persistent" in text else "plain"), (int(mm.group(1)) if mm else 0)
+
+
+def family_of_auto(r):
+    """(family, form) MMH_KERNEL_AUTO launched in this pass, from its launch string (None for compacted datasets)."""
+    if "auto_is" in r:
+        return tuple(r["auto_is"]) if r["auto_is"] else None
+    text = r.get("launched", {}).get("auto", "")
+    mm = re.search(r"<(\d+),(\d+)>", text)
+    if not mm:
+        return None
+    k2w = "loader wave" in text
+    for fam, (kern, bm, bn, *_rest) in FAMILIES.items():
+        if (bm, bn) == (int(mm.group(1)), int(mm.group(2))) and (kern.endswith("_dma5") == k2w or fam == "t256") and \
+                (fam != "t256" or "LDS-DMA" not in text) and (fam == "t256" or "LDS-DMA" in text):
+            return fam, ("sk" if "persistent" in text else "plain")
+    return None
+
+
 def measured(r, fam, form):
+    """TFLOP/s of the family forced in that launch form -- only if the launch TOOK that form (a forced /sk2 on a count
+    the grid divides, or with too few whole tiles, runs plain: that is a second measurement of the plain launch)."""
     kern = FAMILIES[fam][0]
-    for key in ([kern + "/sk2"] if form == "sk" else [kern + "/sk0", kern]):
-        if r.get(key):
+    for key in ([kern + "/sk2"] if form == "sk" else [kern + "/sk0", kern + "/sk2", kern]):
+        if r.get(key) and launch_of(r, key)[0] == form:
             return r[key]
+    if r.get("auto") and family_of_auto(r) == (fam, form):
+        return r["auto"]      # (the pass's own AUTO launched exactly this candidate: e.g. stream-K over thin edge tiles)
     return None
 
 
@@ -218,6 +275,10 @@ def regret(table, dataset):
         m, n, k = r["m"], r["n"], r["k"]
         (fam, form), _ = choose(table, m, n, k)
         got = measured(r, fam, form)
+        if got is None and form == "sk":
+            # the table prices a persistent launch the pass did not measure (forced kernels decide plain / persistent on
+            # the whole tiles alone when a last tile row / column is thin): judged as the plain launch of the family
+            got = measured(r, fam, "plain")
         cands = {}
         for f in FAMILIES:
             for fo in ("plain", "sk"):
@@ -233,25 +294,24 @@ def regret(table, dataset):
 def emit(table, path, source):
     with open(path, "w") as f:
         f.write("// policy_table.inc -- GENERATED by tools/policy_fit.py from " + source + "; do not edit by hand.\n")
-        f.write("// Per tile family: co-residency w, then microseconds: plain launches t = fix_p + cmax * (nk * s_p[o] + tile_p[o]), o = min(cmax, w) - 1,\n")
+        f.write("// Per tile family: co-residency w, has-stream-K, stream-K residency skw, then microseconds: plain launches t = fix_p + cmax * (nk * s_p[o] + tile_p[o]), o = min(cmax, w) - 1,\n")
         f.write("// persistent stream-K launches t = fix_s[w' - 1] + tiles / CUs * (nk * s_s[w' - 1] + tile_s[w' - 1]) (tools/policy_fit.py has the derivation;\n")
         f.write("// rows / rms relative residual of each fit behind it); then fix_p and fix_s of the whole-tile instantiation (shapes\n")
         f.write("// csrc/internal.hpp fast_shape accepts for the family's tile), then tile_p and tile_s.\n")
-        fams = {k: v for k, v in table.items() if not k.startswith("_")}
+        fams = {k: v for k, v in table.items() if not k.startswith("_") and v["n_p"]}
         for fam, e in fams.items():
             f.write(f"// {fam}: plain {e['n_p']} rows, rms {e['rms_p']:.3f}; stream-K {e['n_s']} rows, rms {e['rms_s']:.3f}\n")
         f.write(f"#define MMH_POLICY_MULTIROUND_MARGIN {table.get('_margin', 1.0):.3f}f   // plain launches of more than one round: p90 of measured / predicted\n")
         f.write("#define MMH_POLICY_FAMILIES \\\n")
         for fam, e in fams.items():
-            kern = {"t64": "MMH_KERNEL_MFMA_64X64_DMA5", "t128x64": "MMH_KERNEL_MFMA_128X64_DMA5", "t128": "MMH_KERNEL_MFMA_128X128_DMA5",
-                    "t96": "MMH_KERNEL_MFMA_96X96_DMA5", "t256": "MMH_KERNEL_MFMA_256X256"}[fam]
+            kern = FAMILIES[fam][6]
             sp = ", ".join(f"{v:.6f}f" for v in e["s_p"])
             ss = ", ".join(f"{v:.6f}f" for v in e["s_s"])
             fs = ", ".join(f"{v:.4f}f" for v in e["fix_s"])
             fw = ", ".join(f"{v:.4f}f" for v in e["fix_s_whole"])
             tp = ", ".join(f"{v:.4f}f" for v in e["tile_p"])
             ts = ", ".join(f"{v:.4f}f" for v in e["tile_s"])
-            f.write(f"  {{{kern}, {e['bm']}, {e['bn']}, {e['w']}, {1 if e['n_s'] else 0}, {e['fix_p']:.4f}f, {{{sp}}}, {{{fs}}}, {{{ss}}}, "
+            f.write(f"  {{{kern}, {e['bm']}, {e['bn']}, {e['w']}, {1 if e['n_s'] else 0}, {e['skw'] if e['n_s'] else 0}, {e['fix_p']:.4f}f, {{{sp}}}, {{{fs}}}, {{{ss}}}, "
                     f"{e['fix_p_whole']:.4f}f, {{{fw}}}, {{{tp}}}, {{{ts}}}}}, \\\n")
         f.write("\n")
 
@@ -262,8 +322,13 @@ def main():
     ap.add_argument("--heldout", default="")
     ap.add_argument("--emit", default="")
     ap.add_argument("--report", default="")
+    ap.add_argument("--families", default="", help="comma-separated subset of the families to fit and price (default: all the dataset holds)")
     ap.add_argument("--compact", default="", help="write the fit (and held-out) dataset without launch strings: PREFIX_fit.json, PREFIX_heldout.json")
     args = ap.parse_args()
+    if args.families:
+        for fam in list(FAMILIES):
+            if fam not in args.families.split(","):
+                del FAMILIES[fam]
     fit_set = json.load(open(args.fit))
     if args.compact:
         json.dump(compact(fit_set), open(args.compact + "_fit.json", "w"), separators=(",", ":"))
