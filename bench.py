@@ -576,6 +576,8 @@ def main():
                 mm.set_kernel(args.kernel)
                 extras["sweep_gflops"] = sweep
                 extras["probe_mfma_f32_tflops"] = round(mm.probe_mfma_f32(), 1)
+                # the vector ALU's own roof (a bare v_pk_fma_f32 loop, 2 / 3 / 4 waves per SIMD): the denominator of the `valu_*` rows
+                extras["probe_valu_pk_fma_f32_tflops"] = {f"{w}_waves_per_simd": round(mm.probe_valu_f32(True, w), 1) for w in (2, 3, 4)}
                 extras["probe_hbm_copy_gbps"] = round(mm.probe_hbm_copy(1 << 30), 1)
                 extras["probe_hbm_read_gbps"] = round(mm.probe_hbm_read(1 << 30), 1)
                 extras["probe_lds_read_gbps"] = {w: round(mm.probe_lds_read(v), 1) for w, v in

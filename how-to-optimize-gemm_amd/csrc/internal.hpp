@@ -148,7 +148,7 @@ struct mmh_context {
   int sk_order_min10 = 18;     // ... from this many tiles per workgroup, in tenths (tools build: option 104)
   int dma_edge = 1;            // ragged / 4-byte-aligned shapes may run the guarded LDS-DMA tiles (MMH_OPT_DMA_EDGE)
   int dma_dword_rows = 1;      // ... including operands whose rows are only 4-byte aligned (odd lda / ldb / base)
-  int sk_chain = 1;            // stream-K launches of the K2M tiles run a range's parts as one stream of slices (MMH_OPT_STREAMK_CHAIN)
+  int sk_chain = 1;            // stream-K launches of the K2W tiles (launch_dma5.hip) run a range's parts as one stream of slices (MMH_OPT_STREAMK_CHAIN)
   int rim5 = 0;                // tools build only (MMH_OPT_RIM5): the RIM launch of the 64x64 K2W tile -- measured, it loses
   int ab_nodefer = 0;          // tools build only (option 102): stream-K heads publish on the spot (no deferred publish)
   int ab_valu_old = 0;         // tools build only (option 105): the K1 ids run the register-staged K1 of rounds 1-4, not K1W

@@ -13,7 +13,9 @@
 // MFMA, same k order: the bits of every other kernel here.
 //   * NL: one loader issues a 1 KiB piece per ~64 cycles = 16 B/clk; a 64x64 tile consumes exactly that (16 KiB per
 //     1024 matrix-pipe cycles), so its loader is the bound -- it gets TWO; the larger tiles (24 KiB / 2048, 32 KiB /
-//     4096 cycles) are served by one.
+//     4096 cycles) would be served by one, but one loader shares a SIMD with a consumer and holds it -- and at every
+//     barrier the workgroup -- back: launch_dma5.hip instantiates FOUR for the 128-wide and the 96x64 tiles (measured,
+//     profiles/r04_notes.md section 1).
 //   * NBUF: ring depth.  A loader's `vmcnt` is a 6-bit counter, so (NBUF - 2) x (pieces per loader and slice) <= 63.
 //   * D: fragments are read D k-steps ahead of the MFMAs that use them; with one wave per SIMD a ds_read_b32/_b64
 //     stream reaches a fifth of the LDS rate (MI355X_MICROARCH.md, LDS: "from ~4 waves per SIMD"), so the one-

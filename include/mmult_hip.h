@@ -96,13 +96,14 @@ typedef struct mmh_context *mmh_handle_t;
  * three 32-deep K-slice buffers = 48 / 72 / 96 KiB, i.e. 3 / 2 / 1 workgroups per CU, counted vmcnt waits,
  * no registers -> LDS stores at all) -- the register-staged
  * packing stage is what bounds the small tiles.  Same chain, same bits; any shape and 4-byte alignment (guarded
- * instantiations, round 3); what MMH_KERNEL_AUTO ran in round 3 -- since round 4 it runs K2W, these stay as forced
- * kernels / ladder rungs. */
+ * instantiations, round 3); what MMH_KERNEL_AUTO ran in round 3.  Since round 5 they are candidates of AUTO's cost table
+ * beside K2W: their 256-thread workgroups and shorter preamble win on small shapes (m or n below ~600, K below ~500). */
 #define MMH_KERNEL_MFMA_64X64_DMA 25
 #define MMH_KERNEL_MFMA_128X64_DMA 27
 #define MMH_KERNEL_MFMA_128X128_DMA 28
 /* K2W (sgemm_dma5.hpp, round 4): K2L's tiles with LOADER waves that do nothing but the LDS-DMA (the pieces of a
- * K-slice, two slices ahead; two loaders for the 64x64 tile, one for the others), so that the four MFMA waves never
+ * K-slice, two slices ahead; two loaders for the 64x64 tile, four for the 128-wide and the 96x64 tiles, one for 96x96), so
+ * that the four MFMA waves never
  * stall on a vector-memory issue; under stream-K the loaders walk the parts of a range as ONE stream of slices
  * (MMH_OPT_STREAMK_CHAIN).  Thin edge tiles skip the MFMAs of 16-row / 16-column blocks that hold no element.
  * Same chain, same bits. */
@@ -257,15 +258,16 @@ int mmh_kernel_id(const char *short_name);
  * default because it does not pay: alone the tiles of 1024 x 1024 x 1025 take 20 us and the rim 13 us, together 28-29 us
  * -- against 27 us for the plain launch of 17 x 17 edge tiles. */
 #define MMH_OPT_RIM 11
-/* MMH_OPT_STREAMK_CHAIN (default 1): stream-K launches of the K2M tiles (sgemm_dma32.hpp) run the parts of a workgroup's
- * range as ONE stream of K-slices -- a part's last slices fetch the next part's first ones -- instead of starting every
+/* MMH_OPT_STREAMK_CHAIN (default 1): stream-K launches of the K2W tiles (sgemm_dma5.hpp; launch_dma5.hip picks the
+ * instantiation) run the parts of a workgroup's range as ONE stream of K-slices -- a part's last slices fetch the next part's first ones -- instead of starting every
  * part with an empty pipeline.  Same bits; 0 = the unchained form (the A/B baseline). */
 #define MMH_OPT_STREAMK_CHAIN 12
 /* MMH_OPT_PERSIST (default 0): 1 = tile counts that ARE whole rounds of the persistent grid (>= 2 tiles per
  * workgroup) also run as the persistent launch: every workgroup walks its tiles in the phase tables' level order,
  * so the co-resident workgroups of an XCD start together and stay in K lock-step (what a fresh workgroup per tile
  * loses to dispatch stagger), and the K2W loaders fetch the next tile's first slices under the current tile's
- * store.  No partial tiles are handed over in such a launch. */
+ * store.  No partial tiles are handed over in such a launch.  Applies to FORCED kernels only: under MMH_KERNEL_AUTO the
+ * cost table has decided the launch form (it prices no persistent whole-round launch: measured 0.3 % slower). */
 #define MMH_OPT_PERSIST 13
 /* MMH_OPT_RIM5 (tools build only; the product accepts 0): shapes ONE row and / or column past a multiple of 64 run the
  * 64x64 K2W tiles of the TRIMMED shape and an extra wave per edge tile computes the rim on the vector ALU out of the

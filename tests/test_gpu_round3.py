@@ -457,13 +457,17 @@ def test_the_host_plan_is_what_the_device_launches(mm):
     fam = {("mfma_dma5", "64,64"): "mfma_64x64_dma5", ("dma5_streamk", "64,64"): "mfma_64x64_dma5",
            ("mfma_dma5", "128,64"): "mfma_128x64_dma5", ("dma5_streamk", "128,64"): "mfma_128x64_dma5",
            ("mfma_dma5", "128,128"): "mfma_128x128_dma5", ("dma5_streamk", "128,128"): "mfma_128x128_dma5",
-           ("mfma_dma5", "96,96"): "mfma_96x96_dma5",
+           ("mfma_dma5", "96,96"): "mfma_96x96_dma5", ("mfma_dma5", "96,64"): "mfma_96x64_dma5",
+           ("mfma_dma", "64,64"): "mfma_64x64_dma", ("dma_streamk", "64,64"): "mfma_64x64_dma",           # round 5: K2L is a candidate
+           ("mfma_dma", "128,64"): "mfma_128x64_dma", ("dma_streamk", "128,64"): "mfma_128x64_dma",
+           ("mfma_dma", "128,128"): "mfma_128x128_dma", ("dma_streamk", "128,128"): "mfma_128x128_dma",
            ("mfma", "256,256"): "mfma_256x256", ("mfma_streamk", "256,256"): "mfma_256x256"}
     mm.set_kernel("auto")
     cus = mm.device_info()["cu_count"]
     for (m, n, k) in [(1024, 1024, 64), (1152, 1152, 96), (2048, 2048, 64), (2304, 2304, 64), (2817, 2817, 40), (3584, 3584, 64),
                       (4096, 4096, 64), (4000, 4000, 40), (300, 5000, 70), (8192, 1024, 64), (1023, 1025, 33), (1536, 1536, 1536),
-                      (2560, 2560, 2560), (1025, 1025, 1025), (4352, 4352, 4352), (6000, 3000, 1000)]:
+                      (2560, 2560, 2560), (1025, 1025, 1025), (4352, 4352, 4352), (6000, 3000, 1000), (1152, 1152, 1152), (542, 1106, 283),
+                      (1083, 614, 264), (2000, 2000, 2000), (3329, 3329, 3329)]:
         a = torch.rand((m, k), device="cuda")
         b = torch.rand((k, n), device="cuda")
         mm.matmul(a, b)
