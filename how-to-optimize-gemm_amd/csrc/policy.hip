@@ -78,7 +78,19 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
     const long cmax = (tiles + cus - 1) / cus;
     const int occ = (int)std::min<long>(cmax, f.w);
     const bool whole = fast_shape(f.bm, f.bn, kSliceK, g);
-    double t = (whole ? f.fix_p_whole : f.fix_p) + (double)cmax * (nk * f.s_p[occ - 1] + f.tile_p[occ - 1]);
+    // K2W's thin edge tiles (a last tile row / column with at most 16 valid rows / columns: a fraction of a tile's MFMAs,
+    // dispatched last, beside whole tiles) cost MMH_POLICY_THIN of a round where they add a tile to the fullest CU
+    // (N = 1025 against 1024 on the 64x64 tile: 26.3 against 18.1 us; tools/policy_fit.py THIN)
+    double cmax_p = (double)cmax;
+    if (is_k2w(f.kernel) && !tiles_rim) {
+      const int nbm = (g.m + f.bm - 1) / f.bm, nbn = (g.n + f.bn - 1) / f.bn;
+      const int tr = (nbm > 1 && g.m - (nbm - 1) * f.bm <= 16) ? 1 : 0, tc = (nbn > 1 && g.n - (nbn - 1) * f.bn <= 16) ? 1 : 0;
+      if (tr || tc) {
+        const long full = (long)(nbm - tr) * (nbn - tc), cfull = (full + cus - 1) / cus;
+        cmax_p = (double)cfull + MMH_POLICY_THIN * (double)(cmax - cfull);
+      }
+    }
+    double t = (whole ? f.fix_p_whole : f.fix_p) + cmax_p * (nk * f.s_p[occ - 1] + f.tile_p[occ - 1]);
     if (cmax > f.w && tiles % ((long)f.w * cus) != 0) t *= MMH_POLICY_MULTIROUND_MARGIN;   // a ragged last round
     if (best.kernel < 0 || t < best.us) best = Plan{f.kernel, 1, t, 0, f.bm, f.bn};
     if (f.has_sk && (!ctx || ctx->streamk) && !tiles_rim) {

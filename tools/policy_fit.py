@@ -37,6 +37,7 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CUS = 256
+THIN = 0.55    # what a round of K2W's thin edge tiles costs, in rounds of whole tiles (N = 1025 against 1024, plain: 26.3 against 18.1 us)
 RIM5 = False     # MMH_OPT_RIM5 (tools build; measured, it loses): the fused rim launch of the 64x64 tile
 # family: (kernel short name, BM, BN, co-resident workgroups per CU of a plain launch, has a stream-K form,
 #          persistent workgroups per CU of its stream-K launches, the kernel id's macro)
@@ -78,6 +79,15 @@ def geometry(fam, m, n, k, cus=CUS):
     tiles = nbm * nbn
     nk = -(-k // 32)
     cmax = -(-tiles // cus)
+    # K2W's thin edge tiles (a last tile row / column of at most 16 valid rows / columns: a fraction of a tile's MFMAs,
+    # dispatched last, beside whole tiles): a plain launch is priced as the whole tiles' rounds + THIN x the thin tiles'
+    thin = 0
+    if FAMILIES[fam][0].endswith("_dma5"):
+        tr = 1 if nbm > 1 and m - (nbm - 1) * bm <= 16 else 0
+        tc = 1 if nbn > 1 and n - (nbn - 1) * bn <= 16 else 0
+        thin = tiles - (nbm - tr) * (nbn - tc)
+    cfull = -(-(tiles - thin) // cus)
+    cmax_p = cfull + THIN * (cmax - cfull)     # (thin tiles cost only where they add a tile to the fullest CU)
     wp = 0
     for cand in range(skw, 0, -1):      # (the grid launch_streamk launches: at most skw workgroups per CU)
         if tiles >= cand * cus:
@@ -85,7 +95,7 @@ def geometry(fam, m, n, k, cus=CUS):
             break
     sk_possible = has_sk and wp > 0 and tiles % (wp * cus) != 0
     whole = m % bm == 0 and n % bn == 0 and k % 32 == 0      # dense operands, 16-byte aligned bases (how the sets are measured)
-    return dict(tiles=tiles, nk=nk, cmax=cmax, occ=min(cmax, w), wp=wp, sk_possible=sk_possible, w=w, whole=whole)
+    return dict(tiles=tiles, nk=nk, cmax=cmax, cmax_p=cmax_p, occ=min(cmax, w), wp=wp, sk_possible=sk_possible, w=w, whole=whole)
 
 
 def rows_of(dataset):
@@ -159,8 +169,8 @@ def fit(rows):
                 lo = 3 if g["whole"] else 0
                 if form == "plain":
                     feat[lo] = 1.0
-                    feat[6 + g["occ"] - 1] = g["cmax"] * g["nk"]
-                    feat[9 + g["occ"] - 1] = g["cmax"]
+                    feat[6 + g["occ"] - 1] = g["cmax_p"] * g["nk"]
+                    feat[9 + g["occ"] - 1] = g["cmax_p"]
                 else:
                     feat[lo + g["wp"] - 1] = 1.0
                     feat[6 + g["wp"] - 1] = g["tiles"] * g["nk"] / CUS
@@ -198,7 +208,7 @@ def fit(rows):
         if fo == "plain" and g["cmax"] > g["w"] and g["tiles"] % (g["w"] * CUS) != 0 and table[f]["n_p"]:
             e = table[f]
             ratios.append(us / (e["fix_p_whole" if g["whole"] else "fix_p"] +
-                                g["cmax"] * (g["nk"] * e["s_p"][g["occ"] - 1] + e["tile_p"][g["occ"] - 1])))
+                                g["cmax_p"] * (g["nk"] * e["s_p"][g["occ"] - 1] + e["tile_p"][g["occ"] - 1])))
     table["_margin"] = round(float(np.percentile(ratios, 90)), 3) if ratios else 1.0
     return table
 
@@ -209,7 +219,7 @@ def predict(table, fam, form, m, n, k, cus=CUS):
         return math.inf       # a family the dataset does not hold: not a candidate
     g = geometry(fam, m, n, k, cus)
     if form == "plain":
-        t = e["fix_p_whole" if g["whole"] else "fix_p"] + g["cmax"] * (g["nk"] * e["s_p"][g["occ"] - 1] + e["tile_p"][g["occ"] - 1])
+        t = e["fix_p_whole" if g["whole"] else "fix_p"] + g["cmax_p"] * (g["nk"] * e["s_p"][g["occ"] - 1] + e["tile_p"][g["occ"] - 1])
         return t * table.get("_margin", 1.0) if g["cmax"] > g["w"] and g["tiles"] % (g["w"] * cus) != 0 else t
     if not g["sk_possible"] or e["n_s"] == 0:
         return math.inf
@@ -301,6 +311,7 @@ def emit(table, path, source):
         fams = {k: v for k, v in table.items() if not k.startswith("_") and v["n_p"]}
         for fam, e in fams.items():
             f.write(f"// {fam}: plain {e['n_p']} rows, rms {e['rms_p']:.3f}; stream-K {e['n_s']} rows, rms {e['rms_s']:.3f}\n")
+        f.write(f"#define MMH_POLICY_THIN {THIN:.2f}f   // a round of K2W's thin edge tiles, in rounds of whole tiles (plain launches)\n")
         f.write(f"#define MMH_POLICY_MULTIROUND_MARGIN {table.get('_margin', 1.0):.3f}f   // plain launches of more than one round: p90 of measured / predicted\n")
         f.write("#define MMH_POLICY_FAMILIES \\\n")
         for fam, e in fams.items():
