@@ -565,12 +565,19 @@ def main():
                         if kern in ("rocblas", "hipblaslt"):   # the vendor comparators, behind the same C ABI
                             try:                                # (cuda/MMult_cuBLAS_1.cpp, cuda/MMult_cuBLAS_2.cpp)
                                 ms = mm.time_comparator(kern, p, p, p, pa.data_ptr(), p, pb.data_ptr(), p, pc.data_ptr(), p,
-                                                        warmup=3, reps=20, stream=stream)
+                                                        warmup=3, reps=10, stream=stream)
+                                ms = mm.time_comparator(kern, p, p, p, pa.data_ptr(), p, pb.data_ptr(), p, pc.data_ptr(), p,
+                                                        warmup=max(3, int(15.0 / max(ms, 1e-3))), reps=20, stream=stream)
                             except H.MMultError:
                                 continue
                         else:
+                            # sustained, like `value`: a first burst sizes ~15 ms of untimed launches in front of the timed
+                            # ones (three warm-ups of a 30 us kernel leave the chip at its idle clock: round 4's extras read
+                            # the VALU rung 15 % and `auto` 5 % under their sustained rates at N = 1024)
                             ms = mm.time_sgemm(p, p, p, pa.data_ptr(), p, pb.data_ptr(), p, pc.data_ptr(), p,
-                                               warmup=3, reps=20, stream=stream)
+                                               warmup=3, reps=10, stream=stream)
+                            ms = mm.time_sgemm(p, p, p, pa.data_ptr(), p, pb.data_ptr(), p, pc.data_ptr(), p,
+                                               warmup=max(3, int(15.0 / max(ms, 1e-3))), reps=20, stream=stream)
                         sweep[f"{kern}_{p}"] = round(2.0 * p ** 3 * 1e-9 / (ms * 1e-3), 1)
                 mm.set_splitk(0)
                 mm.set_kernel(args.kernel)
