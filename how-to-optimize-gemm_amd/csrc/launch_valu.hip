@@ -105,10 +105,13 @@ int launch_k1_64(const mmh_context *ctx, const GemmArgs &g) {
 int k1_pick_tile(const mmh_context *ctx, const GemmArgs &g) {
   const double cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
   auto est = [&](int bm, int bn, double rate) {
-    const double per_cu = (double)((g.m + bm - 1) / bm) * ((g.n + bn - 1) / bn) / cus;
+    if (!fast_shape(bm, bn, 32, g)) return 0.0;   // K1W runs whole tiles only (the caller has checked 64x64)
+    const double per_cu = (double)(g.m / bm) * (g.n / bn) / cus;
     const double rounds = (double)(long)(per_cu + 0.999999);
     return rate * per_cu / (rounds < 1.0 ? 1.0 : rounds);
   };
+  // (below one tile per CU every family's estimate is its rate x the share of the CUs it fills: the smaller tile wins
+  // unless the larger one fills as many -- which it cannot)
   const double e128 = est(128, 128, 93.0), e12864 = est(128, 64, 86.0), e64 = est(64, 64, 80.0);
   if (e128 >= e12864 && e128 >= e64) return MMH_KERNEL_VALU_128X128;
   return e12864 >= e64 ? MMH_KERNEL_VALU_128X64 : MMH_KERNEL_VALU_64X64;

@@ -347,9 +347,11 @@ def test_one_element_off_the_grid_is_not_a_cliff(mm, n0):
     ragged row / column of tiles, odd leading dimensions -- stays within 10 % of N.  N + 1 needs one more row AND column
     of tiles (6-13 % more tile work at these sizes): it must stay within 20-26 % of N wherever that does not also start
     a new round of CUs.  1025 does (17 x 17 tiles of 64 x 64 for 256 CUs): round 4's thin edge tiles took it from 0.49 to
-    0.65-0.68 x N = 1024 (60 -> 79-83 TFLOP/s; hipBLASLt 86, rocBLAS 58) and it is held to 0.58 here; the rest is alignment, not
-    tiles -- rows of 1025 floats are only 4-byte aligned, every 16-byte DMA piece straddles two chunks, and 1024-wide data
-    with an odd leading dimension tops out at ~0.80 (profiles/r04_notes.md, r04_thin_tiles_edge.md)."""
+    0.65-0.68 x N = 1024 (60 -> 79-83 TFLOP/s; hipBLASLt 86, rocBLAS 58; round 5: 80.7 against 121) and it is held to 0.64
+    here (round 4 had lowered the bar to 0.58).  Why not the 0.85 round 3 asked for: the rest is
+    alignment, not tiles -- rows of 1025 floats are only 4-byte aligned, every 16-byte DMA piece straddles two chunks, and
+    1024-wide data with an odd leading dimension tops out at ~0.80 of the aligned rate; on top of that the extra row and
+    column of tiles start a second round on 33 of 256 CUs (profiles/r04_notes.md section 3, r04_thin_tiles_edge.md)."""
     import torch
     mm.set_kernel("auto")
     rates = {}
@@ -358,7 +360,7 @@ def test_one_element_off_the_grid_is_not_a_cliff(mm, n0):
         b = torch.rand((n, n), device="cuda") * 2 - 1
         c = torch.empty((n, n), device="cuda")
         best = 1e9
-        for _ in range(3):
+        for _ in range(5):
             ms = mm.time_sgemm(n, n, n, a.data_ptr(), n, b.data_ptr(), n, c.data_ptr(), n, warmup=40, reps=40,
                                stream=torch.cuda.current_stream().cuda_stream)
             best = min(best, ms)
@@ -368,7 +370,7 @@ def test_one_element_off_the_grid_is_not_a_cliff(mm, n0):
     # one (the cost table carries both), which is 5-10 % of a launch at N = 1024 .. 1536.  The bars leave a box's worth of
     # noise under those figures; round 2's cliff was 0.70 for N - 1.
     assert rates[n0 - 1] >= (0.88 if n0 != 1024 else 0.82) * rates[n0], rates
-    assert rates[n0 + 1] >= {1024: 0.58, 1536: 0.74}.get(n0, 0.80) * rates[n0], rates
+    assert rates[n0 + 1] >= {1024: 0.64, 1536: 0.74}.get(n0, 0.80) * rates[n0], rates
     mm.set_kernel("mfma")
 
 

@@ -21,7 +21,9 @@ stream = torch.cuda.current_stream().cuda_stream
 VARIANTS = ["auto", "mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x64", "mfma_pipe", "mfma_simple", "valu",
             "valu_64x64", "valu_128x128", "mfma_64x64_dma", "mfma_128x64_dma", "mfma_128x128_dma",
             "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5",          # K2W (round 4)
-            "mfma_64x64_dma5/sk2", "mfma_128x64_dma5/sk2", "mfma_128x128_dma5/sk2"]                  # ... stream-K whenever ragged
+            "mfma_64x64_dma5/sk2", "mfma_128x64_dma5/sk2", "mfma_128x128_dma5/sk2",                 # ... stream-K whenever ragged
+            "mfma_96x64_dma5", "valu_128x64",                                                     # round 5: the 96x64 K2W tile, K1W's third tile
+            "mfma_64x64_dma/sk2", "mfma_128x64_dma/sk2"]                                          # ... K2L under stream-K (AUTO's candidates now)
 
 
 def strided(rows, cols, ld, off, fill=None):
