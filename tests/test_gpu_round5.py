@@ -176,3 +176,41 @@ def test_k1w_the_vector_alu_rung_with_loader_waves_is_the_same_chain(mm, oracle,
         assert "sgemm_valu_kernel" in H.last_launch() and "guarded" in H.last_launch(), H.last_launch()
         assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True))
     mm.set_kernel("auto")
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "mfma_128x64"])
+def test_reserve_stream_covers_a_forced_register_staged_tile(oracle, kernel):
+    """mmh_reserve_stream promised a workspace set large enough for "anything MMH_KERNEL_AUTO or a forced
+    tile can launch" and sized the partial-tile slots for the LDS-DMA tiles' residencies -- a forced register-staged
+    128x128 tile (64 KiB of LDS: two persistent workgroups per CU, 32 MiB of slots) or 128x64 tile (three) on a shape
+    with fewer 256x256 tiles than CUs was then refused at capture time.  Now the reservation covers them: the stream-K
+    launch captures on a reserved side stream and its replays are the eager result, bit for bit."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    h = H.MMult(0, kernel)
+    h.set_streamk(2)
+    try:
+        m, n, k = 3072 + 128, 3072 + 256, 96          # 650 / 1300 tiles: ragged on 512 / 768 persistent workgroups; 169 tiles of 256x256 < 256 CUs
+        a, b = oracle.harness_inputs(m, n, k, seed=31)
+        da, db = dev(a), dev(b)
+        eager = h.matmul(da, db).clone()
+        assert "streamk" in H.last_launch() and "persistent" in H.last_launch(), H.last_launch()
+        assert np.array_equal(eager.cpu().numpy(), oracle.ref_mmult(a, b, fma=True))
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        h.reserve_stream(side.cuda_stream, m, n, k)
+        c = torch.full((m, n), float("nan"), device="cuda")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                h.matmul(da, db, out=c)                # (refused with MMH_ERR_UNSUPPORTED before round 5)
+        for rep in range(3):
+            c.fill_(float("nan"))
+            with torch.cuda.stream(side):
+                graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(c, eager), rep
+        assert h.streamk_timeouts() == 0
+    finally:
+        h.close()
