@@ -181,3 +181,19 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"(from|import)\s+oracle|oracle/|liboracle|orc_", text):
                     offenders.append(p)
     assert offenders == []
+
+
+def test_the_kernel_headers_carry_no_tools_build_preprocessor_switches():
+    """the product's kernel headers hold what ships.  The tile families that were measured and lost
+    live under tools/ab/ (compiled by build_ab_library() only); where an A/B switch rides in a kernel argument's spare
+    bits the header tests `kAbBuild` with `if constexpr` -- no `#ifdef MMH_AB_BUILD` inside any csrc/*.hpp but the one
+    in internal.hpp that defines the constant."""
+    import glob
+    csrc = os.path.join(REPO, "how-to-optimize-gemm_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hpp"))):
+        text = open(path).read()
+        n = sum(1 for line in text.splitlines() if line.lstrip().startswith("#if") and "MMH_AB_BUILD" in line)
+        assert n == (1 if path.endswith("internal.hpp") else 0), (path, n)
+    for name in ("sgemm_dma32.hpp", "launch_dma32.hip", "sgemm_dma_rim.hpp", "sgemm_dma5_rim.hpp"):
+        assert os.path.exists(os.path.join(REPO, "tools", "ab", name)), name
+        assert not os.path.exists(os.path.join(csrc, name)), name
