@@ -7,8 +7,9 @@ rules are read off (round 4; the reference's `NEW := MMult_xxx` switch, cuda/mak
 
 A variant is a kernel's short name (mmh_kernel_id) optionally followed by /sk0 (MMH_OPT_STREAMK = 0: one
 workgroup per tile), /sk1 (the library's own policy, the default) or /sk2 (stream-K whenever the tile count is
-ragged), with --ab also /gN, /nd and /oo (tools build switches: raster group height, no deferred publish, a whole-tile
-stream-K launch bounded by its own instantiation's residency), /p1 (MMH_OPT_PERSIST = 1: whole rounds of the persistent grid run persistent too), and /nc (MMH_OPT_STREAMK_CHAIN = 0: the K2M tiles' stream-K parts unchained); `rocblas` / `hipblaslt` are the vendor comparators.  Protocol as tools/offgrid_sweep.py: every burst
+ragged), with --ab also /gN, /nd, /oo, /omNN, /np and /k1old (tools build switches: raster group height, no deferred publish, a whole-tile
+stream-K launch bounded by its own instantiation's residency, phase-ordered tables from NN/10 tiles per workgroup, no LDS pin of
+persistent launches, the register-staged K1 of rounds 1-4 instead of K1W), /p1 (MMH_OPT_PERSIST = 1: whole rounds of the persistent grid run persistent too), and /nc (MMH_OPT_STREAMK_CHAIN = 0: the K2M tiles' stream-K parts unchained); `rocblas` / `hipblaslt` are the vendor comparators.  Protocol as tools/offgrid_sweep.py: every burst
 through the C ABI after ~--warm-ms of untimed launches of its own variant, --rounds interleaved rounds, medians.
 --check compares every variant's C with the first variant's, bit for bit.  Needs a GPU."""
 from __future__ import annotations
@@ -75,6 +76,7 @@ def main():
             mm.set_option(101, int(gm[0][1:]) if gm else 0)
             mm.set_option(102, 1 if "nd" in parts[1:] else 0)
             mm.set_option(103, 1 if "oo" in parts[1:] else 0)   # whole-tile stream-K launches bounded by their own residency
+            mm.set_option(100, 0 if "np" in parts[1:] else 1)   # /np: persistent launches ask for their own LDS only (no 160 KiB / w pin)
             mm.set_option(105, 1 if "k1old" in parts[1:] else 0)   # /k1old: the register-staged K1 of rounds 1-4
             om = [x for x in parts[1:] if x.startswith("om") and x[2:].isdigit()]   # /omNN: phase-ordered tables from NN/10 tiles per workgroup
             mm.set_option(104, int(om[0][2:]) if om else 18)
