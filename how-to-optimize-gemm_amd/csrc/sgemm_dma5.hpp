@@ -283,6 +283,9 @@ struct Dma5Segment {
         static_for<LA>([&](auto s_c) {
           constexpr int S = decltype(s_c)::value;
           issue(lds + S * STAGE, kb + S, S);
+          // (the first slice's pieces leave before the second slice's offsets are worked out: left alone hipcc computes
+          // every piece's scalar offset of both slices in front of the first DMA -- ~40 instructions, round 5)
+          __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LA - 1) * NPL) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -613,6 +616,9 @@ sgemm_mfma_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, false, EDGE, false, NL, D>;
   int tm, tn;
+  // (round 5: every kernel argument is requested HERE -- left alone hipcc loads the operands' pointers and leading
+  // dimensions only behind the branch to the loader path, a second scalar-memory round trip in front of the first DMA)
+  asm volatile("" ::"s"(A), "s"(B), "s"(C), "s"(lda), "s"(ldb), "s"(ldc), "s"(k));
   dma_stamp(0);
   if constexpr (EDGE) {
     const int thin_row = (nbm > 1 && m - (nbm - 1) * BM <= 16) ? 1 : 0, thin_col = (nbn > 1 && n - (nbn - 1) * BN <= 16) ? 1 : 0;
@@ -866,6 +872,7 @@ sgemm_dma5_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
                           int *__restrict__ flags, float *__restrict__ parts, const int *__restrict__ order,
                           const int *__restrict__ place, int *__restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  asm volatile("" ::"s"(A), "s"(B), "s"(C), "s"(lda), "s"(ldb), "s"(ldc), "s"(k), "s"(flags), "s"(parts), "s"(order), "s"(place));   // (every argument requested at entry: sgemm_mfma_dma5_kernel)
   streamk5_body<BM, BN, KB, WTM, WTN, NBUF, EDGE, CHAINED, NL, D>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn,
                                                                    flags, parts, order, place, stats);
 }

@@ -94,6 +94,32 @@ __device__ __forceinline__ void block_to_tile_g(int bid, int nblk, int nbm, int 
   const int q = nblk / NXCD, r = nblk % NXCD;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   const int per_group = gm * nbn;
+  // (round 5: the two integer divisions below are ~55 scalar instructions in front of every workgroup's first load; the
+  // reference sweep's grids -- 16 x 16 tiles at N = 1024 -- have power-of-two group sizes: shifts, behind a uniform branch)
+  int group;
+  if ((per_group & (per_group - 1)) == 0) group = logical >> __builtin_ctz(per_group);
+  else group = logical / per_group;
+  const int first_m = group * gm;
+  const int gsize = min(nbm - first_m, gm);
+  const int in_group = logical - group * per_group;
+  if ((gsize & (gsize - 1)) == 0) {
+    tm = first_m + (in_group & (gsize - 1));
+    tn = in_group >> __builtin_ctz(gsize);
+  } else {
+    tn = in_group / gsize;
+    tm = first_m + in_group - tn * gsize;
+  }
+}
+// the same map with its two divisions taken unconditionally (rounds 1-4's form).  K1W keeps it: measured with the
+// power-of-two fast path above its 128x64 tile ran 1-4 % SLOWER (N = 1152 .. 1408, 2304: two builds side by side in one
+// process, tools/ab_lib.py) -- nothing in the map's values or the kernel's registers differs, the VALU loop's code just
+// lands elsewhere -- while the MFMA tiles gained 0.4-2.7 % from it.
+__device__ __forceinline__ void block_to_tile_g_div(int bid, int nblk, int nbm, int nbn, int gm, int &tm, int &tn) {
+  const int xcd = bid % NXCD;
+  const int local = bid / NXCD;
+  const int q = nblk / NXCD, r = nblk % NXCD;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  const int per_group = gm * nbn;
   const int group = logical / per_group;
   const int first_m = group * gm;
   const int gsize = min(nbm - first_m, gm);

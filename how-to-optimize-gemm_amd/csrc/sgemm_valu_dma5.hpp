@@ -57,7 +57,7 @@ sgemm_valu_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda
   typedef float f32x2 __attribute__((ext_vector_type(2)));
 
   int tm, tn;
-  block_to_tile_g(blockIdx.x, nbm * nbn, nbm, nbn, T::GM, tm, tn);
+  block_to_tile_g_div(blockIdx.x, nbm * nbn, nbm, nbn, T::GM, tm, tn);
   const int row0 = tm * BM, col0 = tn * BN;
   const int nk = k / KB;
   const int lane = threadIdx.x & 63;
