@@ -54,7 +54,7 @@ FAMILIES = {
     "t96x64": ("mfma_96x64_dma5", 96, 64, 2, False, 0, "MMH_KERNEL_MFMA_96X64_DMA5"),
     "t256": ("mfma_256x256", 256, 256, 1, True, 1, "MMH_KERNEL_MFMA_256X256"),
     # K2L (round 3's LDS-DMA tiles, every wave issuing its share of the DMA): candidates since round 5
-    "l64": ("mfma_64x64_dma", 64, 64, 2, True, 2, "MMH_KERNEL_MFMA_64X64_DMA"),   # (184 registers with the AGPRs: two workgroups per CU, not the three its LDS allows)
+    "l64": ("mfma_64x64_dma", 64, 64, 2, False, 0, "MMH_KERNEL_MFMA_64X64_DMA"),   # plain launches only: its forced stream-K launches run three per CU (768 workgroups), a grid the two-per-CU model cannot price and AUTO would not launch
     "l128x64": ("mfma_128x64_dma", 128, 64, 2, True, 2, "MMH_KERNEL_MFMA_128X64_DMA"),
     "l128": ("mfma_128x128_dma", 128, 128, 1, True, 1, "MMH_KERNEL_MFMA_128X128_DMA"),
 }
