@@ -101,6 +101,7 @@ struct Dma5Next {
 struct Dma5Link {
   int pos = 0;
   bool primed = false;
+  bool fresh = true;   // nothing has run in this workgroup yet: the ring is idle, no wave holds a fragment read of it
 };
 // A stream-K HEAD part's publish, deferred into the part that follows it (a WHOLE tile: nothing it depends on): the
 // partial tile went out as write-through stores; instead of draining them on the spot -- every consumer wave idle for
@@ -206,10 +207,15 @@ struct Dma5Segment {
       link.primed = chain;
     }
     if (!primed) {
-      if constexpr (CHAIN) __syncthreads();   // every wave is past its last fragment read of whatever ran before
+      // every wave is past its last fragment read of whatever ran before -- nothing did in front of a workgroup's FIRST
+      // segment (round 5: that barrier made the loaders' first DMA wait for the consumers' per-lane setup)
+      if constexpr (CHAIN) {
+        if (!__builtin_amdgcn_readfirstlane((int)link.fresh)) __syncthreads();
+      }
       pos = 0;
       if constexpr (CHAIN) link.pos = n_slices % NBUF;
     }
+    if constexpr (CHAIN) link.fresh = false;
 
     if (L.loader) {
       // ------------------------------------------------------------------ the loader waves
@@ -687,9 +693,19 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
   // total < 2^31: launch_streamk): total q / G = (total / G) q + ((total % G) q) / G, and (total % G) q < G^2.  (The
   // 64-bit divisions this replaces were a microsecond of scalar code in front of every workgroup's first DMA.)
   const unsigned total = (unsigned)Tn * (unsigned)nk;
-  const unsigned per = total / (unsigned)G, rem = total % (unsigned)G;
-  const unsigned u0 = per * (unsigned)q + rem * (unsigned)q / (unsigned)G;
-  const unsigned u1 = per * (unsigned)(q + 1) + rem * (unsigned)(q + 1) / (unsigned)G;
+  unsigned per, rem, u0, u1;
+  if ((G & (G - 1)) == 0) {   // (256 / 512 persistent workgroups: four divisions, ~110 scalar instructions, become shifts -- round 5)
+    const int sh = __builtin_ctz((unsigned)G);
+    per = total >> sh;
+    rem = total & (unsigned)(G - 1);
+    u0 = per * (unsigned)q + ((rem * (unsigned)q) >> sh);
+    u1 = per * (unsigned)(q + 1) + ((rem * (unsigned)(q + 1)) >> sh);
+  } else {
+    per = total / (unsigned)G;
+    rem = total % (unsigned)G;
+    u0 = per * (unsigned)q + rem * (unsigned)q / (unsigned)G;
+    u1 = per * (unsigned)(q + 1) + rem * (unsigned)(q + 1) / (unsigned)G;
+  }
   if (u1 <= u0) return;
   const int t_first = (int)(u0 / (unsigned)nk), k_first = (int)(u0 - (unsigned)t_first * (unsigned)nk);
   const int t_last = (int)((u1 - 1) / (unsigned)nk), k_last_end = (int)(u1 - (unsigned)t_last * (unsigned)nk);
@@ -699,8 +715,13 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
     const int group = tt / per_group, first_m = group * GMr;
     const int gsize = min(nbm - first_m, GMr);
     const int in_group = tt - group * per_group;
-    tm = first_m + in_group % gsize;
-    tn = in_group / gsize;
+    if ((gsize & (gsize - 1)) == 0) {
+      tm = first_m + (in_group & (gsize - 1));
+      tn = in_group >> __builtin_ctz((unsigned)gsize);
+    } else {
+      tn = in_group / gsize;
+      tm = first_m + in_group - tn * gsize;
+    }
   };
   // one lane's word made workgroup-uniform through the line of LDS behind the ring (the ring itself is never idle here)
   volatile int *word = reinterpret_cast<volatile int *>(lds + T::RING_BYTES / sizeof(float));
