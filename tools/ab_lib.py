@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--other", required=True)
     ap.add_argument("--kernels", default="auto")
     ap.add_argument("--sizes", default="1024,1152,1280,1408,1536,2048,4096")
+    ap.add_argument("--shapes", default="", help="m,n,k;m,n,k;... instead of square sizes")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--warm-ms", type=float, default=20.0)
@@ -51,17 +52,19 @@ def main():
         for which, (L, h) in libs.items():
             kid = L.mmh_kernel_id(kern.encode())
             assert kid >= 0 and L.mmh_set_kernel(h, kid) == 0, (which, kern)
-        for n in (int(x) for x in args.sizes.split(",")):
-            a = torch.rand((n, n), device="cuda") * 2 - 1
-            b = torch.rand((n, n), device="cuda") * 2 - 1
-            c = {w: torch.empty((n, n), device="cuda") for w in libs}
+        shapes = ([tuple(int(x) for x in t.split(",")) for t in args.shapes.split(";") if t] if args.shapes
+                  else [(int(x),) * 3 for x in args.sizes.split(",")])
+        for (m, n, k) in shapes:
+            a = torch.rand((m, k), device="cuda") * 2 - 1
+            b = torch.rand((k, n), device="cuda") * 2 - 1
+            c = {w: torch.empty((m, n), device="cuda") for w in libs}
             res = {w: [] for w in libs}
             launched, warm = {}, {}
             for w, (L, h) in libs.items():
-                assert L.mmh_sgemm(h, n, n, n, a.data_ptr(), n, b.data_ptr(), n, c[w].data_ptr(), n, 0, stream) == 0
+                assert L.mmh_sgemm(h, m, n, k, a.data_ptr(), k, b.data_ptr(), n, c[w].data_ptr(), n, 0, stream) == 0
                 launched[w] = L.mmh_last_launch().decode()
                 ms = C.c_float(0)
-                assert L.mmh_time_sgemm(h, n, n, n, a.data_ptr(), n, b.data_ptr(), n, c[w].data_ptr(), n, 3, 5, stream, C.byref(ms)) == 0
+                assert L.mmh_time_sgemm(h, m, n, k, a.data_ptr(), k, b.data_ptr(), n, c[w].data_ptr(), n, 3, 5, stream, C.byref(ms)) == 0
                 warm[w] = max(3, int(args.warm_ms / max(ms.value, 1e-3)))
             torch.cuda.synchronize()
             same = bool(torch.equal(c["new"], c["old"]))
@@ -69,11 +72,11 @@ def main():
                 for w in (("old", "new") if rnd % 2 else ("new", "old")):
                     L, h = libs[w]
                     ms = C.c_float(0)
-                    assert L.mmh_time_sgemm(h, n, n, n, a.data_ptr(), n, b.data_ptr(), n, c[w].data_ptr(), n, warm[w], args.reps, stream,
+                    assert L.mmh_time_sgemm(h, m, n, k, a.data_ptr(), k, b.data_ptr(), n, c[w].data_ptr(), n, warm[w], args.reps, stream,
                                             C.byref(ms)) == 0
-                    res[w].append(2.0 * n ** 3 / (ms.value * 1e-3) / 1e12)
+                    res[w].append(2.0 * m * n * k / (ms.value * 1e-3) / 1e12)
             med = {w: sorted(v)[len(v) // 2] for w, v in res.items()}
-            print(json.dumps({"kernel": kern, "n": n, "old_tf": round(med["old"], 2), "new_tf": round(med["new"], 2),
+            print(json.dumps({"kernel": kern, "shape": [m, n, k], "old_tf": round(med["old"], 2), "new_tf": round(med["new"], 2),
                               "new_over_old": round(med["new"] / med["old"], 4), "bit_equal": same,
                               "launched": launched["new"][:60]}), flush=True)
 
