@@ -53,7 +53,7 @@ EXPORTS = [
     "mmh_set_option", "mmh_get_option",
     "mmh_sgemm", "mmh_sgemm_host", "mmh_sgemm_host_timed", "mmh_igemm_s8", "mmh_quantize_sym_s8", "mmh_qgemm_f32",
     "mmh_sgemm_rocblas", "mmh_sgemm_hipblaslt", "mmh_shard_rows",
-    "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm", "mmh_shard_sgemm_streamed", "mmh_shard_pin",
+    "mmh_shard_create", "mmh_shard_destroy", "mmh_shard_set_kernel", "mmh_shard_info", "mmh_shard_sgemm", "mmh_shard_sgemm_streamed", "mmh_shard_chunks", "mmh_shard_pin",
     "mmh_shard_unpin",
     "mmh_rccl_version",
     "mmh_sgemm_sharded", "mmh_time_sgemm", "mmh_time_comparator", "mmh_trace_sgemm", "mmh_probe_mfma_f32", "mmh_probe_valu_f32", "mmh_probe_mfma_i8",
@@ -191,6 +191,7 @@ def lib() -> C.CDLL:
     L.mmh_shard_info.argtypes = [vp, ip, ip]
     L.mmh_shard_sgemm.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, fp]
     L.mmh_shard_sgemm_streamed.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, fp]
+    L.mmh_shard_chunks.argtypes = [C.c_int, C.c_int, ip]
     L.mmh_shard_pin.argtypes = [vp, vp, C.c_size_t]
     L.mmh_shard_unpin.argtypes = [vp, vp]
     L.mmh_rccl_version.argtypes = [ip]
@@ -230,6 +231,15 @@ def rccl_version() -> int:
     v = C.c_int(0)
     _check(lib().mmh_rccl_version(C.byref(v)), "mmh_rccl_version")
     return v.value
+
+
+def shard_chunks(k: int, b_chunks: int) -> list[int]:
+    """K boundaries of mmh_shard_sgemm_streamed's broadcast chunks (host arithmetic, no GPU): [0, ..., k]."""
+    k0 = (C.c_int * 65)()
+    c = lib().mmh_shard_chunks(int(k), int(b_chunks), k0)
+    if c < 0:
+        raise MMultError(c, "mmh_shard_chunks")
+    return [k0[i] for i in range(c + 1)]
 
 
 def shard_rows(m: int, nranks: int, rank: int) -> tuple[int, int]:
@@ -688,7 +698,7 @@ def sgemm_sharded(ngpus: int, a: np.ndarray, b: np.ndarray, kernel="mfma"):
     return c, dict(zip(("h2d", "bcast", "gemm", "d2h"), list(t)))
 
 
-__all__ = ["MMult", "ShardedMMult", "MMultError", "lib", "use_ab_library", "device_count", "rccl_version", "shard_rows",
+__all__ = ["MMult", "ShardedMMult", "MMultError", "lib", "use_ab_library", "device_count", "rccl_version", "shard_rows", "shard_chunks",
            "kernel_name", "last_launch", "use_timeline_library", "streamk_plan", "auto_plan", "sgemm_sharded", "KERNELS", "CHAIN_KERNELS", "AB_LIB_PATH",
            "OPT_SPLITK", "OPT_HOST_PANELS", "OPT_STREAMK_SPIN_LIMIT", "OPT_FAULT_INJECT", "OPT_STREAMK_ORDER", "OPT_DMA_EDGE", "OPT_STREAMK_DELEGATIONS", "OPT_RIM", "OPT_STREAMK_CHAIN", "OPT_PERSIST", "OPT_RIM5", "KERNEL_AUTO", "KERNEL_VALU", "KERNEL_MFMA", "KERNEL_MFMA_256", "KERNEL_NAIVE", "KERNEL_MFMA_SIMPLE", "KERNEL_MFMA_PIPE",
            "EXPORTS", "LIB_PATH", "OPT_STREAMK", "OPT_STREAMK_TIMEOUTS", "OPT_IGEMM_MODE", "OK", "ERR_INVALID_ARG", "ERR_HIP", "ERR_NO_DEVICE",

@@ -231,6 +231,12 @@ static int chunk_bounds(int k, int chunks, int *k0) {
   return chunks;
 }
 
+// the chunking as host arithmetic (tests, tools): k0[0 .. return value] = the K boundaries mmh_shard_sgemm_streamed uses
+int mmh_shard_chunks(int k, int b_chunks, int *k0) {
+  if (k < 0 || b_chunks < 0 || !k0) return MMH_ERR_INVALID_ARG;
+  return chunk_bounds(k, b_chunks, k0);
+}
+
 int mmh_shard_sgemm_streamed(mmh_shard_t sh, int m, int n, int k, const float *A, int lda, const float *B, int ldb, float *C,
                              int ldc, int gemm_reps, int b_chunks, float *timings_ms) {
   using clk = std::chrono::steady_clock;

@@ -382,6 +382,10 @@ int mmh_shard_sgemm(mmh_shard_t shard, int m, int n, int k, const float *A, int 
                     int ldb, float *C, int ldc, int gemm_reps, float *timings_ms);
 int mmh_shard_sgemm_streamed(mmh_shard_t shard, int m, int n, int k, const float *A, int lda, const float *B,
                              int ldb, float *C, int ldc, int gemm_reps, int b_chunks, float *timings_ms);
+/* The K boundaries of the streamed broadcast as host arithmetic (no device): returns the number of chunks c actually
+ * used (1 <= c <= min(b_chunks, ceil(k / 128), 64)) and fills k0[0 .. c] (k0 holds at least 65 ints): chunk i is rows
+ * k0[i] .. k0[i + 1] - 1 of B, every interior boundary a multiple of 128. */
+int mmh_shard_chunks(int k, int b_chunks, int *k0);
 /* Page-lock (hipHostRegister) a host range that is about to be passed to mmh_shard_sgemm more than once -- A, B
  * and C of one sweep size: copies from / to pageable memory run at a fraction of the PCIe rate.  Unpin before
  * the memory is freed; mmh_shard_destroy unpins whatever is left.

@@ -197,3 +197,24 @@ def test_the_kernel_headers_carry_no_tools_build_preprocessor_switches():
     for name in ("sgemm_dma32.hpp", "launch_dma32.hip", "sgemm_dma_rim.hpp", "sgemm_dma5_rim.hpp"):
         assert os.path.exists(os.path.join(REPO, "tools", "ab", name)), name
         assert not os.path.exists(os.path.join(csrc, name)), name
+
+
+def test_streamed_broadcast_chunks_are_whole_k_blocks_that_cover_k():
+    """mmh_shard_chunks: the K boundaries mmh_shard_sgemm_streamed cuts B's broadcast at (host arithmetic).  Every chunk is a
+    run of whole 128-deep K blocks (a chunk's A columns then start 512 bytes into a row: the unchunked launch's alignment
+    class), the chunks cover [0, k) in order, none is empty, and there are min(b_chunks, ceil(k / 128), 64) of them -- one
+    for b_chunks <= 1 or k <= 128 (and for k = 0: the GEMM then only clears C)."""
+    for k in (0, 1, 96, 128, 129, 300, 1024, 4096, 16384, 16385, 100000):
+        for b in (0, 1, 2, 3, 7, 8, 64, 65, 1000):
+            k0 = H.shard_chunks(k, b)
+            c = len(k0) - 1
+            blocks = (k + 127) // 128
+            assert c == max(1, min(b, blocks, 64)), (k, b, k0)
+            assert k0[0] == 0 and k0[-1] == k, (k, b, k0)
+            assert all(x % 128 == 0 for x in k0[:-1]), (k, b, k0)
+            if k > 0:
+                assert all(k0[i] < k0[i + 1] for i in range(c)), (k, b, k0)
+                sizes = [k0[i + 1] - k0[i] for i in range(c)]
+                assert max(sizes) - min(sizes[:-1] or sizes) <= 128 or c == 1, (k, b, sizes)      # near-equal runs
+    with pytest.raises(H.MMultError):
+        H.shard_chunks(-1, 4)
