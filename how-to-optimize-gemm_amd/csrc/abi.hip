@@ -92,9 +92,9 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       workspaces_suspect(h);   // a launch that timed out may have left hand-off counters behind
       return MMH_OK;
     case MMH_OPT_IGEMM_MODE:
-      if ((value >= 0 && value <= 8 && value != 7)
+      if ((value >= 0 && value <= 9)
 #ifdef MMH_AB_BUILD
-          || value == 7 || (value >= 10 && value <= 13)
+          || (value >= 10 && value <= 13)
 #endif
       ) {
         h->igemm_mode = value;

@@ -11,7 +11,28 @@
 
 using namespace mmh;
 
+// K3p's launch form.  Persistent (one workgroup per CU walking the tiles) saves a tile's launch and prologue: +1.3 / +4.5 /
+// +1.7 % at 8192 x 8192 x 1024 / x 2048 and 5120^3; one workgroup per tile lets the dispatcher hand the next tile to whichever
+// CU is free first -- tiles of a long K finish up to 20 us apart (tools/i8_timeline.py) -- and is 1.5 % ahead at 8192^3;
+// level in between (profiles/r06_i8_persist_ab.txt).  Mode 8 / 9 force one or the other.
+static int pp_grid_cap(const mmh_context *h, int mode, int k, int cus) {
+  if (mode == 9) return 0;
+  if (h->i8_grid_cap > 0) return h->i8_grid_cap;   // test hook: a few persistent workgroups walk a small shape's tiles
+  if (mode == 8) return cus;
+  return k <= 5120 ? cus : 0;
+}
+
 extern "C" {
+
+#ifdef MMH_DMA_TIMELINE
+// timeline build only: where K3p's waves 0 and 4 write their per-tile stamps (2 x 16 x 8 uint64 per workgroup; NULL = off)
+int mmh_ab_set_stamps_i8(mmh_handle_t h, void *stamps) {
+  if (!h) return MMH_ERR_INVALID_ARG;
+  ENTER(h);
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_i8_stamps), &stamps, sizeof(void *)));
+  return MMH_OK;
+}
+#endif
 
 int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda, const int8_t *dB,
                  int ldb, int32_t *dC, int ldc, int accumulate, void *stream) {
@@ -26,17 +47,16 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
       HIP_TRY(hipMemset2DAsync(dC, (size_t)ldc * 4, 0, (size_t)n * 4, (size_t)m, s));
     return MMH_OK;
   }
-  // mode 7 (A/B switch while K3p is being measured): the ping-pong schedule of the 256x256 in-place kernel
-  // K3p (igemm_s8_pp.hpp): the 256x256 in-place tile with its wave groups in ping-pong -- what mode 0 runs from one
-  // tile per CU up (mode 8 forces it, 7 is its 16-MFMA-per-phase form; 6 stays the lockstep K3t kernel for A/B)
+  // K3p (igemm_s8_pp.hpp): the 256x256 in-place tile with its wave groups in ping-pong, persistent over the tiles --
+  // what mode 0 runs from one tile per CU up.  Forced: 8 (as mode 0 launches it), 9 (one workgroup per tile: round 5's
+  // launch form, the A/B switch for the persistent loop), 7 (the same kernel on v_mfma_i32_16x16x32_i8, the instruction
+  // BASELINE.json configs[4] names: same bits, half the pipe's rate); 6 stays the lockstep K3t kernel.
   const int cus_ = h->cu_count > 0 ? h->cu_count : 256;
   if (igemm_s8_inplace_ok(dA, lda, dB, ldb, k) &&
-      (h->igemm_mode == 7 || h->igemm_mode == 8 || (h->igemm_mode == 0 && igemm_s8_big_tile(m, n, cus_)))) {
-#ifdef MMH_AB_BUILD   // (the 16-MFMA-per-phase form: tools build only)
-    if (h->igemm_mode == 7) HIP_TRY(launch_igemm_s8_pp<4>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
-    else
-#endif
-    HIP_TRY(launch_igemm_s8_pp<2>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s));
+      (h->igemm_mode == 7 || h->igemm_mode == 8 || h->igemm_mode == 9 ||
+       (h->igemm_mode == 0 && igemm_s8_big_tile(m, n, cus_)))) {
+    if (h->igemm_mode == 7) HIP_TRY(launch_igemm_s8_pp<32>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s, pp_grid_cap(h, 0, k, cus_)));
+    else HIP_TRY(launch_igemm_s8_pp<64>(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s, pp_grid_cap(h, h->igemm_mode, k, cus_)));
     return MMH_OK;
   }
   // Default mode: operands the in-place kernel cannot take as they are (an odd leading dimension, a
@@ -130,7 +150,7 @@ int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
   if (h->igemm_mode == 0 && igemm_s8_inplace_ok(qa, ka, qb, nb, k)) {
     // the int8 GEMM dequantises in its epilogue: no int32 image of C at all
     if (igemm_s8_big_tile(m, n, cus))
-      HIP_TRY(launch_igemm_s8_pp<2>(m, n, k, qa, ka, qb, nb, reinterpret_cast<int32_t *>(dC), ldc, 0, s, scales));
+      HIP_TRY(launch_igemm_s8_pp<64>(m, n, k, qa, ka, qb, nb, reinterpret_cast<int32_t *>(dC), ldc, 0, s, pp_grid_cap(h, 0, k, cus), scales));
     else
       HIP_TRY(launch_igemm_s8_dequant(m, n, k, qa, ka, qb, nb, dC, ldc, scales, s, cus));
     return MMH_OK;

@@ -579,26 +579,57 @@ __device__ __forceinline__ void igemm_s8_dma_tile(int m, int n, int k, const int
   }
 
   const float deq_inv = deq ? 1.0f / (deq[0] * deq[1]) : 0.0f;
-#pragma unroll
-  for (int t = 0; t < TM; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = crow + 16 * t + (BTR ? 0 : r), col = ccol + (BTR ? 16 * r : 0);
-      i32x4 v = BTR ? acc[t][r] : i32x4{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
-      if (ABL == 4 && (v[0] ^ v[1] ^ v[2] ^ v[3]) != 0x7ffffff1) continue;
-      if (deq) {
-        typedef float f32x4_t __attribute__((ext_vector_type(4)));
-        const f32x4_t f = {(float)v[0] * deq_inv, (float)v[1] * deq_inv, (float)v[2] * deq_inv, (float)v[3] * deq_inv};
-        v = __builtin_bit_cast(i32x4, f);
-      }
-      if (whole_c) {
-        *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + col) = v;
-      } else if (row < m) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (col + u < n) C[(size_t)row * ldc + col + u] = v[u];
-      }
+  auto to_c = [&](i32x4 v) {
+    if (deq) {
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      const f32x4_t f = {(float)v[0] * deq_inv, (float)v[1] * deq_inv, (float)v[2] * deq_inv, (float)v[3] * deq_inv};
+      v = __builtin_bit_cast(i32x4, f);
     }
+    return v;
+  };
+  auto put = [&](int row, int col, i32x4 v) {
+    if (whole_c) {
+      *reinterpret_cast<c_vec *>(C + (size_t)row * ldc + col) = v;
+    } else if (row < m) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (col + u < n) C[(size_t)row * ldc + col + u] = v[u];
+    }
+  };
+  if constexpr (BTR && ABL == 0) {
+    // In place, a lane holds tile[16 t + li][16 u + 4 g .. + 3]: stored as they are, the sixteen lanes of a quarter-wave
+    // hit sixteen ROWS with 16 bytes each (64 requests per store; round 6's timeline of K3p: 7.5 - 14 us to issue a
+    // 256x256 tile's stores).  Out through 4 KiB of the -- now idle -- ring per wave instead (igemm_s8_pp.hpp, the same
+    // transposer): lane l stores tile[16 t + 4 q + l / 16][4 (l % 16) .. + 3], a quarter-wave 256 contiguous bytes.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no LDS-DMA may land in what is reused below)
+    __syncthreads();                                    // every wave is past its last fragment read
+    int8_t *cx = ilds + wave * 4096;
+    const int eg = lane >> 4, eli = lane & 15;
+    const int drow = row0 + wm * 16 * TM + eg, dcol = col0 + wn * 64 + 4 * eli;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+      for (int u = 0; u < TN; ++u) *reinterpret_cast<i32x4 *>(cx + li * 256 + 16 * ((4 * u + g) ^ li)) = to_c(acc[t][u]);
+      i32x4 out[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = 4 * q + eg;
+        out[q] = *reinterpret_cast<const i32x4 *>(cx + rr * 256 + 16 * (eli ^ rr));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) put(drow + 16 * t + 4 * q, dcol, out[q]);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = crow + 16 * t + (BTR ? 0 : r), col = ccol + (BTR ? 16 * r : 0);
+        i32x4 v = BTR ? acc[t][r] : i32x4{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+        if (ABL == 4 && (v[0] ^ v[1] ^ v[2] ^ v[3]) != 0x7ffffff1) continue;
+        put(row, col, to_c(v));
+      }
+  }
 }
 
 // The kernel proper is a thin shell around the __device__ template (see LdsDma above).
@@ -788,16 +819,17 @@ inline bool igemm_s8_needs_pack(int mode, const int8_t *A, int lda, const int8_t
 
 // C_f32 = (float)(A x B) * (1 / (scales[0] * scales[1])) with the dequantisation in the epilogue; in-place
 // kernel only (the caller checks igemm_s8_inplace_ok and otherwise runs the two-pass form).
-// Tile choice of the in-place kernel by how evenly the tiles fill whole rounds of the chip: 256x256
-// tiles run one per CU and are ~12 % faster per MAC, 128x128 tiles two per CU (no stream-K for int8).
+// Tile choice of the in-place kernels: 256x256 tiles (K3p) run one per CU, 128x128 tiles (K3t) two per CU, and a full
+// round of 128x128 tiles takes 0.58 of a 256x256 round's time for half its work (4096^3: 68.5 us in two rounds against
+// 58.7 in one).  Rounds 3 - 5 never chose the big tile below one tile per CU; with the C stores coalesced (round 6) a
+// part-filled chip of big tiles beats two rounds of small ones: 3072^3 31.8 against 43.1 us, 3584^3 42.9 / 53.0, 6144^3
+// 205 / 217 -- and a single round of small tiles wins where there is one: 2048^3 14.1 / 22.5, 1024^3 9.8 / 13.1
+// (profiles/r06_i8_persist_ab.txt).
 inline bool igemm_s8_big_tile(int m, int n, int num_cus) {
   const long tiles256 = (long)((m + 255) / 256) * ((n + 255) / 256);
-  if (tiles256 < num_cus) return false;
   const long tiles128 = (long)((m + 127) / 128) * ((n + 127) / 128);
   const long r256 = (tiles256 + num_cus - 1) / num_cus, r128 = (tiles128 + 2L * num_cus - 1) / (2L * num_cus);
-  const double e256 = (double)tiles256 / (double)(r256 * num_cus);
-  const double e128 = 0.88 * (double)tiles128 / (double)(r128 * 2L * num_cus);
-  return e256 >= e128;
+  return (double)r256 <= 0.6 * (double)r128 + 1e-9;
 }
 
 inline hipError_t launch_igemm_s8_dequant(int m, int n, int k, const int8_t *A, int lda, const int8_t *B, int ldb,

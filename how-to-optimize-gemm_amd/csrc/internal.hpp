@@ -115,6 +115,7 @@ struct mmh_context {
   mmh::DevBuf a, b, c;     // staging for the host-pointer flavour
   mmh::DevBuf bt;          // int8 GEMM: packed (transposed, padded) B
   int igemm_mode = 0;      // 0 auto, see MMH_OPT_IGEMM_MODE
+  int i8_grid_cap = 0;     // test hook (environment MMH_I8_GRID_CAP, read at mmh_create): K3p's persistent grid, so that small shapes walk several tiles per workgroup
   mmh::DevBuf qa, qb, qc, qs;   // quantised GEMM workspace: int8 A, int8 B, int32 C, {amax bits, scales}
   // stream-K / split-K workspaces, one set PER STREAM the handle has launched on: launches on different streams
   // never share hand-off words or partial tiles, so nothing has to order one stream behind another and the handle

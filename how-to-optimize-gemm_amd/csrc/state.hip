@@ -346,6 +346,7 @@ int create_context(mmh_context **out, int device, bool warm) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
   if (const char *e = std::getenv("MMH_NO_PIN")) ctx->pin = (*e && *e != '0') ? 0 : 1;   // diagnostic A/B switches
   if (const char *e = std::getenv("MMH_NO_SK_ORDER")) ctx->sk_order = (*e && *e != '0') ? 0 : 1;
+  if (const char *e = std::getenv("MMH_I8_GRID_CAP")) ctx->i8_grid_cap = std::atoi(e) > 0 ? std::atoi(e) : 0;   // test hook (fuzz_i8.py)
   // the sticky error word: pinned, mapped host memory (the device adds to it with a system-scope atomic)
   void *host = nullptr, *dev = nullptr;
   if (hipHostMalloc(&host, 64, hipHostMallocMapped) == hipSuccess) {

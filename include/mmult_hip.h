@@ -214,7 +214,9 @@ int mmh_kernel_id(const char *short_name);
  * ds_read_b64_tr_b8) for 4-byte aligned operands -- from one 256x256 tile per CU up the ping-pong kernel K3p
  * (igemm_s8_pp.hpp), below that 128x128 tiles (K3t) -- otherwise B packed once per call; 1 transpose B inside
  * the GEMM kernel; 2 the correctness-first kernel; 3 / 4 the packed-B kernel with 128x128 / 256x256 tiles,
- * 5 / 6 the lockstep in-place kernel K3t likewise, 7 / 8 K3p with 16 / 32 MFMAs per phase (A/B switches).
+ * 5 / 6 the lockstep in-place kernel K3t likewise, 8 / 9 K3p as a persistent launch / one workgroup per tile
+ * (mode 0 picks by K), 7 K3p on v_mfma_i32_16x16x32_i8 -- the instruction BASELINE.json configs[4] names: the
+ * same integers at half the matrix pipe's rate (A/B switches).
  * (Modes 10..13, timing-only ablations with wrong results, exist in libmmult_hip_ab.so only; the product
  * library rejects them.) */
 #define MMH_OPT_IGEMM_MODE 3
@@ -228,8 +230,9 @@ int mmh_kernel_id(const char *short_name);
 /* Test hooks.  MMH_OPT_STREAMK_SPIN_LIMIT: bound of the split-K finisher's wait in units of 1024 polls (default
  * 65536, seconds).  MMH_OPT_FAULT_INJECT (default 0): 1 = split-K producers do not announce their
  * partial tiles, so that every finisher times out and the sticky error path can be exercised.
- * (Diagnostic environment switch, read at mmh_create: MMH_NO_PIN=1 -- persistent launches then do not
- * ask for 160 KiB / w of LDS to pin w workgroups per CU.) */
+ * (Diagnostic environment switches, read at mmh_create: MMH_NO_PIN=1 -- persistent launches then do not
+ * ask for 160 KiB / w of LDS to pin w workgroups per CU; MMH_I8_GRID_CAP=g -- the int8 ping-pong kernel's
+ * persistent grid is g workgroups, so that a test's small shapes walk several tiles per workgroup.) */
 #define MMH_OPT_STREAMK_SPIN_LIMIT 6
 #define MMH_OPT_FAULT_INJECT 7
 /* MMH_OPT_STREAMK_ORDER (default 1): stream-K launches with >= 1.8 tiles per workgroup take their ranges

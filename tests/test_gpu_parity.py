@@ -500,7 +500,7 @@ def test_invalid_arguments_return_codes(mm):
     for kid in list(range(16, 20)) + list(range(21, 25)) + list(range(32, 45)):
         assert L.mmh_set_kernel(h, kid) == H.ERR_INVALID_ARG, kid
         assert H.kernel_name(kid) is None
-    for mode in (9, 10, 11, 12, 13, -1):
+    for mode in (10, 11, 12, 13, 14, -1):
         assert L.mmh_set_option(h, H.OPT_IGEMM_MODE, mode) == H.ERR_INVALID_ARG, mode
     assert L.mmh_set_option(h, H.OPT_SPLITK, 17) == H.ERR_INVALID_ARG
     assert L.mmh_set_option(h, H.OPT_HOST_PANELS, 99) == H.ERR_INVALID_ARG
@@ -637,12 +637,13 @@ def test_int8_bit_exact(mm, oracle):
     assert np.array_equal(out.cpu().numpy(), oracle.ref_igemm_s8(a, b, c0.copy()))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 8])      # (7, the 16-MFMA-per-phase ping-pong: tools build, tests/test_tools_build.py)
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_int8_every_kernel_bit_exact(mm, oracle, mode):
     """Each int8 kernel forced in turn (MMH_OPT_IGEMM_MODE: 1 in-kernel transpose, 2 simple,
-    3 / 4 packed-B LDS-DMA with 128x128 / 256x256 tiles, 5 / 6 B read in place likewise, 7 / 8 the ping-pong
-    schedule of the in-place 256x256 tile with 16 / 32 MFMAs per phase) on whole, ragged and tiny shapes, odd and
-    even slice counts (k around multiples of 128 and 256)."""
+    3 / 4 packed-B LDS-DMA with 128x128 / 256x256 tiles, 5 / 6 B read in place likewise, 8 / 9 the ping-pong
+    schedule of the in-place 256x256 tile as a persistent launch / one workgroup per tile, 7 the same kernel on
+    v_mfma_i32_16x16x32_i8 -- the instruction BASELINE.json configs[4] names) on whole, ragged and tiny shapes,
+    odd and even slice counts (k around multiples of 128 and 256)."""
     rng = np.random.default_rng(900 + mode)
     mm.set_igemm_mode(mode)
     try:
@@ -695,27 +696,63 @@ def test_quantised_gemm_end_to_end(mm, oracle):
         assert np.abs(got - exact).max() <= 0.02 * np.abs(exact).max() + 0.05
 
 
-def test_int8_headline_4096(mm):
+def test_int8_headline_4096(mm, oracle):
+    """BASELINE.json configs[4] at its own size: the FULL 4096 x 4096 int32 matrix of the shipped kernel against the
+    int32 triple loop of the oracle (threaded; seconds), every forced kernel -- the config-named 16x16x32 instruction
+    (mode 7) among them -- against the same integers."""
     import torch
     g = torch.Generator(device="cuda").manual_seed(5)
     a = torch.randint(-127, 128, (4096, 4096), device="cuda", dtype=torch.int8, generator=g)
     b = torch.randint(-127, 128, (4096, 4096), device="cuda", dtype=torch.int8, generator=g)
     got = mm.igemm_s8(a, b)
-    # exact integer check of sampled rows/cols on the device: fp64 is exact here
-    # (|partial sums| <= 127*127*4096 < 2^53)
-    rows = torch.tensor([0, 1, 127, 128, 2047, 4095], device="cuda")
-    want = a[rows].double() @ b.double()
-    assert torch.equal(got[rows].double(), want)
-    cols = torch.tensor([0, 63, 64, 4095], device="cuda")
-    want = a.double() @ b[:, cols].double()
-    assert torch.equal(got[:, cols].double(), want)
-    # and every kernel produces the same 4096 x 4096 integers
+    want = oracle.ref_igemm_s8(a.cpu().numpy(), b.cpu().numpy())
+    assert np.array_equal(got.cpu().numpy(), want)
     try:
-        for mode in (1, 3, 4, 5, 6):
+        for mode in (1, 3, 4, 5, 6, 7, 8, 9):
             mm.set_igemm_mode(mode)
             assert torch.equal(mm.igemm_s8(a, b), got), mode
     finally:
         mm.set_igemm_mode(0)
+
+
+def test_int8_persistent_tiles_bit_exact(mm, oracle):
+    """K3p walks several 256x256 tiles per workgroup once there are more tiles than CUs: the next tile's prologue is
+    requested in front of the finished tile's C stores and its first two waits count past them.  Whole and ragged
+    tile grids of 2 .. 5 tiles per CU, short K (the stores of a tile are still in flight when the next one ends),
+    accumulate, the dequantising epilogue, and the one-workgroup-per-tile launch of the same kernel (mode 9)."""
+    import torch
+    rng = np.random.default_rng(66)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    side = 256 * int(np.ceil(np.sqrt(2.2 * cus)))            # ~2.2 tiles per CU, whole tiles
+    shapes = [(side, side, 128), (side, side, 256), (side, side + 256, 640), (side + 3, side - 5, 384),
+              (256 * (cus + 1), 256, 128), (256, 256 * (4 * cus + 3), 256), (3 * side // 2, 2 * side, 1000)]
+    for (m, n, k) in shapes:
+        a = torch.from_numpy(rng.integers(-127, 128, (m, k), dtype=np.int8)).cuda()
+        b = torch.from_numpy(rng.integers(-127, 128, (k, n), dtype=np.int8)).cuda()
+        want = torch.from_numpy(oracle.ref_igemm_s8(a.cpu().numpy(), b.cpu().numpy())).cuda()
+        for mode in (0, 8, 9, 7):
+            mm.set_igemm_mode(mode)
+            try:
+                got = mm.igemm_s8(a, b)
+                assert torch.equal(got, want), (mode, m, n, k)
+                for rep in range(3):                          # back to back: nothing left behind in the ring
+                    assert torch.equal(mm.igemm_s8(a, b, out=got), want), (mode, m, n, k, rep)
+            finally:
+                mm.set_igemm_mode(0)
+        c0 = torch.from_numpy(rng.integers(-1000, 1000, (m, n), dtype=np.int32)).cuda()
+        out = c0.clone()
+        mm.igemm_s8(a, b, out=out, accumulate=True)
+        assert torch.equal(out, want + c0), (m, n, k)
+    # the dequantising epilogue over several tiles per workgroup
+    m = n = side
+    k = 192
+    af = torch.from_numpy(rng.uniform(-2, 2, (m, k)).astype(np.float32)).cuda()
+    bf = torch.from_numpy(rng.uniform(-0.5, 0.5, (k, n)).astype(np.float32)).cuda()
+    got = mm.qgemm(af, bf).cpu().numpy()
+    qa_ref, sa_ref = oracle.quantize_sym_s8(af.cpu().numpy())
+    qb_ref, sb_ref = oracle.quantize_sym_s8(bf.cpu().numpy())
+    inv = np.float32(1.0) / (np.float32(sa_ref) * np.float32(sb_ref))
+    assert np.array_equal(got, oracle.ref_igemm_s8(qa_ref, qb_ref).astype(np.float32) * inv)
 
 
 def test_rocblas_comparator_agrees(mm, oracle):
@@ -833,7 +870,7 @@ def test_int8_differential_fuzz():
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_i8.py"), "60", "2026"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "int8 fuzz: 60 cases x 7 modes, 0 failures" in r.stdout
+    assert "int8 fuzz: 60 cases x 9 modes, 0 failures" in r.stdout
 
 
 def test_launches_capture_into_a_hip_graph(mm, oracle):

@@ -93,6 +93,24 @@ for name in ("mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma
             got = mm.matmul(dev(a), dev(b)).cpu().numpy()
             assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True)), (name, sk, m, n, k, H.last_launch())
 mm.set_streamk(1)
+mm.close()
+print("tools-build ok")
+"""
+
+_TILES = _HEAD + r"""
+mm = H.MMult(0, "auto")
+shapes = [(256, 256, 64), (384, 512, 192), (1024, 1024, 1024), (1152, 1152, 1152), (300, 259, 101), (1025, 1023, 257), (2304, 2304, 512)]
+for name in ("mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma", "mfma32b_128x64_dma",
+             "mfma32b_64x128_dma", "mfma32b_128x128_dma", "exp5_64x64_l1d2", "exp5_128x64_l1d2", "exp5_128x128_l1d2",
+             "exp5_160x96_l1d2", "exp5_160x160_l1d2"):
+    mm.set_kernel(name)
+    for sk in (1, 2):
+        mm.set_streamk(sk)
+        for (m, n, k) in shapes:
+            a, b = oracle.harness_inputs(m, n, k, seed=m + n + k)
+            got = mm.matmul(dev(a), dev(b)).cpu().numpy()
+            assert np.array_equal(got, oracle.ref_mmult(a, b, fma=True)), (name, sk, m, n, k, H.last_launch())
+mm.set_streamk(1)
 # the int8 ping-pong kernel with 16 MFMAs per phase (MMH_OPT_IGEMM_MODE = 7)
 rng = np.random.default_rng(7)
 mm.set_igemm_mode(7)
@@ -192,6 +210,6 @@ def test_the_product_library_refuses_the_tools_builds_switches(mm):
         mm.set_option(H.OPT_RIM5, 1)
     mm.set_option(H.OPT_RIM5, 0)
     with pytest.raises(H.MMultError):
-        mm.set_igemm_mode(7)
+        mm.set_igemm_mode(10)     # (timing-only ablation: tools build)
     mm.set_igemm_mode(0)
     mm.set_kernel("auto")

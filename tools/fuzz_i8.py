@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzz of the int8 kernels on one GPU: every MMH_OPT_IGEMM_MODE (0 auto, 1 in-kernel
 transpose, 3 / 4 packed B, 5 / 6 B read in place) against mode 2 (the correctness-first kernel, an
-independent code path; integers -> bit-equal) on random shapes, leading dimensions, byte-misaligned
+independent code path; integers -> bit-equal; MMH_I8_GRID_CAP=3 in the environment makes the persistent ping-pong
+kernel walk several tiles per workgroup on these small shapes) on random shapes, leading dimensions, byte-misaligned
 bases and accumulate flags, with guard bands around C.  usage: python tools/fuzz_i8.py [cases] [seed]"""
 import os
 import sys
@@ -15,7 +16,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 mm = H.MMult(0)
-MODES = [0, 1, 3, 4, 5, 6, 8]   # (7, the 16-MFMA-per-phase ping-pong, lives in the tools build)
+MODES = [0, 1, 3, 4, 5, 6, 7, 8, 9]   # (7: K3p on the config-named 16x16x32 instruction; 8 / 9: persistent / one workgroup per tile)
 GUARD = -2139062144          # 0x80808080: never a valid sum here
 
 
