@@ -4,7 +4,7 @@
 // Part of libmmult_hip.so (see internal.hpp).
 #include <algorithm>
 
-#include "internal.hpp"   // (first: kAbBuild)
+#include "internal.hpp"
 #include "igemm_s8.hpp"
 #include "igemm_s8_pp.hpp"
 #include "quant_s8.hpp"

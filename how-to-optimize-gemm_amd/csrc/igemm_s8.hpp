@@ -45,6 +45,7 @@
 
 #include <type_traits>
 
+#include "ab_build.hpp"
 #include "sgemm_tile.hpp"   // block_to_tile, static_for
 
 namespace mmh {

@@ -28,6 +28,7 @@
 #include <utility>
 #include <vector>
 
+#include "ab_build.hpp"
 #include "../../include/mmult_hip.h"
 
 // Kernel ids of the tools build (libmmult_hip_ab.so) that name whole tile families; the product library neither
@@ -43,15 +44,6 @@
 #define MMH_KERNEL_MFMA32B_128X128_DMA 62
 
 namespace mmh {
-
-// Is this the tools build (libmmult_hip_ab.so)?  The kernel headers test it with `if constexpr` where an A/B switch
-// rides in a kernel argument's spare bits (raster group height, publish-on-the-spot): no preprocessor in the kernels,
-// and nothing of the switches in the product's code objects.
-#ifdef MMH_AB_BUILD
-constexpr bool kAbBuild = true;
-#else
-constexpr bool kAbBuild = false;
-#endif
 
 // ---- error text (thread-local, state.hip) ----
 void set_last_error(const std::string &s);

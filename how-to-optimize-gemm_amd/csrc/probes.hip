@@ -85,28 +85,39 @@ __global__ void __launch_bounds__(1024) probe_valu_kernel(float *out, int iters,
 
 int probe_valu_f32(int cu_count, int packed, int waves_per_simd, float *tflops) {
   if (cu_count <= 0) cu_count = 256;
-  float *d = nullptr;
-  MMH_HIP_TRY(hipMalloc(&d, 64));
+  // (every early return releases what was created; a launch that failed must not leave ms at 0 and an
+  // infinite rate in the bench line)
+  struct Res {
+    float *d = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    ~Res() {
+      if (t0) (void)hipEventDestroy(t0);
+      if (t1) (void)hipEventDestroy(t1);
+      if (d) (void)hipFree(d);
+    }
+  } r;
+  MMH_HIP_TRY(hipMalloc(&r.d, 64));
   const int iters = 20000, blocks = cu_count, threads = 256 * waves_per_simd;
-  hipEvent_t t0, t1;
-  MMH_HIP_TRY(hipEventCreate(&t0));
-  MMH_HIP_TRY(hipEventCreate(&t1));
+  MMH_HIP_TRY(hipEventCreate(&r.t0));
+  MMH_HIP_TRY(hipEventCreate(&r.t1));
   auto launch = [&](int n) {
-    if (packed) hipLaunchKernelGGL(probe_valu_kernel<true>, dim3(blocks), dim3(threads), 0, 0, d, n, 0.001f);
-    else hipLaunchKernelGGL(probe_valu_kernel<false>, dim3(blocks), dim3(threads), 0, 0, d, n, 0.001f);
+    if (packed) hipLaunchKernelGGL(probe_valu_kernel<true>, dim3(blocks), dim3(threads), 0, 0, r.d, n, 0.001f);
+    else hipLaunchKernelGGL(probe_valu_kernel<false>, dim3(blocks), dim3(threads), 0, 0, r.d, n, 0.001f);
+    return hipGetLastError();
   };
-  for (int w = 0; w < 3; ++w) launch(iters);      // ~10 ms: the power manager's sustained state
-  MMH_HIP_TRY(hipEventRecord(t0, 0));
-  launch(iters);
-  MMH_HIP_TRY(hipEventRecord(t1, 0));
-  MMH_HIP_TRY(hipEventSynchronize(t1));
+  for (int w = 0; w < 3; ++w) MMH_HIP_TRY(launch(iters));      // ~10 ms: the power manager's sustained state
+  MMH_HIP_TRY(hipEventRecord(r.t0, 0));
+  MMH_HIP_TRY(launch(iters));
+  MMH_HIP_TRY(hipEventRecord(r.t1, 0));
+  MMH_HIP_TRY(hipEventSynchronize(r.t1));
   float ms = 0.f;
-  MMH_HIP_TRY(hipEventElapsedTime(&ms, t0, t1));
+  MMH_HIP_TRY(hipEventElapsedTime(&ms, r.t0, r.t1));
+  if (!(ms > 0.f)) {
+    set_last_error("probe_valu_f32: the timed launch took no measurable time");
+    return MMH_ERR_HIP;
+  }
   const double flops = (double)blocks * threads * iters * 64.0 * 2.0;
   *tflops = (float)(flops / (ms * 1e-3) / 1e12);
-  (void)hipEventDestroy(t0);
-  (void)hipEventDestroy(t1);
-  (void)hipFree(d);
   return MMH_OK;
 }
 

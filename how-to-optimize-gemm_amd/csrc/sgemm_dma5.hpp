@@ -49,6 +49,7 @@
 #pragma once
 #include <type_traits>
 
+#include "ab_build.hpp"
 #include "sgemm_dma.hpp"
 #include "sgemm_mfma.hpp"   // the stream-K hand-over words (SK_*), GROUP_M
 

@@ -40,6 +40,8 @@
 #include <utility>
 #include <vector>
 
+#include "ab_build.hpp"
+
 namespace mmh {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

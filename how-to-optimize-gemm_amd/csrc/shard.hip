@@ -256,6 +256,22 @@ int mmh_shard_sgemm_streamed(mmh_shard_t sh, int m, int n, int k, const float *A
     int prev;
     ~Restore() { if (prev >= 0) (void)hipSetDevice(prev); }
   } restore{prev};
+  // An error return after the first enqueue must not leave copies, collectives or GEMMs in flight on the handle's
+  // streams: the next call re-uploads into the buffers they read and re-records the same events.  (Declared behind
+  // `restore`: it runs first and leaves the device switching to it.)
+  struct Drain {
+    mmh_shard *sh;
+    bool armed;
+    ~Drain() {
+      if (!armed) return;
+      for (int d = 0; d < sh->ngpus; ++d) {
+        if (hipSetDevice(sh->devices[d]) != hipSuccess) continue;
+        (void)hipStreamSynchronize(sh->bstreams[d]);
+        (void)hipStreamSynchronize(sh->streams[d]);
+      }
+      (void)hipGetLastError();
+    }
+  } drain{sh, false};
   std::vector<int> row0(G), rows(G);
   const size_t kk = k > 0 ? k : 1;
   for (int d = 0; d < G; ++d) {
@@ -286,6 +302,7 @@ int mmh_shard_sgemm_streamed(mmh_shard_t sh, int m, int n, int k, const float *A
   // ---- host -> device: A panels to their owners, B to device 0 only (every device when there is no
   // communicator, i.e. G == 1) ----
   auto t = clk::now();
+  drain.armed = true;
   if (k > 0) {
     rc = per_device([&](int d) -> hipError_t {
       hipError_t e = hipSuccess;
@@ -364,9 +381,10 @@ int mmh_shard_sgemm_streamed(mmh_shard_t sh, int m, int n, int k, const float *A
     if (with_bcast) HIP_TRY(hipStreamWaitEvent(sh->streams[d], sh->events[d][1], 0));   // (a device without rows still ends after its broadcast)
     HIP_TRY(hipEventRecord(sh->events[d][3], sh->streams[d]));
   }
-  // ---- gemm_reps back-to-back full-K launches per device (the harness's NREPEATS loop: phase time / reps); with ONE
-  // repetition and an unchunked broadcast the pass above is that launch ----
-  const bool rep_loop = gemm_reps > 1 || chunks > 1;
+  // ---- gemm_reps > 1: that many back-to-back full-K launches per device BEHIND the pass above (the harness's NREPEATS
+  // loop: phase time / reps -- gemm_reps + 1 launches in all, C = A B each time).  With ONE repetition the pass above is
+  // the launch: the C that goes back to the host is the chunked pass's, and timings_ms[2] its time. ----
+  const bool rep_loop = gemm_reps > 1;
   if (rep_loop) {
     for (int d = 0; d < G; ++d) {
       HIP_TRY(hipSetDevice(sh->devices[d]));
@@ -428,6 +446,7 @@ int mmh_shard_sgemm_streamed(mmh_shard_t sh, int m, int n, int k, const float *A
   });
   if (rc != MMH_OK) return rc;
   if (timings_ms) timings_ms[3] = ms_since(t);
+  drain.armed = false;   // (per_device synchronised every GEMM stream; the broadcast streams were drained above)
   return MMH_OK;
 }
 

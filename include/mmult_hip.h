@@ -369,7 +369,9 @@ int mmh_shard_rows(int m, int nranks, int rank, int *row0, int *rows);
  *   mmh_shard_sgemm_streamed (round 5): the same with B travelling in `b_chunks` runs of K (whole 128-deep blocks; 0 or
  *            1 = ONE broadcast, at most 64) on a second, higher-priority stream per device while the chunks already
  *            landed are consumed -- C = A[:, chunk] B[chunk, :] + C with C's value as the first term of each chain, i.e.
- *            the unchunked launch's bits -- followed, when b_chunks > 1 or gemm_reps > 1, by gemm_reps full-K launches.
+ *            the unchunked launch's bits.  With gemm_reps == 1 that pass IS the launch: the C copied back is the chunked
+ *            pass's and timings_ms[2] its time; gemm_reps > 1 adds that many full-K launches behind it (gemm_reps + 1 in
+ *            all) and reports their mean.  An error return drains the handle's streams first.
  *            timings_ms (may be NULL) receives EIGHT floats, every device phase taken with events on that device's own
  *            streams, the slowest device reported: {h2d (host clock), broadcast (first chunk out .. last chunk landed),
  *            gemm per full-K launch, d2h (host clock), OVERLAPPED (broadcast start .. end of the first GEMM pass: what

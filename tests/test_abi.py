@@ -187,13 +187,16 @@ def test_the_kernel_headers_carry_no_tools_build_preprocessor_switches():
     """the product's kernel headers hold what ships.  The tile families that were measured and lost
     live under tools/ab/ (compiled by build_ab_library() only); where an A/B switch rides in a kernel argument's spare
     bits the header tests `kAbBuild` with `if constexpr` -- no `#ifdef MMH_AB_BUILD` inside any csrc/*.hpp but the one
-    in internal.hpp that defines the constant."""
+    in ab_build.hpp that defines the constant (its own header since round 6, included by every header that tests it:
+    ADVICE r05)."""
     import glob
     csrc = os.path.join(REPO, "how-to-optimize-gemm_amd", "csrc")
     for path in sorted(glob.glob(os.path.join(csrc, "*.hpp"))):
         text = open(path).read()
         n = sum(1 for line in text.splitlines() if line.lstrip().startswith("#if") and "MMH_AB_BUILD" in line)
-        assert n == (1 if path.endswith("internal.hpp") else 0), (path, n)
+        assert n == (1 if path.endswith("ab_build.hpp") else 0), (path, n)
+        if "kAbBuild" in text and not path.endswith("ab_build.hpp"):
+            assert '#include "ab_build.hpp"' in text or '#include "sgemm_tile.hpp"' in text or '#include "igemm_s8.hpp"' in text, path
     for name in ("sgemm_dma32.hpp", "launch_dma32.hip", "sgemm_dma_rim.hpp", "sgemm_dma5_rim.hpp"):
         assert os.path.exists(os.path.join(REPO, "tools", "ab", name)), name
         assert not os.path.exists(os.path.join(csrc, name)), name
