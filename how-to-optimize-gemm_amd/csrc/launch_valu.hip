@@ -50,6 +50,21 @@ int launch_valu_w(const GemmArgs &g) {
   return MMH_OK;
 }
 
+// K1Wp (round 6): the persistent stream-K launch of a K1W tile for ragged tile counts -- K2W's body, ranges, hand-over
+// words and workspaces (launch_streamk) around the vector-ALU consumer.  Returns 1 when the shape does not qualify or
+// the launcher's rule prefers the plain launch.
+template <int BM, int BN, int NBUF, int NL, int AK, int WPE>
+int launch_valu_sk(mmh_context *ctx, const GemmArgs &g) {
+  using T = Dma5Tile<BM, BN, 32, BM / 32, BN / 32, NBUF, NL>;
+  if (!ctx || !ctx->streamk || !fast_shape(BM, BN, 32, g) || !window_ok(BM, BN, g.k, g.lda, g.ldb)) return 1;
+  auto kern = sgemm_valu_dma5_streamk_kernel<BM, BN, NBUF, NL, AK, WPE>;
+  char what[224];
+  snprintf(what, sizeof what,
+           "sgemm_valu_dma5_streamk_kernel<%d,%d> thread tile %dx%d on v_pk_fma_f32, K-slice 32 x %d ring buffers by %d loader waves' "
+           "LDS-DMA, chained parts", BM, BN, BM / 16, BN / 16, NBUF, NL);
+  return launch_streamk(ctx, kern, kern, BM, BN, 32, T::THREADS, T::LDS_BYTES, what, g);
+}
+
 int valu_w() {   // MMH_VALU_W=0: K1 as it was before round 5 (register-staged), for A/B
   static const int v = [] { const char *e = std::getenv("MMH_VALU_W"); return e && *e == '0' ? 0 : 1; }();
   return v;
@@ -65,9 +80,13 @@ int launch_valu_tile(const GemmArgs &g) {
 }
 
 // a K1 tile: K1W on whole-tile shapes, K1's own (guarded or not) instantiation otherwise
-int launch_k1_128(const mmh_context *ctx, const GemmArgs &g) {
+int launch_k1_128(mmh_context *ctx, const GemmArgs &g) {
   const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
   const long tiles = (long)((g.m + 127) / 128) * ((g.n + 127) / 128);
+  if (valu_w() && !(ctx && ctx->ab_valu_old)) {
+    const int sk = launch_valu_sk<128, 128, 2, 2, 2, 2>(ctx, g);   // (256 registers: ONE persistent workgroup per CU -- at 168 the chained body spills 36)
+    if (sk <= 0) return sk;
+  }
   // (from four tiles per CU the register-staged K1 is 1-3 % ahead -- N = 4096 / 6144: 92.9 / 94.4 against 91.8 / 91.9:
   // two loader waves per workgroup take issue slots from the FMA waves of two SIMDs and there is no round left to
   // fill; below that K1W leads by 8 % (2048) to 17 % (1536): profiles/r05_notes.md)
@@ -77,15 +96,21 @@ int launch_k1_128(const mmh_context *ctx, const GemmArgs &g) {
   }
   return launch_valu_tile<128, 128, 32>(g);
 }
-int launch_k1_128x64(const mmh_context *ctx, const GemmArgs &g) {   // (K1W only: 72 KiB ring, 128 registers: two per CU)
+int launch_k1_128x64(mmh_context *ctx, const GemmArgs &g) {   // (K1W only: 72 KiB ring, 128 registers: two per CU)
   if (valu_w() && !(ctx && ctx->ab_valu_old)) {
+    const int sk = launch_valu_sk<128, 64, 3, 2, 2, 3>(ctx, g);
+    if (sk <= 0) return sk;
     const int w = launch_valu_w<128, 64, 3, 2, 2, 2, 3>(g);
     if (w <= 0) return w;
   }
   return launch_k1_128(ctx, g);
 }
-int launch_k1_64(const mmh_context *ctx, const GemmArgs &g) {
+int launch_k1_64(mmh_context *ctx, const GemmArgs &g) {
   if (valu_w() && !(ctx && ctx->ab_valu_old)) {
+    {
+      const int sk = launch_valu_sk<64, 64, 3, 2, 2, 5>(ctx, g);
+      if (sk <= 0) return sk;
+    }
     // 48 KiB ring, 76-84 registers: three workgroups per CU.  A read as ds_read_b64 (two k-steps) where a CU holds ONE
     // workgroup -- one wave per SIMD: N = 1024 71.7 against 63.2 TFLOP/s -- as ds_read_b128 (four) otherwise (1536: 66.6
     // against 63.0, 4096: 81.0 against 77.5)
@@ -97,24 +122,45 @@ int launch_k1_64(const mmh_context *ctx, const GemmArgs &g) {
   return launch_valu_tile<64, 64, 64>(g);
 }
 
-// MMH_KERNEL_VALU's tile (round 5): a tile family runs at its chip-full rate R times the share of its last round that
-// is filled, counted per CU -- (tiles / CUs) / ceil(tiles / CUs): a lone workgroup has its CU's vector ALUs to itself
-// and runs about as fast as two sharing them, so what a ragged count costs is the CUs left idle while the fullest one
-// finishes.  R measured at whole-round sizes: 93 (128x128), 86 (128x64), 80 (64x64) TFLOP/s.  Picks the measured best
-// tile at 12 of 13 sizes of the sweep 1024 .. 4096 step 256 (3072: the 64x64 tile at 78 where 128x64 reaches 83.5).
-int k1_pick_tile(const mmh_context *ctx, const GemmArgs &g) {
+// MMH_KERNEL_VALU's tile and launch form.  Plain launches (round 5): a tile family runs at its chip-full rate R times the
+// share of its last round that is filled, counted per CU -- (tiles / CUs) / ceil(tiles / CUs): a lone workgroup has its
+// CU's vector ALUs to itself and runs about as fast as two sharing them, so what a ragged count costs is the CUs left
+// idle while the fullest one finishes.  R measured at whole-round sizes: 93 (128x128), 86 (128x64), 80 (64x64) TFLOP/s.
+// Persistent stream-K launches (round 6, profiles/r06_valu_sweep.md): no idle round, but ONE workgroup per CU where the
+// tiles do not fill two -- one FMA wave per SIMD, whose roof is 77 TFLOP/s against 106 for two (mmh_probe_valu_f32):
+//   128x128 (one per CU, 222 registers): 91 x t / (t + 0.17), t = tiles per workgroup (78.9 at 1.13 .. 89 at 3.5);
+//   128x64 between one and two tiles per CU: 73;  64x64: 62 / 72 / 68 on one / two / three workgroups per CU.
+// (128x64 on two workgroups per CU runs 60-75 and is left out.)  `form`: 1 = plain, 2 = persistent (GemmArgs::form).
+int k1_pick_tile(const mmh_context *ctx, const GemmArgs &g, int *form) {
   const double cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
-  auto est = [&](int bm, int bn, double rate) {
-    if (!fast_shape(bm, bn, 32, g)) return 0.0;   // K1W runs whole tiles only (the caller has checked 64x64)
-    const double per_cu = (double)(g.m / bm) * (g.n / bn) / cus;
-    const double rounds = (double)(long)(per_cu + 0.999999);
-    return rate * per_cu / (rounds < 1.0 ? 1.0 : rounds);
+  const bool sk_ok = ctx && ctx->streamk;
+  double best = -1.0;
+  int best_kernel = MMH_KERNEL_VALU_64X64, best_form = 1;
+  auto offer = [&](double est, int kernel, int f) {
+    if (est > best) best = est, best_kernel = kernel, best_form = f;
   };
-  // (below one tile per CU every family's estimate is its rate x the share of the CUs it fills: the smaller tile wins
-  // unless the larger one fills as many -- which it cannot)
-  const double e128 = est(128, 128, 93.0), e12864 = est(128, 64, 86.0), e64 = est(64, 64, 80.0);
-  if (e128 >= e12864 && e128 >= e64) return MMH_KERNEL_VALU_128X128;
-  return e12864 >= e64 ? MMH_KERNEL_VALU_128X64 : MMH_KERNEL_VALU_64X64;
+  auto family = [&](int bm, int bn, double rate, int kernel) {
+    if (!fast_shape(bm, bn, 32, g)) return;   // K1W runs whole tiles only (the caller has checked 64x64)
+    const double tiles = (double)(g.m / bm) * (g.n / bn), per_cu = tiles / cus;
+    const double rounds = (double)(long)(per_cu + 0.999999);
+    // (below one tile per CU every family's estimate is its rate x the share of the CUs it fills: the smaller tile wins
+    // unless the larger one fills as many -- which it cannot)
+    offer(rate * per_cu / (rounds < 1.0 ? 1.0 : rounds), kernel, 1);
+    if (!sk_ok || tiles <= cus) return;
+    const long w = (long)per_cu;   // whole workgroups per CU the tiles fill
+    if (kernel == MMH_KERNEL_VALU_128X128) {
+      if ((long)tiles % (long)cus != 0) offer(91.0 * per_cu / (per_cu + 0.17), kernel, 2);
+    } else if (kernel == MMH_KERNEL_VALU_128X64) {
+      if (w == 1) offer(73.0, kernel, 2);
+    } else if ((long)tiles % ((w > 3 ? 3 : w) * (long)cus) != 0) {
+      offer(w == 1 ? 62.0 : w == 2 ? 72.0 : 68.0, kernel, 2);
+    }
+  };
+  family(128, 128, 93.0, MMH_KERNEL_VALU_128X128);
+  family(128, 64, 86.0, MMH_KERNEL_VALU_128X64);
+  family(64, 64, 80.0, MMH_KERNEL_VALU_64X64);
+  *form = best_form;
+  return best_kernel;
 }
 
 int launch_naive(const GemmArgs &g) {
@@ -131,12 +177,15 @@ int launch_valu(mmh_context *ctx, int kernel, const GemmArgs &g) {
   const long cus = ctx && ctx->cu_count > 0 ? ctx->cu_count : 256;
   const long tiles128 = (long)((g.m + 127) / 128) * ((g.n + 127) / 128);
   switch (kernel) {
-    case MMH_KERNEL_VALU:   // K1: the tile by rounds (k1_pick_tile); whole-tile shapes on K1W, the others on K1's guarded kernels
-      switch (fast_shape(64, 64, 32, g) ? k1_pick_tile(ctx, g) : 0) {
-        case MMH_KERNEL_VALU_128X128: return launch_k1_128(ctx, g);
-        case MMH_KERNEL_VALU_128X64: return launch_k1_128x64(ctx, g);
-        case MMH_KERNEL_VALU_64X64: return launch_k1_64(ctx, g);
-        default: break;
+    case MMH_KERNEL_VALU:   // K1: tile and launch form by k1_pick_tile; whole-tile shapes on K1W, the others on K1's guarded kernels
+      if (fast_shape(64, 64, 32, g)) {
+        GemmArgs ga = g;
+        const int pick = k1_pick_tile(ctx, g, &ga.form);
+        switch (pick) {
+          case MMH_KERNEL_VALU_128X128: return launch_k1_128(ctx, ga);
+          case MMH_KERNEL_VALU_128X64: return launch_k1_128x64(ctx, ga);
+          default: return launch_k1_64(ctx, ga);
+        }
       }
       {   // ragged / unaligned: K1's guarded tiles, the 64x64 one where its rounds are cheaper (round 4's rule)
         const long tiles64 = (long)((g.m + 63) / 64) * ((g.n + 63) / 64);

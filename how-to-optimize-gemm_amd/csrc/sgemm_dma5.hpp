@@ -126,10 +126,28 @@ struct Dma5Rim {
 template <class Segment>
 struct Dma5RimWave;
 
+// VALU (round 6): the segment's consumer waves run K1W's vector-ALU loop (sgemm_valu_dma5.hpp: ds_read + v_pk_fma_f32, a
+// thread tile of BM / 16 x BN / 16) instead of the MFMA one -- BASELINE.json configs[1]'s rung under the SAME loaders, ring
+// protocol, chained segments and stream-K body.  What differs on this side of the barrier: A's image (K1W reads A along
+// k: one bit of the row XORed into the chunk position, not three) and the fragment registers; D is then the A read's
+// width in k-steps (2: ds_read_b64, 4: ds_read_b128).  Whole tiles only.
+template <class Segment>
+struct Dma5ValuConsumer;
+template <int TI, int RJ, int AK>
+struct Dma5ValuFrags {
+  typedef float afrag_t __attribute__((ext_vector_type(AK)));
+  afrag_t a[2][TI];   // the current and the next group of AK k-steps
+  f32x4 b[4][RJ];     // k-step mod 4
+};
+
 template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool PART_WT = false, bool EDGE = false, bool CHAIN = false,
-          int NL = 1, int D = 2, bool RIM = false>
+          int NL = 1, int D = 2, bool RIM = false, bool VALU = false>
 struct Dma5Segment {
   using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
+  static_assert(!VALU || (!EDGE && !RIM && (D == 2 || D == 4) && (BM == 64 || BM == 128) && (BN == 64 || BN == 128)),
+                "the vector-ALU consumer: whole tiles, 16 x 16 threads of 4x4 output blocks");
+  static constexpr bool kChain = CHAIN, kPartWt = PART_WT, kValu = VALU;
+  static constexpr int kBM = BM, kBN = BN, kNBUF = NBUF, kAK = D;
   static_assert(!RIM || (BM == 64 && BN == 64 && WTN == 2 && NL == 2 && EDGE && !CHAIN), "the rim rides on the guarded 64x64 tile's plain launch");
   // RIM: floats behind the ring (and its word line): per ring position one 1 KiB piece of rim-row A values
   // [row e][32 k] and one of rim-column B values [k][4 columns]
@@ -144,10 +162,11 @@ struct Dma5Segment {
   static constexpr int SLOTS = D <= 3 ? 4 : 8;
   static_assert(D >= 1 && D < T::KS && T::KS % SLOTS == 0 && D < SLOTS, "fragment slots are numbered by k-step mod SLOTS");
 
-  struct Frags {
+  struct MfmaFrags {
     float a[SLOTS][WTM];
     float b[SLOTS][WTN];
   };
+  using Frags = std::conditional_t<VALU, Dma5ValuFrags<BM / 16, BN / 64, D>, MfmaFrags>;
 
   // per-lane constants: the consumers' fragment addresses, the loaders' offsets inside a piece
   struct Lane {
@@ -155,6 +174,7 @@ struct Dma5Segment {
     bool loader, rim;
     int stamp_base = 0;   // timeline build: the stream-K body moves it from part to part
     int a_off[8], b_off[BBLK ? WTN : 1];
+    int v_tx = 0, v_wrow = 0, v_a_even = 0, v_a_odd = 0, v_b_col = 0, v_b_col_odd = 0;   // VALU consumers (sgemm_valu_dma5.hpp)
     uint32_t voff_a, voff_b[T::PB];
     __device__ __forceinline__ void init(int lda, int ldb) {
       const int tid = threadIdx.x, lane = tid & 63;
@@ -178,12 +198,22 @@ struct Dma5Segment {
       // loaders: the 16-byte chunk a lane fetches is the one that belongs at its (swizzled) position of the image
       {
         const int r = lane / 8, p = lane % 8;                              // piece j holds A rows 8 j + r
-        voff_a = (uint32_t)(r * lda + 4 * (p ^ (r & 7))) * 4u;
+        voff_a = (uint32_t)(r * lda + 4 * (p ^ (VALU ? (r >> 1) & 1 : r & 7))) * 4u;
       }
 #pragma unroll
       for (int jj = 0; jj < T::PB; ++jj) {
         const int c = 64 * jj + lane, r = c / T::CPR_B, pc = c % T::CPR_B; // piece PB g + jj holds k-rows RB g + r
         voff_b[jj] = (uint32_t)(r * ldb + 4 * T::src_chunk_b(r, pc)) * 4u;
+      }
+      if constexpr (VALU) {
+        // a wave is 16 (tx) x 4 (t) threads: rows (BM / 4) wave + t + 4 i, columns 4 tx + 64 h (sgemm_valu_dma5.hpp)
+        v_tx = lane & 15;
+        v_wrow = (BM / 4) * (wave & 3) + (lane >> 4);
+        const int a_bit = (v_wrow >> 1) & 1;
+        v_a_even = v_wrow * KB + 4 * a_bit;
+        v_a_odd = v_wrow * KB + 4 * (1 ^ a_bit);
+        v_b_col = T::A_FLOATS + 4 * v_tx;
+        v_b_col_odd = T::A_FLOATS + 4 * (BN == 64 ? (v_tx ^ 8) : v_tx);
       }
     }
   };
@@ -316,6 +346,10 @@ struct Dma5Segment {
     }
 
     // -------------------------------------------------------------------- the consumer waves
+    if constexpr (VALU) {
+      Dma5ValuConsumer<Dma5Segment>::consume(lds, L, C, ldc, row0, col0, kb, ke, pos, primed, chain, init_from_c, part_in, part_out, fr,
+                                             pub_flag, pub_reply);
+    } else {
     // EDGE: how many of this wave's 16-row / 16-column blocks hold a valid element (wave-uniform).  Block t holds rows
     // 16 (WTM wm + t) .. + 15 of the tile; block u holds, column-blocked, columns 16 (WTN wn + u) .. + 15, and with
     // WTN consecutive columns per lane the columns 16 WTN wn + WTN li + u -- its first (li = 0) is its smallest.
@@ -346,6 +380,7 @@ struct Dma5Segment {
     }
     consume(std::false_type{}, std::false_type{}, lds, L, m, n, k, C, ldc, row0, col0, rows_valid, cols_valid, kb, ke, pos, primed, chain,
             init_from_c, part_in, part_out, fr, pub_flag, pub_reply);
+  }   // (!VALU)
   }
 
   // The consumer side of a segment with NT x NU of the wave's WTM x WTN blocks kept (all of them, or -- thin edge
@@ -668,14 +703,14 @@ sgemm_mfma_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda
 // looked at (they depend on nobody); should the word say the head's owner is not running (the wait-free path: leave),
 // they are dropped.
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE, bool CHAINED, int NL, int D>
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE, bool CHAINED, int NL, int D, bool VALU = false>
 __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
                                               const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                               int accumulate, int nbm, int nbn, int *__restrict__ flags,
                                               float *__restrict__ parts, const int *__restrict__ order,
                                               const int *__restrict__ place, int *__restrict__ stats) {
   constexpr bool chained = CHAINED;
-  using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, true, EDGE, true, NL, D>;
+  using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, true, EDGE, true, NL, D, false, VALU>;
   using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
   // tools build: bit 1 of `accumulate` = publish every head on the spot, bits 8-15 = raster group height
   const bool ab_nodefer = kAbBuild && (accumulate & 2) != 0;

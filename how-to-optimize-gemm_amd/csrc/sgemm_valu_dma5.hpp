@@ -25,6 +25,14 @@
 //
 // Whole tiles only (m, n multiples of the tile, k of 32, 16-byte aligned rows): everything else stays on K1's guarded
 // instantiation.
+//
+// Round 6: the same consumer as a SEGMENT of K2W's machinery (Dma5ValuConsumer below, reached through
+// Dma5Segment<..., VALU = true>): the loaders, the chained ring, the stream-K body with its hand-over words and partial
+// tiles are sgemm_dma5.hpp's, only what happens between two barriers is this file's.  A ragged tile count then costs
+// the vector-ALU rung what it costs the MFMA rung -- a head and a tail per workgroup -- instead of a whole idle round
+// (N = 2176 on 128x128 tiles: 289 tiles for 256 CUs ran 56 TFLOP/s; the reference's own non-tensor rungs are flat across
+// its sweep, cuda/output_MMult_cuda_3.m:5-29).  The partial sums travel as fp32 and each element's chain resumes where
+// the head left it: the bits of the plain launch.
 #pragma once
 #include "sgemm_dma5.hpp"
 
@@ -225,6 +233,171 @@ sgemm_valu_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda
       const f32x4 v = {acc[i][2 * h][0], acc[i][2 * h][1], acc[i][2 * h + 1][0], acc[i][2 * h + 1][1]};
       *reinterpret_cast<f32x4 *>(C + (size_t)(row0 + wrow + 4 * i) * ldc + col0 + 4 * tx + 64 * h) = v;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The vector-ALU consumer of one (tile, K-range) segment: Dma5Segment::consume's contract -- accumulators from zero / C
+// / the head's partial tile, a first fragment read when the pipeline is not primed, one barrier per slice (the deferred
+// publish of a stream-K head rides on the first), the ring entered at a run-time position, the result to C or, write-
+// through, to the workgroup's partial-tile slot -- with the kernel above's k-step in between.
+// ---------------------------------------------------------------------------------------------------------------
+template <class S>
+struct Dma5ValuConsumer {
+  using T = typename S::T;
+  static constexpr int BM = S::kBM, BN = S::kBN, NBUF = S::kNBUF, AK = S::kAK, KB = 32, P = 2;
+  static constexpr int TI = BM / 16, RJ = BN / 64, TJ = 4 * RJ, STAGE = T::STAGE;
+  static constexpr bool CHAIN = S::kChain;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+  static __device__ __forceinline__ void consume(float *lds, const typename S::Lane &L, float *__restrict__ C, int ldc, int row0,
+                                                 int col0, int kb, int ke, int pos, bool primed, bool chain, bool init_from_c,
+                                                 const float *part_in, float *part_out, typename S::Frags &fr, int *pub_flag,
+                                                 int &pub_reply) {
+    const int wrow = L.v_wrow, tx = L.v_tx;
+    f32x2 acc[TI][TJ / 2];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int h = 0; h < RJ; ++h) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (part_in) v = *reinterpret_cast<const f32x4 *>(part_in + (size_t)(wrow + 4 * i) * BN + 4 * tx + 64 * h);
+        else if (init_from_c) v = *reinterpret_cast<const f32x4 *>(C + (size_t)(row0 + wrow + 4 * i) * ldc + col0 + 4 * tx + 64 * h);
+        acc[i][2 * h] = f32x2{v[0], v[1]};
+        acc[i][2 * h + 1] = f32x2{v[2], v[3]};
+      }
+    // the accumulators' initial values arrive before the K loop starts (see sgemm_valu.hpp)
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ / 2; j += 2) asm volatile("" : "+v"(acc[i][j]), "+v"(acc[i][j + 1]));
+
+    typedef float afrag_t __attribute__((ext_vector_type(AK)));
+    auto read_a = [&](const float *buf, auto g_c) __attribute__((always_inline)) {
+      constexpr int g = decltype(g_c)::value, c = AK * g / 4, half = AK * g % 4;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+        fr.a[g & 1][i] = *reinterpret_cast<const afrag_t *>(buf + ((c & 1) ? L.v_a_odd : L.v_a_even) + 4 * i * KB + 8 * (c >> 1) + half);
+    };
+    auto read_b = [&](const float *buf, auto kk_c) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kk_c)::value;
+#pragma unroll
+      for (int h = 0; h < RJ; ++h)
+        fr.b[kk % 4][h] = *reinterpret_cast<const f32x4 *>(buf + ((kk & 1) ? L.v_b_col_odd : L.v_b_col) + kk * BN + 64 * h);
+    };
+    if (!primed) {
+      __builtin_amdgcn_s_barrier();   // the loaders have the first slice in LDS
+      read_a(lds, std::integral_constant<int, 0>{});
+      static_for<P>([&](auto p_c) { read_b(lds, p_c); });
+    }
+    dma_stamp(L.stamp_base + 1);
+    // a HEAD's deferred publish (sgemm_dma5.hpp): pending until the first slice barrier of this part
+    bool pend = CHAIN && __builtin_amdgcn_readfirstlane((int)(pub_flag != nullptr)) != 0;
+    auto slice_at = [&](const float *buf, const float *nxt) __attribute__((always_inline)) {
+      static_for<KB>([&](auto kk_c) __attribute__((always_inline)) {
+        constexpr int kk = decltype(kk_c)::value, g = kk / AK, q = kk % AK;
+        if constexpr (kk == KB - P) {
+          if constexpr (CHAIN) {
+            if (pend) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial-tile stores have completed
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if constexpr (CHAIN) {
+            if (pend) {   // ... and so have every other consumer wave's: ONE lane sets DONE
+              if (threadIdx.x == 0)
+                pub_reply = __hip_atomic_fetch_or(pub_flag, SK_HEAD_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              pend = false;
+            }
+          }
+        }
+        if constexpr (kk + P < KB) read_b(buf, std::integral_constant<int, kk + P>{});
+        else read_b(nxt, std::integral_constant<int, kk + P - KB>{});
+        if constexpr (q == AK - 2) {   // the next group, two k-steps before its first use
+          if constexpr (g + 1 < KB / AK) read_a(buf, std::integral_constant<int, g + 1>{});
+          else read_a(nxt, std::integral_constant<int, 0>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const float a = fr.a[g & 1][i][q];
+#pragma unroll
+          for (int j = 0; j < TJ / 2; ++j) {
+            const f32x4 bv = fr.b[kk % 4][j >> 1];
+            const f32x2 b2 = (j & 1) ? f32x2{bv[2], bv[3]} : f32x2{bv[0], bv[1]};
+            acc[i][j] = __builtin_elementwise_fma(f32x2{a, a}, b2, acc[i][j]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ / 2; j += 2) asm volatile("" : "+v"(acc[i][j]), "+v"(acc[i][j + 1])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    auto slice = [&](auto cur_c) __attribute__((always_inline)) {
+      constexpr int CUR = decltype(cur_c)::value, NXT = (CUR + 1) % NBUF;
+      slice_at(lds + CUR * STAGE, lds + NXT * STAGE);
+    };
+    int kt = kb;
+    if constexpr (CHAIN) {   // up to NBUF - 1 slices to reach ring position 0
+      static_for<NBUF - 1>([&](auto p_c) {
+        constexpr int PP = decltype(p_c)::value + 1;
+        if (pos == PP && kt < ke) {
+          slice(std::integral_constant<int, PP>{});
+          ++kt;
+          pos = (PP + 1) % NBUF;
+        }
+      });
+    }
+    while (kt + NBUF <= ke) {
+      static_for<NBUF>([&](auto c_c) { slice(c_c); });
+      kt += NBUF;
+    }
+    static_for<NBUF - 1>([&](auto c_c) {   // (only reached at ring position 0)
+      if (kt < ke) {
+        slice(c_c);
+        ++kt;
+      }
+    });
+    if (!chain) {
+      // (the fragments requested past the last slice are never used; keep them formally alive so that their waits stay where they are)
+#pragma unroll
+      for (int i = 0; i < TI; ++i) asm volatile("" ::"v"(fr.a[0][i]));
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+        for (int h = 0; h < RJ; ++h) asm volatile("" ::"v"(fr.b[sl][h]));
+    }
+    dma_stamp(L.stamp_base + 2);
+    __amdgpu_buffer_rsrc_t rsrc_p;
+    if (part_out) rsrc_p = __builtin_amdgcn_make_buffer_rsrc(part_out, 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int h = 0; h < RJ; ++h) {
+        const f32x4 v = {acc[i][2 * h][0], acc[i][2 * h][1], acc[i][2 * h + 1][0], acc[i][2 * h + 1][1]};
+        if (part_out) {
+          // the partial tile of a stream-K head: write-through (sc1), published by a drain + one atomic (sgemm_dma5.hpp)
+          typedef int i32x4_t __attribute__((ext_vector_type(4)));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rsrc_p,
+                                                 (uint32_t)(((wrow + 4 * i) * BN + 4 * tx + 64 * h) * 4), 0, 16);
+        } else {
+          *reinterpret_cast<f32x4 *>(C + (size_t)(row0 + wrow + 4 * i) * ldc + col0 + 4 * tx + 64 * h) = v;
+        }
+      }
+  }
+};
+
+// K1Wp: the persistent stream-K launch of the vector-ALU rung -- sgemm_dma5_streamk_kernel with the consumer above.
+template <int BM, int BN, int NBUF, int NL, int AK, int WPE>
+__global__ void __launch_bounds__(64 * (4 + NL), WPE)
+sgemm_valu_dma5_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                               float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn, int *__restrict__ flags,
+                               float *__restrict__ parts, const int *__restrict__ order, const int *__restrict__ place,
+                               int *__restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  asm volatile("" ::"s"(A), "s"(B), "s"(C), "s"(lda), "s"(ldb), "s"(ldc), "s"(k), "s"(flags), "s"(parts), "s"(order), "s"(place));
+  streamk5_body<BM, BN, 32, BM / 32, BN / 32, NBUF, false, true, NL, AK, true>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn,
+                                                                              flags, parts, order, place, stats);
 }
 
 }  // namespace mmh

@@ -57,7 +57,10 @@ def test_no_fp32_gemm_kernel_spills_except_the_known_256x256_forms():
         # scalars parked in a vector register's lanes (a v_readlane to get one back): none in any one-workgroup-per-tile
         # kernel; the persistent stream-K bodies carry a range's bookkeeping beside a segment's -- 2 to 49 as the round
         # ends (outside the K loop; a lever nobody has pulled yet)
-        assert r["sgpr_spill"] <= (64 if "streamk" in r["kernel"] else 0), r
+        # (round 6: the vector-ALU consumer under the same body parks 78 on its 128x128 tile -- the thread tile's address
+        # constants are scalars too)
+        cap = 96 if r["kernel"].startswith("sgemm_valu_dma5_streamk_kernel") else 64 if "streamk" in r["kernel"] else 0
+        assert r["sgpr_spill"] <= cap, r
 
 
 def test_the_k2w_tiles_fit_the_co_residency_their_launches_count_on():
