@@ -92,9 +92,9 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
       workspaces_suspect(h);   // a launch that timed out may have left hand-off counters behind
       return MMH_OK;
     case MMH_OPT_IGEMM_MODE:
-      if ((value >= 0 && value <= 9)
+      if ((value >= 0 && value <= 9 && value != 1 && value != 3 && value != 4)
 #ifdef MMH_AB_BUILD
-          || (value >= 10 && value <= 13)
+          || value == 1 || value == 3 || value == 4 || (value >= 10 && value <= 13)   // tools/ab/igemm_s8_k3.hpp
 #endif
       ) {
         h->igemm_mode = value;

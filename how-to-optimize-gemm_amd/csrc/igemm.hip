@@ -7,6 +7,9 @@
 #include "internal.hpp"
 #include "igemm_s8.hpp"
 #include "igemm_s8_pp.hpp"
+#ifdef MMH_AB_BUILD
+#include "igemm_s8_k3.hpp"   // tools/ab/: K3 and the packed-B kernel K3d (modes 1, 3, 4, 10..13)
+#endif
 #include "quant_s8.hpp"
 
 using namespace mmh;
@@ -20,6 +23,25 @@ static int pp_grid_cap(const mmh_context *h, int mode, int k, int cus) {
   if (h->i8_grid_cap > 0) return h->i8_grid_cap;   // test hook: a few persistent workgroups walk a small shape's tiles
   if (mode == 8) return cus;
   return k <= 5120 ? cus : 0;
+}
+
+// tools build: the rungs that left the product (tools/ab/igemm_s8_k3.hpp).  Returns 1 when `mode` is not one of theirs.
+static int launch_ab_modes(mmh_context *h, int mode, int m, int n, int k, const int8_t *A, int lda, const int8_t *B, int ldb, int32_t *C,
+                           int ldc, int acc, hipStream_t s) {
+#ifdef MMH_AB_BUILD
+  if (mode == 1 || mode == 3 || mode == 4 || (mode >= 10 && mode <= 13)) {
+    int8_t *bt = nullptr;
+    if (igemm_s8_needs_pack(mode, A, lda, B, ldb, k) && h->bt.reserve(igemm_s8_pack_bytes(n, k)) == MMH_OK)
+      bt = static_cast<int8_t *>(h->bt.p);
+    const hipError_t e = launch_igemm_s8_ab(m, n, k, A, lda, B, ldb, C, ldc, acc, s, bt, mode);
+    if (e == hipErrorNotSupported) return 1;   // an operand those kernels cannot take: the product's path
+    HIP_TRY(e);
+    return MMH_OK;
+  }
+#else
+  (void)h; (void)mode; (void)m; (void)n; (void)k; (void)A; (void)lda; (void)B; (void)ldb; (void)C; (void)ldc; (void)acc; (void)s;
+#endif
+  return 1;
 }
 
 extern "C" {
@@ -78,18 +100,13 @@ int mmh_igemm_s8(mmh_handle_t h, int m, int n, int k, const int8_t *dA, int lda,
       sb = static_cast<const int8_t *>(h->qb.p);
     }
     if (igemm_s8_inplace_ok(sa, ka, sb, nb, k)) {
-      HIP_TRY(launch_igemm_s8(m, n, k, sa, ka, sb, nb, dC, ldc, accumulate ? 1 : 0, s, nullptr, 0,
-                                   h->cu_count > 0 ? h->cu_count : 256));
+      HIP_TRY(launch_igemm_s8(m, n, k, sa, ka, sb, nb, dC, ldc, accumulate ? 1 : 0, s, 0, cus_));
       return MMH_OK;
     }
-    // (operands beyond the descriptors' 2 GiB window: the general path below)
+    // (operands beyond the descriptors' 2 GiB window: the correctness-first kernel below)
   }
-  int8_t *bt = nullptr;
-  if (igemm_s8_needs_pack(h->igemm_mode, dA, lda, dB, ldb, k) &&
-      h->bt.reserve(igemm_s8_pack_bytes(n, k)) == MMH_OK)
-    bt = static_cast<int8_t *>(h->bt.p);
-  HIP_TRY(launch_igemm_s8(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s, bt, h->igemm_mode,
-                               h->cu_count > 0 ? h->cu_count : 256));
+  if ((rc = launch_ab_modes(h, h->igemm_mode, m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s)) <= 0) return rc;
+  HIP_TRY(launch_igemm_s8(m, n, k, dA, lda, dB, ldb, dC, ldc, accumulate ? 1 : 0, s, h->igemm_mode, cus_));
   return MMH_OK;
 }
 
@@ -158,11 +175,8 @@ int mmh_qgemm_f32(mmh_handle_t h, int m, int n, int k, const float *dA, int lda,
   // two-pass form (A/B modes of the int8 kernel): int32 C, then the dequantisation pass
   if ((rc = h->qc.reserve((size_t)m * nb * sizeof(int32_t))) != MMH_OK) return rc;
   int32_t *qc = static_cast<int32_t *>(h->qc.p);
-  int8_t *bt = nullptr;
-  if (igemm_s8_needs_pack(h->igemm_mode, qa, ka, qb, nb, k) &&
-      h->bt.reserve(igemm_s8_pack_bytes(n, k)) == MMH_OK)
-    bt = static_cast<int8_t *>(h->bt.p);
-  HIP_TRY(launch_igemm_s8(m, n, k, qa, ka, qb, nb, qc, nb, 0, s, bt, h->igemm_mode, cus));
+  if ((rc = launch_ab_modes(h, h->igemm_mode, m, n, k, qa, ka, qb, nb, qc, nb, 0, s)) < 0) return rc;
+  if (rc == 1) HIP_TRY(launch_igemm_s8(m, n, k, qa, ka, qb, nb, qc, nb, 0, s, h->igemm_mode, cus));
   hipLaunchKernelGGL(dequantize_kernel, dim3(quant_rows_grid(m, 0)), dim3(256), 0, s, qc, m, n, nb,
                      scales, scales + 1, dC, ldc);
   HIP_TRY(hipGetLastError());

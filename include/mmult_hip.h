@@ -211,14 +211,14 @@ int mmh_kernel_id(const char *short_name);
 #define MMH_OPT_STREAMK 1
 #define MMH_OPT_STREAMK_TIMEOUTS 2
 /* MMH_OPT_IGEMM_MODE: 0 (default) B read in place (LDS-DMA of its row-major slices, fragments by
- * ds_read_b64_tr_b8) for 4-byte aligned operands -- from one 256x256 tile per CU up the ping-pong kernel K3p
- * (igemm_s8_pp.hpp), below that 128x128 tiles (K3t) -- otherwise B packed once per call; 1 transpose B inside
- * the GEMM kernel; 2 the correctness-first kernel; 3 / 4 the packed-B kernel with 128x128 / 256x256 tiles,
- * 5 / 6 the lockstep in-place kernel K3t likewise, 8 / 9 K3p as a persistent launch / one workgroup per tile
- * (mode 0 picks by K), 7 K3p on v_mfma_i32_16x16x32_i8 -- the instruction BASELINE.json configs[4] names: the
- * same integers at half the matrix pipe's rate (A/B switches).
- * (Modes 10..13, timing-only ablations with wrong results, exist in libmmult_hip_ab.so only; the product
- * library rejects them.) */
+ * ds_read_b64_tr_b8) for 4-byte aligned operands -- 256x256 tiles on the ping-pong kernel K3p (igemm_s8_pp.hpp) where
+ * their rounds are cheaper, 128x128 tiles (K3t) otherwise; operands that are not 4-byte aligned are first copied
+ * into dense workspace images; 2 the correctness-first kernel (also what anything beyond the descriptors' 2 GiB
+ * window runs); 5 / 6 the lockstep in-place kernel K3t with 128x128 / 256x256 tiles, 8 / 9 K3p as a persistent launch /
+ * one workgroup per tile (mode 0 picks by K), 7 K3p on v_mfma_i32_16x16x32_i8 -- the instruction BASELINE.json
+ * configs[4] names: the same integers at half the matrix pipe's rate (A/B switches).
+ * (Modes 1, 3, 4 -- the in-kernel-transpose and packed-B rungs of rounds 1-2 -- and 10..13, timing-only ablations with
+ * wrong results, exist in libmmult_hip_ab.so only; the product library rejects them.) */
 #define MMH_OPT_IGEMM_MODE 3
 /* MMH_OPT_SPLITK (default 0 = off): 1 lets MMH_KERNEL_AUTO run shapes with fewer 128x128 tiles than
  * CUs as a split-K launch with as many concurrent K parts as fill the chip; 2..16 asks for that many

@@ -75,6 +75,15 @@ try:
     raise SystemExit("MMH_OPT_RIM = 17 accepted")
 except H.MMultError:
     pass
+# the int8 rungs that left the product in round 6 (tools/ab/igemm_s8_k3.hpp): K3 (mode 1), the packed-B kernel (3 / 4)
+rng = np.random.default_rng(7)
+for mode in (1, 3, 4):
+    mm.set_igemm_mode(mode)
+    for (m, n, k) in [(256, 256, 128), (512, 768, 640), (257, 255, 129), (100, 92, 72), (1280, 1024, 384)]:
+        qa = rng.integers(-127, 128, (m, k), dtype=np.int8)
+        qb = rng.integers(-127, 128, (k, n), dtype=np.int8)
+        assert np.array_equal(mm.igemm_s8(dev(qa), dev(qb)).cpu().numpy(), oracle.ref_igemm_s8(qa, qb)), (mode, m, n, k)
+mm.set_igemm_mode(0)
 mm.close()
 print("tools-build ok")
 """
@@ -209,7 +218,8 @@ def test_the_product_library_refuses_the_tools_builds_switches(mm):
     with pytest.raises(H.MMultError):
         mm.set_option(H.OPT_RIM5, 1)
     mm.set_option(H.OPT_RIM5, 0)
-    with pytest.raises(H.MMultError):
-        mm.set_igemm_mode(10)     # (timing-only ablation: tools build)
+    for mode in (1, 3, 4, 10):    # (K3 / packed-B rungs and the timing-only ablations: tools build)
+        with pytest.raises(H.MMultError):
+            mm.set_igemm_mode(mode)
     mm.set_igemm_mode(0)
     mm.set_kernel("auto")

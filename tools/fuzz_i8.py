@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the int8 kernels on one GPU: every MMH_OPT_IGEMM_MODE (0 auto, 1 in-kernel
-transpose, 3 / 4 packed B, 5 / 6 B read in place) against mode 2 (the correctness-first kernel, an
+"""Differential fuzz of the int8 kernels on one GPU: every MMH_OPT_IGEMM_MODE (0 auto, 5 / 6 B read in
+place, 7 / 8 / 9 the ping-pong kernel; FUZZ_I8_AB=1: the tools build's 1 in-kernel transpose and 3 / 4 packed B too) against mode 2 (the correctness-first kernel, an
 independent code path; integers -> bit-equal; MMH_I8_GRID_CAP=3 in the environment makes the persistent ping-pong
 kernel walk several tiles per workgroup on these small shapes) on random shapes, leading dimensions, byte-misaligned
 bases and accumulate flags, with guard bands around C.  usage: python tools/fuzz_i8.py [cases] [seed]"""
@@ -15,8 +15,11 @@ import how_to_optimize_gemm_amd as H  # noqa: E402
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
+MODES = [0, 5, 6, 7, 8, 9]   # (7: K3p on the config-named 16x16x32 instruction; 8 / 9: persistent / one workgroup per tile)
+if os.environ.get("FUZZ_I8_AB") == "1":    # the tools build: K3 (1) and the packed-B kernel (3 / 4) too
+    H.use_ab_library()
+    MODES += [1, 3, 4]
 mm = H.MMult(0)
-MODES = [0, 1, 3, 4, 5, 6, 7, 8, 9]   # (7: K3p on the config-named 16x16x32 instruction; 8 / 9: persistent / one workgroup per tile)
 GUARD = -2139062144          # 0x80808080: never a valid sum here
 
 
