@@ -37,8 +37,10 @@ struct RocblasApi {
 inline RocblasApi &rocblas_api() {
   static RocblasApi api = [] {
     RocblasApi a;
-    a.lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!a.lib) a.lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    // (the image's ROCm library by its path FIRST: inside a Python process that has imported torch the bare name resolves to
+    // the copy bundled in torch's wheel -- an older ROCm's, see blaslt_api)
+    a.lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (!a.lib) a.lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
     if (!a.lib) return a;
     a.create = reinterpret_cast<decltype(a.create)>(dlsym(a.lib, "rocblas_create_handle"));
     a.destroy = reinterpret_cast<decltype(a.destroy)>(dlsym(a.lib, "rocblas_destroy_handle"));
@@ -100,9 +102,14 @@ struct BlasLtApi {
 BlasLtApi &blaslt_api() {
   static BlasLtApi api = [] {
     BlasLtApi a;
-    a.lib = dlopen("libhipblaslt.so", RTLD_NOW | RTLD_LOCAL);
+    // The image's ROCm library by its path FIRST.  `dlopen("libhipblaslt.so")` inside a Python process that has imported torch
+    // returns the copy bundled in torch's wheel (ROCm 7.0 beside the image's 7.2): 15-20 % slower on its stream-K sizes
+    // (N = 2560: 122.6 against 147.9 TFLOP/s) -- what every in-process comparison of rounds 1-5 measured (round 6 notes).
+    // MMH_VENDOR_BARE_NAMES=1: the old order (whatever the process already holds).
+    const char *bare = getenv("MMH_VENDOR_BARE_NAMES");
+    if (!(bare && *bare == '1')) a.lib = dlopen("/opt/rocm/lib/libhipblaslt.so", RTLD_NOW | RTLD_LOCAL);
+    if (!a.lib) a.lib = dlopen("libhipblaslt.so", RTLD_NOW | RTLD_LOCAL);
     if (!a.lib) a.lib = dlopen("libhipblaslt.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!a.lib) a.lib = dlopen("/opt/rocm/lib/libhipblaslt.so", RTLD_NOW | RTLD_LOCAL);
     if (!a.lib) return a;
 #define MMH_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name))
     MMH_SYM(create, "hipblasLtCreate");

@@ -23,7 +23,8 @@ VARIANTS = ["auto", "mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x6
             "mfma_64x64_dma5", "mfma_128x64_dma5", "mfma_128x128_dma5", "mfma_96x96_dma5",          # K2W (round 4)
             "mfma_64x64_dma5/sk2", "mfma_128x64_dma5/sk2", "mfma_128x128_dma5/sk2",                 # ... stream-K whenever ragged
             "mfma_96x64_dma5", "valu_128x64",                                                     # round 5: the 96x64 K2W tile, K1W's third tile
-            "mfma_64x64_dma/sk2", "mfma_128x64_dma/sk2"]                                          # ... K2L under stream-K (AUTO's candidates now)
+            "mfma_64x64_dma/sk2", "mfma_128x64_dma/sk2",                                          # ... K2L under stream-K (AUTO's candidates now)
+            "valu_64x64/sk2", "valu_128x64/sk2", "valu_128x128/sk2"]                              # round 6: K1W under K2W's stream-K body
 
 
 def strided(rows, cols, ld, off, fill=None):
@@ -95,7 +96,7 @@ for n in (1152, 1536, 1792, 2176, 2432, 2944, 3072, 3456, 3712, 4352, 4608, 2049
     mm.set_kernel("mfma_tiles")
     ref = mm.matmul(a, b)
     # "auto": the LDS-DMA tiles under stream-K below 4096, the 256x256 tile above; "mfma": the register-staged 128x128 tile
-    for kern in ("auto", "mfma", "mfma_128x128_dma5/sk2", "mfma_64x64_dma5/sk2"):
+    for kern in ("auto", "mfma", "mfma_128x128_dma5/sk2", "mfma_64x64_dma5/sk2", "valu_128x128/sk2", "valu_64x64/sk2", "valu"):
         mm.set_kernel(kern.split("/")[0])
         mm.set_streamk(2 if kern.endswith("/sk2") else 1)
         c = torch.empty_like(ref)

@@ -55,6 +55,11 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--warm-ms", type=float, default=25.0)
     ap.add_argument("--variants", default=",".join(OURS + VENDORS))
+    ap.add_argument("--vendor-harness", action="store_true",
+                    help="take the rocblas / hipblaslt columns from harness/test_MMult.x, one C++ process per shape and library: "
+                         "the image's ROCm libraries.  In THIS process (torch imported) dlopen finds the copies inside torch's "
+                         "wheel -- an older hipBLASLt, 15-20 %% slower on its stream-K sizes; those figures are then kept "
+                         "under <lib>_torch_bundled (round 6)")
     args = ap.parse_args()
     import torch
     import how_to_optimize_gemm_amd as H
@@ -101,6 +106,23 @@ def main():
         for v in variants:
             xs = sorted(res[v]) if res.get(v) else None
             row[v] = round(xs[len(xs) // 2], 1) if xs else None
+        if args.vendor_harness:
+            import subprocess
+            exe = os.path.join(REPO, "how-to-optimize-gemm_amd", "harness", "test_MMult.x")
+            torch.cuda.synchronize()
+            for v in [x for x in variants if x in VENDORS]:
+                row[v + "_torch_bundled"] = row[v]
+                row[v] = None
+                env = {**os.environ, "KERNEL": v, "REF": "skip", "WARMUP_MS": "50", "TRIALS": "3", "M": str(m), "N": str(n), "K": str(k),
+                       "LDA": str(lda), "LDB": str(ldb), "LDC": str(ldc), "PFIRST": "1", "PLAST": "1", "PINC": "1"}
+                try:
+                    r = subprocess.run([exe], cwd=os.path.dirname(exe), env=env, capture_output=True, text=True, timeout=120)
+                    for line in r.stdout.splitlines():
+                        f = line.split()
+                        if len(f) == 3 and f[0] == "1":
+                            row[v] = round(float(f[1]) / 1e3, 1)
+                except Exception:
+                    pass
         rows.append(row)
         print(json.dumps(row), flush=True)
     mm.close()
