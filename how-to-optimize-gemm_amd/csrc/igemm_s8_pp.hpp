@@ -36,9 +36,9 @@
 // names: each 64-deep step is two 32-deep instructions on the low / high 8 bytes of the lanes' 16 (both operands
 // use the same lane -> k map, so the sum runs over the same 64 products) -- bit-identical, half the rate of the
 // pipe (profiles/r04_i8_instr_ab.md: 2.33 against 3.91 POPS on random operands).  MMH_OPT_IGEMM_MODE 7.
-// Measured (profiles/r03_igemm_s8_ksweep.txt, r03_notes.md section 4; M = N = 4096, K swept, us per launch =
-// fixed + slope x K): 17.1 us + 3.18 POPS in the loop = 0.83 of what the matrix pipe sustains on random
-// operands at the power-managed clock (3.84 POPS).
+// Measured: round 3 (profiles/r03_igemm_s8_ksweep.txt; M = N = 4096, K swept) 17.1 us + a loop at 3.18 POPS = 0.83 of what
+// the matrix pipe sustains on random operands at the power-managed clock; round 6 (profiles/r06_notes.md section 1): the
+// "fixed" part was the C stores' issue time -- with the transposer 4096^3 runs 56.5 us (2.43 POPS), 8192^3 2.65 - 2.74 POPS.
 // BASELINE.json config 5; no reference code (README.md:71-85 is prose): parity unpinned.
 #pragma once
 #include "igemm_s8.hpp"

@@ -129,7 +129,7 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_SPLITK_128X64 20 /* the same on 128x64 tiles                                            */
 /* The product library accepts exactly the ids above: every one of them returns correct results.
  * The scheduling A/B variants (ids 16-19) and the TIMING-ONLY ablation builds whose results are
- * wrong (21-24, 32-44; int8 modes 10-13) exist only in libmmult_hip_ab.so, a tools-only build of the
+ * wrong (21-24, 32-44; int8 modes 10-13), and the int8 rungs mode 0 never reaches (modes 1, 3, 4), exist only in libmmult_hip_ab.so, a tools-only build of the
  * same sources (-DMMH_AB_BUILD; how_to_optimize_gemm_amd.build.build_ab_library(), tools/ab_bench.py).
  * mmh_is_ab_build() tells the two apart.  See profiles/r01_ablation.md. */
 
