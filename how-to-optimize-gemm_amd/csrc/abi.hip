@@ -169,6 +169,10 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
                 // their own instantiation's residency (77 / 117 registers: three / two workgroups per CU) instead of the guarded one's
       h->ab_own_occ = value ? 1 : 0;
       return MMH_OK;
+    case 106:   // A/B (round 6): persistent launches of ragged counts with WHOLE-tile ranges -- no partial tiles, no hand-over, a
+                // deterministic share per CU where a plain launch's last round is placed greedily (profiles/r06_notes.md section 6)
+      h->ab_whole_ranges = value ? 1 : 0;
+      return MMH_OK;
     case 105:   // A/B: the vector-ALU rung as it was before round 5 (register-staged K1) instead of K1W
       h->ab_valu_old = value ? 1 : 0;
       return MMH_OK;

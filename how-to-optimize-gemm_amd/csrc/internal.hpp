@@ -143,6 +143,7 @@ struct mmh_context {
   int dma_dword_rows = 1;      // ... including operands whose rows are only 4-byte aligned (odd lda / ldb / base)
   int sk_chain = 1;            // stream-K launches of the K2W tiles (launch_dma5.hip) run a range's parts as one stream of slices (MMH_OPT_STREAMK_CHAIN)
   int rim5 = 0;                // tools build only (MMH_OPT_RIM5): the RIM launch of the 64x64 K2W tile -- measured, it loses
+  int ab_whole_ranges = 0;     // tools build only (option 106): persistent launches take WHOLE tiles (ranges rounded to tile boundaries: no hand-over)
   int ab_nodefer = 0;          // tools build only (option 102): stream-K heads publish on the spot (no deferred publish)
   int ab_valu_old = 0;         // tools build only (option 105): the K1 ids run the register-staged K1 of rounds 1-4, not K1W
   int ab_own_occ = 0;          // tools build only (option 103): a whole-tile stream-K launch is bounded by ITS OWN instantiation's residency

@@ -64,7 +64,7 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
 #endif
   GemmArgs ga = g;
 #ifdef MMH_AB_BUILD   // A/B switches ride in the upper bits of `accumulate` (sgemm_dma5.hpp)
-  if (ctx) ga.acc |= (ctx->ab_nodefer ? 2 : 0) | ((ctx->ab_group_m & 0xff) << 8);
+  if (ctx) ga.acc |= (ctx->ab_nodefer ? 2 : 0) | (ctx->ab_whole_ranges ? 4 : 0) | ((ctx->ab_group_m & 0xff) << 8);
 #endif
   if constexpr (SK) {
     if (ctx && ctx->streamk) {

@@ -712,8 +712,9 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
   constexpr bool chained = CHAINED;
   using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, true, EDGE, true, NL, D, false, VALU>;
   using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
-  // tools build: bit 1 of `accumulate` = publish every head on the spot, bits 8-15 = raster group height
+  // tools build: bit 1 of `accumulate` = publish every head on the spot, bit 2 = whole-tile ranges, bits 8-15 = raster group height
   const bool ab_nodefer = kAbBuild && (accumulate & 2) != 0;
+  const bool ab_whole = kAbBuild && (accumulate & 4) != 0;
   const int ab_gm = kAbBuild ? (accumulate >> 8) & 0xff : 0;
   if constexpr (kAbBuild) accumulate &= 1;
   const int GMr = ab_gm > 0 ? ab_gm : T::GM;
@@ -741,6 +742,12 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
     rem = total % (unsigned)G;
     u0 = per * (unsigned)q + rem * (unsigned)q / (unsigned)G;
     u1 = per * (unsigned)(q + 1) + rem * (unsigned)(q + 1) / (unsigned)G;
+  }
+  if constexpr (kAbBuild) {
+    if (ab_whole) {   // ranges rounded to tile boundaries: range q takes tiles [Tn q / G, Tn (q + 1) / G)
+      u0 = (unsigned)(((unsigned long long)Tn * (unsigned)q) / (unsigned)G) * (unsigned)nk;
+      u1 = (unsigned)(((unsigned long long)Tn * (unsigned)(q + 1)) / (unsigned)G) * (unsigned)nk;
+    }
   }
   if (u1 <= u0) return;
   const int t_first = (int)(u0 / (unsigned)nk), k_first = (int)(u0 - (unsigned)t_first * (unsigned)nk);

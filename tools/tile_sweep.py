@@ -78,6 +78,7 @@ def main():
             mm.set_option(103, 1 if "oo" in parts[1:] else 0)   # whole-tile stream-K launches bounded by their own residency
             mm.set_option(100, 0 if "np" in parts[1:] else 1)   # /np: persistent launches ask for their own LDS only (no 160 KiB / w pin)
             mm.set_option(105, 1 if "k1old" in parts[1:] else 0)   # /k1old: the register-staged K1 of rounds 1-4
+            mm.set_option(106, 1 if "wr" in parts[1:] else 0)      # /wr: persistent launches with whole-tile ranges (round 6)
             om = [x for x in parts[1:] if x.startswith("om") and x[2:].isdigit()]   # /omNN: phase-ordered tables from NN/10 tiles per workgroup
             mm.set_option(104, int(om[0][2:]) if om else 18)
 
