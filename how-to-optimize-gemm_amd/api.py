@@ -38,7 +38,7 @@ KERNELS = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA,
            "valu_128x128": 13, "valu_64x64": 14, "valu_128x64": 9, "mfma_splitk": 15, "mfma_splitk_128x64": 20,
            "mfma_64x64_dma": 25, "mfma_128x64_dma": 27, "mfma_128x128_dma": 28,
            "mfma_64x64_dma5": 29, "mfma_128x64_dma5": 30, "mfma_128x128_dma5": 31,
-           "mfma_96x96_dma5": 7, "mfma_96x64_dma5": 26,
+           "mfma_96x96_dma5": 7, "mfma_96x64_dma5": 26, "mfma_160x160_dma5": 100,
            }
 # (tools build only, libmmult_hip_ab.so: the 32x32x2 tiles mfma32_* / mfma32b_* (ids 48-51, 60-62), exp5_*, the rim --
 # their names resolve through the library's own table, mmh_kernel_id)

@@ -255,6 +255,7 @@ const char *mmh_kernel_name(int kernel) {
     case MMH_KERNEL_MFMA_128X128_DMA5: return "MMult_hip_mfma_128x128_dma5";
     case MMH_KERNEL_MFMA_96X96_DMA5: return "MMult_hip_mfma_96x96_dma5";
     case MMH_KERNEL_MFMA_96X64_DMA5: return "MMult_hip_mfma_96x64_dma5";
+    case MMH_KERNEL_MFMA_160X160_DMA5: return "MMult_hip_mfma_160x160_dma5";
     case MMH_KERNEL_MFMA_SPLITK: return "MMult_hip_mfma_splitk";
     case MMH_KERNEL_MFMA_SPLITK_128X64: return "MMult_hip_mfma_splitk_128x64";
 #ifdef MMH_AB_BUILD
@@ -306,7 +307,6 @@ const char *mmh_kernel_name(int kernel) {
     case 72: return "exp5_128x128_l1d2";
     case 79: return "exp5_160x96_l1d2";
     case 80: return "exp5_160x160_l1d2";
-    case 81: return "exp5_160x160_l4";
     case 82: return "exp5_160x160_l2";
     case 83: return "exp5_96x64_l4";
     case 84: return "exp5_96x64_l2";
@@ -317,6 +317,11 @@ const char *mmh_kernel_name(int kernel) {
     case 92: return "k1w_64x64_a4";
     case 93: return "k1w_128x128_b2l4a2";
     case 94: return "k1w_128x128_b2l1a2";
+    case 95: return "exp5_160x160_rs0";
+    case 96: return "exp5_128x128_rs0";
+    case 97: return "exp5_128x64_rs0";
+    case 98: return "exp5_64x64_rs0";
+    case 99: return "exp5_96x96_rs0";
 #endif
     default: return nullptr;
   }

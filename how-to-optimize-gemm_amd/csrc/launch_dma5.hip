@@ -1,5 +1,5 @@
 // launch_dma5.hip -- launchers of the LDS-DMA tiles with loader waves (sgemm_dma5.hpp, K2W): 64x64, 128x64, 128x128 and
-// the whole-round tiles 96x96 / 160x96 / 160x160, each as one workgroup per tile or as the persistent stream-K form
+// the whole-round tiles 96x96 / 96x64 / 160x160 (160x96: tools build), each as one workgroup per tile or as the persistent stream-K form
 // (chained parts), each in a whole-tile and a guarded (EDGE: any m, n, k, 4-byte aligned operands) instantiation.
 // Part of libmmult_hip.so (see internal.hpp).
 #include "launch_common.hpp"
@@ -22,7 +22,7 @@ int dma5_form(const mmh_context *ctx, const GemmArgs &g) {
 }
 
 // SK: the tile has a stream-K form (the whole-round tiles are launched one workgroup per tile only)
-template <int BM, int BN, int WTM, int WTN, int NBUF, int NL, int D, bool SK = true>
+template <int BM, int BN, int WTM, int WTN, int NBUF, int NL, int D, bool SK = true, int RS = 1>
 int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
   constexpr int KB = 32;
   using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
@@ -70,11 +70,11 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
     if (ctx && ctx->streamk) {
       // the parts of a range as ONE stream of slices (MMH_OPT_STREAMK_CHAIN, default on), or each with a prologue of its own
       const bool chained = ctx->sk_chain != 0;
-      auto kern = chained ? sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false, true, NL, D>
-                          : sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false, false, NL, D>;
-      auto kern_edge = chained ? sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true, NL, D>
-                               : sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, false, NL, D>;
-      auto occ = sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true, NL, D>;
+      auto kern = chained ? sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false, true, NL, D, RS>
+                          : sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, false, false, NL, D, RS>;
+      auto kern_edge = chained ? sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true, NL, D, RS>
+                               : sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, false, NL, D, RS>;
+      auto occ = sgemm_dma5_streamk_kernel<BM, BN, KB, WTM, WTN, NBUF, true, true, NL, D, RS>;
 #ifdef MMH_AB_BUILD   // option 103: the residency of the instantiation that is launched (found on the CPU)
       if (ctx->ab_own_occ && !edge) occ = kern;
 #endif
@@ -96,8 +96,8 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
     }
   }
   const int nbm = (g.m + BM - 1) / BM, nbn = (g.n + BN - 1) / BN;
-  auto kern = edge ? sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, true, NL, D>
-                   : sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, false, NL, D>;
+  auto kern = edge ? sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, true, NL, D, RS>
+                   : sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, false, NL, D, RS>;
   const int ok = allow_big_lds(kern, T::LDS_BYTES);
   if (ok != MMH_OK) return ok;
   hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(T::THREADS), T::LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda, g.B,
@@ -145,6 +145,7 @@ bool dma5_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g) {
     case MMH_KERNEL_MFMA_128X128_DMA5: return dma5_form<128, 128, 32>(ctx, g) >= 0;
     case MMH_KERNEL_MFMA_96X96_DMA5: return dma5_form<96, 96, 32>(ctx, g) >= 0;
     case MMH_KERNEL_MFMA_96X64_DMA5: return dma5_form<96, 64, 32>(ctx, g) >= 0;
+    case MMH_KERNEL_MFMA_160X160_DMA5: return dma5_form<160, 160, 32>(ctx, g) >= 0;
     default: return false;
   }
 }
@@ -165,6 +166,8 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
       return launch_dma5_tile<96, 96, 3, 3, 3, 1, 2, false>(ctx, g);
     case MMH_KERNEL_MFMA_96X64_DMA5:    // 96x64 tile, consumers of 48x32 + four loaders, 60 KiB ring: 2 per CU (round 5; N = 1152: 110.5 against 106.6 TFLOP/s)
       return launch_dma5_tile<96, 64, 3, 2, 3, 4, 2, false>(ctx, g);
+    case MMH_KERNEL_MFMA_160X160_DMA5:  // 160x160 tile, consumers of 80x80 (column-blocked B) + four loaders, 120 KiB ring: 1 per CU (N = 2560: 256 of them)
+      return launch_dma5_tile<160, 160, 5, 5, 3, 4, 2, false>(ctx, g);
 #ifdef MMH_AB_BUILD
     // A/B (valid results): ONE loader wave (round 4's first form), and the 160-wide whole-round tiles that lost to the
     // chained stream-K launch of the 128-wide ones (N = 2560: 140.8 against 145.2; N = 1920 on 160x96: 130.9 against 137.5)
@@ -178,15 +181,22 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
     case 72: return launch_dma5_tile<128, 128, 4, 4, 3, 1, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 79: return launch_dma5_tile<160, 96, 5, 3, 3, 1, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 80: return launch_dma5_tile<160, 160, 5, 5, 3, 1, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
-    // (the 160x160 tile's loss is not its one loader: 1 / 2 / 4 loaders at N = 2560 -- 256 tiles, one whole round -- 139.9 /
-    // 139.8 / 140.6 against the 128x128 tile's chained stream-K 144.6; four whole rounds at N = 5120: 143.9 against 150.2.
-    // Five column-blocked B fragments of single floats per k-step and 100 accumulator registers: the loop itself is slower.)
-    case 81: return launch_dma5_tile<160, 160, 5, 5, 3, 4, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    // (rounds 4-5, fragment reads as a block: 1 / 2 / 4 loaders at N = 2560 -- 256 tiles, one whole round -- 139.9 / 139.8 /
+    // 140.6 against the 128x128 tile's chained stream-K 144.6; four whole rounds at N = 5120: 143.9 against 150.2.  It was
+    // the ten ds_read instructions per k-step leaving in one block (id 95 keeps that form); the four-loader form with
+    // the reads spread is the product's MMH_KERNEL_MFMA_160X160_DMA5)
     case 82: return launch_dma5_tile<160, 160, 5, 5, 3, 2, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     // round 5: 96x64 / 64x96 (N = 1152: 216 tiles -- one round of 256 CUs at 84 % -- instead of 324 tiles of 64x64 under stream-K)
     case 83: return launch_dma5_tile<96, 64, 3, 2, 3, 4, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;   // (with a stream-K form: never ahead)
     case 84: return launch_dma5_tile<96, 64, 3, 2, 3, 2, 2>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 85: return launch_dma5_tile<64, 96, 2, 3, 3, 2, 2, false>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    // round 6 (second session): the fragment reads as a BLOCK in front of the k-step's MFMAs (RS = 0: rounds 4-6's form) --
+    // what every tile here ran until the reads were spread behind the first MFMAs (sgemm_dma5.hpp, RS)
+    case 95: return launch_dma5_tile<160, 160, 5, 5, 3, 4, 2, false, 0>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 96: return launch_dma5_tile<128, 128, 4, 4, 3, 4, 2, true, 0>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 97: return launch_dma5_tile<128, 64, 4, 2, 3, 4, 2, true, 0>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 98: return launch_dma5_tile<64, 64, 2, 2, 3, 2, 2, true, 0>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    case 99: return launch_dma5_tile<96, 96, 3, 3, 3, 1, 2, false, 0>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
 #endif
     default:
       set_last_error("unknown kernel variant");
@@ -210,6 +220,7 @@ int warm_dma5(mmh_context *ctx, float *scratch, hipStream_t s) {
   if ((rc = warm_dma5_tile<128, 64, 4, 2, 3, 4, 2>(ctx, scratch, s)) != MMH_OK) return rc;
   if ((rc = warm_dma5_tile<128, 128, 4, 4, 3, 4, 2>(ctx, scratch, s)) != MMH_OK) return rc;
   if ((rc = warm_dma5_tile<96, 96, 3, 3, 3, 1, 2, false>(ctx, scratch, s)) != MMH_OK) return rc;
+  if ((rc = warm_dma5_tile<160, 160, 5, 5, 3, 4, 2, false>(ctx, scratch, s)) != MMH_OK) return rc;
   return warm_dma5_tile<96, 64, 3, 2, 3, 4, 2, false>(ctx, scratch, s);
 }
 

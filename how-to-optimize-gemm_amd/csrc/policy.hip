@@ -43,7 +43,7 @@ struct Plan {
 
 bool is_k2w(int kernel) {
   return kernel == MMH_KERNEL_MFMA_64X64_DMA5 || kernel == MMH_KERNEL_MFMA_128X64_DMA5 || kernel == MMH_KERNEL_MFMA_128X128_DMA5 ||
-         kernel == MMH_KERNEL_MFMA_96X96_DMA5 || kernel == MMH_KERNEL_MFMA_96X64_DMA5;
+         kernel == MMH_KERNEL_MFMA_96X96_DMA5 || kernel == MMH_KERNEL_MFMA_96X64_DMA5 || kernel == MMH_KERNEL_MFMA_160X160_DMA5;
 }
 bool is_k2l(int kernel) {
   return kernel == MMH_KERNEL_MFMA_64X64_DMA || kernel == MMH_KERNEL_MFMA_128X64_DMA || kernel == MMH_KERNEL_MFMA_128X128_DMA;
@@ -218,6 +218,7 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
     }
     case MMH_KERNEL_MFMA_128X128_DMA5:
     case MMH_KERNEL_MFMA_96X64_DMA5:
+    case MMH_KERNEL_MFMA_160X160_DMA5:
     case MMH_KERNEL_MFMA_96X96_DMA5: {
       const int d = launch_dma5(ctx, kernel, g);
       return d <= 0 ? d : launch_reg(ctx, MMH_KERNEL_MFMA, g);
@@ -266,7 +267,7 @@ int sgemm_on(mmh_context *ctx, int kernel, int m, int n, int k, const float *dA,
       return launch_dma(ctx, kernel, g);
     case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59:
       return launch_dma32(ctx, kernel, g);
-    case 64: case 65: case 66: case 67: case 68: case 69: case 72: case 79: case 80: case 81: case 82: case 83: case 84: case 85:
+    case 64: case 65: case 66: case 67: case 68: case 69: case 72: case 79: case 80: case 82: case 83: case 84: case 85: case 95: case 96: case 97: case 98: case 99:
       return launch_dma5(ctx, kernel, g);
     case 87: case 89: case 91: case 92: case 93: case 94:
       return launch_valu(ctx, kernel, g);

@@ -141,7 +141,7 @@ struct Dma5ValuFrags {
 };
 
 template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool PART_WT = false, bool EDGE = false, bool CHAIN = false,
-          int NL = 1, int D = 2, bool RIM = false, bool VALU = false>
+          int NL = 1, int D = 2, bool RIM = false, bool VALU = false, int RS = 1>
 struct Dma5Segment {
   using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
   static_assert(!VALU || (!EDGE && !RIM && (D == 2 || D == 4) && (BM == 64 || BM == 128) && (BN == 64 || BN == 128)),
@@ -503,12 +503,33 @@ struct Dma5Segment {
             }
           }
         }
+        // RS (read spread): the fragment reads of k-step ks + D leave ONE AT A TIME behind the first MFMAs of k-step ks,
+        // each in the shadow of a matrix instruction, instead of as a block in front of them (a wave alone on its SIMD
+        // issues nothing else while eight ds_read instructions leave: the 160x160 tile's 5 + 5 single-float fragments)
+        constexpr int UA = (WTM + 1) / 2, UB = BBLK ? WTN : 1, UNITS = UA + UB;
+        auto read_unit = [&](auto j_c) {
+          constexpr int j = decltype(j_c)::value;
+          constexpr int rks = ks + D < KS ? ks + D : ks + D - KS;
+          const float *rb = ks + D < KS ? buf : nxt;
+          float(&fa)[WTM] = fr.a[(ks + D) % SLOTS];
+          float(&fb)[WTN] = fr.b[(ks + D) % SLOTS];
+          if constexpr (j < UA) {
+#pragma unroll
+            for (int t = 2 * j; t < 2 * j + 2 && t < WTM; ++t) fa[t] = rb[L.a_off[rks & 7] + 4 * (rks & ~7) + t * 16 * KB];
+          } else if constexpr (BBLK) {
+            fb[j - UA] = rb[L.b_off[j - UA] + 4 * rks * BN];
+          } else {
+            frag_b(rb, std::integral_constant<int, rks>{}, fb);
+          }
+        };
+        if constexpr (RS == 0) {
         if constexpr (ks + D < KS) {
           frag_a(buf, std::integral_constant<int, ks + D>{}, fr.a[(ks + D) % SLOTS]);
           frag_b(buf, std::integral_constant<int, ks + D>{}, fr.b[(ks + D) % SLOTS]);
         } else {
           frag_a(nxt, std::integral_constant<int, ks + D - KS>{}, fr.a[(ks + D) % SLOTS]);
           frag_b(nxt, std::integral_constant<int, ks + D - KS>{}, fr.b[(ks + D) % SLOTS]);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         float a[NT], b[NU];
@@ -525,10 +546,25 @@ struct Dma5Segment {
 #pragma unroll
           for (int u = 0; u < NU; ++u) b[u] = live ? b[u] : 0.0f;
         }
+        if constexpr (RS == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int u = 0; u < NU; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
+        } else {
+          static_for<NT * NU>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value, t = i / NU, u = i % NU;
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
+            if constexpr (i < UNITS) {
+              __builtin_amdgcn_sched_barrier(0);
+              read_unit(i_c);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
+          static_for<UNITS>([&](auto j_c) {   // (thin waves: fewer MFMAs than reads)
+            if constexpr (decltype(j_c)::value >= NT * NU) read_unit(j_c);
+          });
+        }
         __builtin_amdgcn_sched_barrier(0);
       });
     };
@@ -651,12 +687,12 @@ struct Dma5Segment {
 // of the trimmed shape would, and the thin tiles -- a fraction of a whole tile's matrix-pipe time each -- land beside
 // them as second workgroups.  In raster order they would take first-round slots and push whole tiles into a second
 // round (N = 1025: 289 tiles of 64x64 for 256 CUs, 33 of them thin).
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false, int NL = 1, int D = 2>
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false, int NL = 1, int D = 2, int RS = 1>
 __global__ void __launch_bounds__(64 * (4 + NL))
 sgemm_mfma_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
                        float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, false, EDGE, false, NL, D>;
+  using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, false, EDGE, false, NL, D, false, false, RS>;
   int tm, tn;
   // (round 5: every kernel argument is requested HERE -- left alone hipcc loads the operands' pointers and leading
   // dimensions only behind the branch to the loader path, a second scalar-memory round trip in front of the first DMA)
@@ -703,14 +739,14 @@ sgemm_mfma_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda
 // looked at (they depend on nobody); should the word say the head's owner is not running (the wait-free path: leave),
 // they are dropped.
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE, bool CHAINED, int NL, int D, bool VALU = false>
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE, bool CHAINED, int NL, int D, bool VALU = false, int RS = 1>
 __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, const float *__restrict__ A, int lda,
                                               const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc,
                                               int accumulate, int nbm, int nbn, int *__restrict__ flags,
                                               float *__restrict__ parts, const int *__restrict__ order,
                                               const int *__restrict__ place, int *__restrict__ stats) {
   constexpr bool chained = CHAINED;
-  using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, true, EDGE, true, NL, D, false, VALU>;
+  using S = Dma5Segment<BM, BN, KB, WTM, WTN, NBUF, true, EDGE, true, NL, D, false, VALU, RS>;
   using T = Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>;
   // tools build: bit 1 of `accumulate` = publish every head on the spot, bit 2 = whole-tile ranges, bits 8-15 = raster group height
   const bool ab_nodefer = kAbBuild && (accumulate & 2) != 0;
@@ -929,7 +965,7 @@ __device__ __forceinline__ void streamk5_body(float *lds, int m, int n, int k, c
 }
 
 // CHAINED = false: every part of a range starts with an empty pipeline (the A/B baseline, tools build)
-template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false, bool CHAINED = true, int NL = 1, int D = 2>
+template <int BM, int BN, int KB, int WTM, int WTN, int NBUF, bool EDGE = false, bool CHAINED = true, int NL = 1, int D = 2, int RS = 1>
 __global__ void __launch_bounds__(64 * (4 + NL))
 sgemm_dma5_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int lda, const float *__restrict__ B,
                           int ldb, float *__restrict__ C, int ldc, int accumulate, int nbm, int nbn,
@@ -937,7 +973,7 @@ sgemm_dma5_streamk_kernel(int m, int n, int k, const float *__restrict__ A, int 
                           const int *__restrict__ place, int *__restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   asm volatile("" ::"s"(A), "s"(B), "s"(C), "s"(lda), "s"(ldb), "s"(ldc), "s"(k), "s"(flags), "s"(parts), "s"(order), "s"(place));   // (every argument requested at entry: sgemm_mfma_dma5_kernel)
-  streamk5_body<BM, BN, KB, WTM, WTN, NBUF, EDGE, CHAINED, NL, D>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn,
+  streamk5_body<BM, BN, KB, WTM, WTN, NBUF, EDGE, CHAINED, NL, D, false, RS>(lds, m, n, k, A, lda, B, ldb, C, ldc, accumulate, nbm, nbn,
                                                                    flags, parts, order, place, stats);
 }
 

@@ -112,10 +112,16 @@ typedef struct mmh_context *mmh_handle_t;
 #define MMH_KERNEL_MFMA_128X128_DMA5 31
 /* ... and a whole-round tile of 32 i x 32 j (wave tiles of 48 x 48; B fragments column-blocked): 96x96 lands
  * N = 1536 of the reference sweep (cuda/parameters.h:5-7) on exactly 256 tiles.  One workgroup per tile only (no
- * stream-K form).  (160x96 and 160x160 were built and measured too -- N = 1920, 2560 -- and lose to the chained
- * stream-K launch of the 128-wide tiles; they live in the tools build, profiles/r04_notes.md.) */
+ * stream-K form).  (160x96 was built and measured too -- N = 1920 -- and loses to the chained stream-K launch of
+ * the 128-wide tiles; it lives in the tools build, profiles/r04_notes.md.) */
 #define MMH_KERNEL_MFMA_96X96_DMA5 7
 #define MMH_KERNEL_MFMA_96X64_DMA5 26  /* round 5: 96x64 (wave tile 48x32), one workgroup per tile only: N = 1152 is 216 of them */
+/* 160x160 (wave tiles of 80 x 80, four loaders, 120 KiB ring: one workgroup per CU; one workgroup per tile only).
+ * Rounds 4-5 measured it BEHIND the 128x128 tile's stream-K launch (N = 2560: 140.8 against 145.2 TFLOP/s) and kept it in
+ * the tools build: its ten single-float fragment reads per k-step left as a block in front of the 25 MFMAs, with a lone
+ * wave per SIMD issuing nothing else meanwhile.  Since round 6 every K2W tile spreads its fragment reads behind the k-step's
+ * first MFMAs (sgemm_dma5.hpp, RS): N = 2560 -- exactly 256 tiles -- 149.4, N = 5120 152.0 (profiles/r06_notes.md section 8). */
+#define MMH_KERNEL_MFMA_160X160_DMA5 100
 /* (Tools build only -- libmmult_hip_ab.so, never this library: K2M, the same LDS-DMA ring feeding
  * v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x1_2b_f32 (ids 48-51, 60-62; measured slower than the 16x16x4 tiles,
  * profiles/r04_notes.md), the one-loader and 160-wide forms of K2W (64, 68, 72, 79, 80), the scheduling A/Bs and the

@@ -93,7 +93,9 @@ mm = H.MMult(0, "auto")
 shapes = [(256, 256, 64), (384, 512, 192), (1024, 1024, 1024), (1152, 1152, 1152), (300, 259, 101), (1025, 1023, 257), (2304, 2304, 512)]
 for name in ("mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma", "mfma32b_128x64_dma",
              "mfma32b_64x128_dma", "mfma32b_128x128_dma", "exp5_64x64_l1d2", "exp5_128x64_l1d2", "exp5_128x128_l1d2",
-             "exp5_160x96_l1d2", "exp5_160x160_l1d2"):
+             "exp5_160x96_l1d2", "exp5_160x160_l1d2",
+             # round 6: the fragment reads as a block in front of the k-step's MFMAs (what rounds 4-6 shipped; RS = 0)
+             "exp5_160x160_rs0", "exp5_128x128_rs0", "exp5_128x64_rs0", "exp5_64x64_rs0", "exp5_96x96_rs0"):
     mm.set_kernel(name)
     for sk in (1, 2):
         mm.set_streamk(sk)
@@ -111,7 +113,9 @@ mm = H.MMult(0, "auto")
 shapes = [(256, 256, 64), (384, 512, 192), (1024, 1024, 1024), (1152, 1152, 1152), (300, 259, 101), (1025, 1023, 257), (2304, 2304, 512)]
 for name in ("mfma32_64x64_dma", "mfma32_128x64_dma", "mfma32_64x128_dma", "mfma32_128x128_dma", "mfma32b_128x64_dma",
              "mfma32b_64x128_dma", "mfma32b_128x128_dma", "exp5_64x64_l1d2", "exp5_128x64_l1d2", "exp5_128x128_l1d2",
-             "exp5_160x96_l1d2", "exp5_160x160_l1d2"):
+             "exp5_160x96_l1d2", "exp5_160x160_l1d2",
+             # round 6: the fragment reads as a block in front of the k-step's MFMAs (what rounds 4-6 shipped; RS = 0)
+             "exp5_160x160_rs0", "exp5_128x128_rs0", "exp5_128x64_rs0", "exp5_64x64_rs0", "exp5_96x96_rs0"):
     mm.set_kernel(name)
     for sk in (1, 2):
         mm.set_streamk(sk)

@@ -102,7 +102,7 @@ PY
 fi
 if has dataset; then    # every (tile family, launch form) forced over the fit / held-out shape lists: what MMH_KERNEL_AUTO's table is fitted on
   # (round 5: the K2L tiles forced both ways too -- candidates of the table since this round -- and the 96x64 tile)
-  DV="auto,mfma_64x64_dma5/sk0,mfma_64x64_dma5/sk2,mfma_128x64_dma5/sk0,mfma_128x64_dma5/sk2,mfma_128x128_dma5/sk0,mfma_128x128_dma5/sk2,mfma_96x96_dma5,mfma_96x64_dma5,mfma_256x256/sk0,mfma_256x256/sk2,mfma_64x64_dma/sk0,mfma_64x64_dma/sk2,mfma_128x64_dma/sk0,mfma_128x64_dma/sk2,mfma_128x128_dma/sk0,mfma_128x128_dma/sk2"
+  DV="auto,mfma_64x64_dma5/sk0,mfma_64x64_dma5/sk2,mfma_128x64_dma5/sk0,mfma_128x64_dma5/sk2,mfma_128x128_dma5/sk0,mfma_128x128_dma5/sk2,mfma_96x96_dma5,mfma_96x64_dma5,mfma_160x160_dma5,mfma_256x256/sk0,mfma_256x256/sk2,mfma_64x64_dma/sk0,mfma_64x64_dma/sk2,mfma_128x64_dma/sk0,mfma_128x64_dma/sk2,mfma_128x128_dma/sk0,mfma_128x128_dma/sk2"
   for which in ${DATASETS:-fit heldout}; do
     timeout 900 python tools/tile_sweep.py --shape-file tools/policy_shapes_$which.txt --variants "$DV" --rounds 2 --reps 10 --warm-ms 10 \
       --out $OUT/dataset_$which > $OUT/dataset_$which.log 2>&1

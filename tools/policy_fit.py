@@ -52,6 +52,7 @@ FAMILIES = {
     "t128": ("mfma_128x128_dma5", 128, 128, 1, True, 1, "MMH_KERNEL_MFMA_128X128_DMA5"),
     "t96": ("mfma_96x96_dma5", 96, 96, 2, False, 0, "MMH_KERNEL_MFMA_96X96_DMA5"),
     "t96x64": ("mfma_96x64_dma5", 96, 64, 2, False, 0, "MMH_KERNEL_MFMA_96X64_DMA5"),
+    "t160": ("mfma_160x160_dma5", 160, 160, 1, False, 0, "MMH_KERNEL_MFMA_160X160_DMA5"),   # round 6: ships since the fragment reads are spread (N = 2560: 256 tiles)
     "t256": ("mfma_256x256", 256, 256, 1, True, 1, "MMH_KERNEL_MFMA_256X256"),
     # K2L (round 3's LDS-DMA tiles, every wave issuing its share of the DMA): candidates since round 5
     "l64": ("mfma_64x64_dma", 64, 64, 2, False, 0, "MMH_KERNEL_MFMA_64X64_DMA"),   # plain launches only: its forced stream-K launches run three per CU (768 workgroups), a grid the two-per-CU model cannot price and AUTO would not launch
