@@ -91,7 +91,13 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
       }
     }
     double t = (whole ? f.fix_p_whole : f.fix_p) + cmax_p * (nk * f.s_p[occ - 1] + f.tile_p[occ - 1]);
-    if (cmax > f.w && tiles % ((long)f.w * cus) != 0) t *= MMH_POLICY_MULTIROUND_MARGIN;   // a ragged last round
+    if (cmax > f.w && tiles % ((long)f.w * cus) != 0) {   // a ragged last round
+      // ... of between half a tile and one tile per CU: the dispatcher hands those out one per CU, or in pairs to the
+      // CUs whose workgroups ended together -- a whole extra round (the same launch 142 and 110 TFLOP/s in two passes:
+      // tools/policy_fit.py PAIRING); priced at the risk
+      const long rem = tiles % ((long)f.w * cus);
+      t *= (2 * rem > cus && rem <= cus) ? std::max(MMH_POLICY_PAIRING_MARGIN, MMH_POLICY_MULTIROUND_MARGIN) : MMH_POLICY_MULTIROUND_MARGIN;
+    }
     if (best.kernel < 0 || t < best.us) best = Plan{f.kernel, 1, t, 0, f.bm, f.bn};
     if (f.has_sk && (!ctx || ctx->streamk) && !tiles_rim) {
       // the grid launch_streamk will launch: the largest w' <= skw workgroups per CU that leaves every one a whole tile

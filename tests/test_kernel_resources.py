@@ -134,7 +134,7 @@ def test_the_cost_tables_stream_k_residency_is_one_the_binary_allows():
     ring allow for the instantiation that bounds the grid."""
     text = open(os.path.join(REPO, "how-to-optimize-gemm_amd", "csrc", "policy_table.inc")).read()
     fams = re.findall(r"\{(MMH_KERNEL_\w+), (\d+), (\d+), (\d+), (\d+), (\d+),", text)
-    assert len(fams) == 9, fams
+    assert len(fams) == 10, fams
     rows = {r["kernel"]: r for r in _rows()}
     bound = {   # the instantiation launch_*.hip passes as `occ_kern`, and its LDS request in KiB
         "MMH_KERNEL_MFMA_64X64_DMA5": ("sgemm_dma5_streamk_kernel<64,64,32,2,2,3,true,true,2,2,1>", 48),

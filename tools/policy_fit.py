@@ -38,6 +38,10 @@ import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CUS = 256
 THIN = 0.55    # what a round of K2W's thin edge tiles costs, in rounds of whole tiles (N = 1025 against 1024, plain: 26.3 against 18.1 us)
+PAIRING = 1.10   # a plain launch whose last round holds between half a tile and one tile per CU (cus / 2 < tiles mod (w cus) <= cus, more than
+                 # one round): the dispatcher may hand those tiles out one per CU -- or in pairs, to the CUs whose two workgroups ended
+                 # together, and the launch takes a whole extra round (round 6: 4822 x 1268 x 2551 on the 128x64 tile, 760 tiles,
+                 # 142.2 TFLOP/s in one pass and 110.1 in the next; eight such shapes of 500).  Priced at the risk, not the median.
 RIM5 = False     # MMH_OPT_RIM5 (tools build; measured, it loses): the fused rim launch of the 64x64 tile
 # family: (kernel short name, BM, BN, co-resident workgroups per CU of a plain launch, has a stream-K form,
 #          persistent workgroups per CU of its stream-K launches, the kernel id's macro)
@@ -221,7 +225,10 @@ def predict(table, fam, form, m, n, k, cus=CUS):
     g = geometry(fam, m, n, k, cus)
     if form == "plain":
         t = e["fix_p_whole" if g["whole"] else "fix_p"] + g["cmax_p"] * (g["nk"] * e["s_p"][g["occ"] - 1] + e["tile_p"][g["occ"] - 1])
-        return t * table.get("_margin", 1.0) if g["cmax"] > g["w"] and g["tiles"] % (g["w"] * cus) != 0 else t
+        rem = g["tiles"] % (g["w"] * cus)
+        if g["cmax"] > g["w"] and cus / 2 < rem <= cus:
+            return t * max(PAIRING, table.get("_margin", 1.0))
+        return t * table.get("_margin", 1.0) if g["cmax"] > g["w"] and rem != 0 else t
     if not g["sk_possible"] or e["n_s"] == 0:
         return math.inf
     return (e["fix_s_whole" if g["whole"] else "fix_s"][g["wp"] - 1] +
@@ -314,6 +321,7 @@ def emit(table, path, source):
             f.write(f"// {fam}: plain {e['n_p']} rows, rms {e['rms_p']:.3f}; stream-K {e['n_s']} rows, rms {e['rms_s']:.3f}\n")
         f.write(f"#define MMH_POLICY_THIN {THIN:.2f}f   // a round of K2W's thin edge tiles, in rounds of whole tiles (plain launches)\n")
         f.write(f"#define MMH_POLICY_MULTIROUND_MARGIN {table.get('_margin', 1.0):.3f}f   // plain launches of more than one round: p90 of measured / predicted\n")
+        f.write(f"#define MMH_POLICY_PAIRING_MARGIN {PAIRING:.3f}f   // ... whose last round holds between half a tile and one tile per CU: may pair up on half the CUs\n")
         f.write("#define MMH_POLICY_FAMILIES \\\n")
         for fam, e in fams.items():
             kern = FAMILIES[fam][6]
