@@ -197,6 +197,8 @@ int launch_dma5(mmh_context *ctx, int kernel, const GemmArgs &g) {
     case 97: return launch_dma5_tile<128, 64, 4, 2, 3, 4, 2, true, 0>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 98: return launch_dma5_tile<64, 64, 2, 2, 3, 2, 2, true, 0>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
     case 99: return launch_dma5_tile<96, 96, 3, 3, 3, 1, 2, false, 0>(ctx, g) <= 0 ? MMH_OK : MMH_ERR_UNSUPPORTED;
+    // (with the reads spread, the prefetch distance D = 1 / 2 / 3 k-steps measures the same on the 64x64, 96x64 and 128x64
+    // tiles, N = 1024 .. 2048, 3072, 4096: +-0.3 % -- profiles/r06_prefetch_distance_ab.md)
     // (RS = 2, measured and dropped: the slice's barrier BEHIND the k-step's first MFMA, its wait in that instruction's 32
     // cycles of matrix-pipe time -- +-0.2 % on every tile and size: the barrier is not what the loop waits for)
 #endif

@@ -24,7 +24,8 @@ VARIANTS = ["auto", "mfma", "mfma256", "mfma_256x256", "mfma_128x64", "mfma_64x6
             "mfma_64x64_dma5/sk2", "mfma_128x64_dma5/sk2", "mfma_128x128_dma5/sk2",                 # ... stream-K whenever ragged
             "mfma_96x64_dma5", "valu_128x64",                                                     # round 5: the 96x64 K2W tile, K1W's third tile
             "mfma_64x64_dma/sk2", "mfma_128x64_dma/sk2",                                          # ... K2L under stream-K (AUTO's candidates now)
-            "valu_64x64/sk2", "valu_128x64/sk2", "valu_128x128/sk2"]                              # round 6: K1W under K2W's stream-K body
+            "valu_64x64/sk2", "valu_128x64/sk2", "valu_128x128/sk2",                             # round 6: K1W under K2W's stream-K body
+            "mfma_160x160_dma5"]                                                                  # round 6: the 160x160 K2W tile (every K2W tile: fragment reads spread)
 
 
 def strided(rows, cols, ld, off, fill=None):

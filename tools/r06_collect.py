@@ -40,7 +40,8 @@ cp("harness_sharded_1gpu.txt", "r06_harness_sharded_shared_device.txt")
 cp("harness_sharded_rccl1.txt", "r06_harness_sharded_one_rank_rccl.txt")
 cp("prof4096_kernel_stats.csv", "r06_sgemm4096_kernel_stats.csv")
 cp("prof4096_summary.json", "r06_sgemm4096_auto_k2w128x64_rocprofv3.json")
-cp("prof2560_summary.json", "r06_sgemm2560_k2w_streamk128x128_rocprofv3.json")
+cp("prof2560_summary.json", "r06_sgemm2560_k2w160x160_rocprofv3.json")     # (second session: the 160x160 tile; the first session's stream-K profile keeps its name)
+cp("prof3584_summary.json", "r06_sgemm3584_k2w_streamk128x128_rocprofv3.json")
 cp("prof1152_summary.json", "r06_sgemm1152_k2w96x64_rocprofv3.json")
 cp("prof1024_summary.json", "r06_sgemm1024_k2w64x64_rocprofv3.json")
 cp("prof1536_summary.json", "r06_sgemm1536_k2w96x96_rocprofv3.json")

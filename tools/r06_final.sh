@@ -74,7 +74,7 @@ if has bench; then
   cat $OUT/cold_start.txt
 fi
 if has offgrid; then
-  timeout 2600 python tools/offgrid_sweep.py --vendor-harness --set all --variants "auto,mfma_64x64_dma5,mfma_128x64_dma5,mfma_128x128_dma5,mfma_96x96_dma5,mfma_96x64_dma5,mfma_256x256,mfma_64x64_dma,mfma_128x64_dma,mfma_128x128_dma,rocblas,hipblaslt" \
+  timeout 2600 python tools/offgrid_sweep.py --vendor-harness --set all --variants "auto,mfma_64x64_dma5,mfma_128x64_dma5,mfma_128x128_dma5,mfma_96x96_dma5,mfma_96x64_dma5,mfma_160x160_dma5,mfma_256x256,mfma_64x64_dma,mfma_128x64_dma,mfma_128x128_dma,rocblas,hipblaslt" \
     --out $OUT/offgrid > $OUT/offgrid.log 2>&1
   tail -2 $OUT/offgrid.log | cut -c1-200
 fi
@@ -98,7 +98,9 @@ if has prof; then
   TAG=r06z/prof_valu2176 KERNEL=valu BENCH_ARGS="--n 2176" PASSES="trace pmc1" bash tools/gpu_profile.sh > $OUT/prof_valu2176.log 2>&1
   python tools/summarize_profile.py $OUT/prof_valu2176 "sgemm_valu_dma5_streamk_kernel" > $OUT/prof_valu2176_summary.json 2>> $OUT/prof_valu2176.log
   python tools/summarize_profile.py $OUT/prof4096 "sgemm_mfma_dma5_kernel" > $OUT/prof4096_summary.json 2>> $OUT/prof4096.log
-  python tools/summarize_profile.py $OUT/prof2560 "sgemm_dma5_streamk_kernel" > $OUT/prof2560_summary.json 2>> $OUT/prof2560.log
+  python tools/summarize_profile.py $OUT/prof2560 "sgemm_mfma_dma5_kernel" > $OUT/prof2560_summary.json 2>> $OUT/prof2560.log   # (the 160x160 tile, one whole round, since this round)
+  TAG=r06z/prof3584 KERNEL=auto BENCH_ARGS="--n 3584" PASSES="trace pmc1 pmc3 pmc4" bash tools/gpu_profile.sh > $OUT/prof3584.log 2>&1
+  python tools/summarize_profile.py $OUT/prof3584 "sgemm_dma5_streamk_kernel" > $OUT/prof3584_summary.json 2>> $OUT/prof3584.log
   python tools/summarize_profile.py $OUT/prof1152 "sgemm_mfma_dma5_kernel" > $OUT/prof1152_summary.json 2>> $OUT/prof1152.log
   python tools/summarize_profile.py $OUT/prof1024 "sgemm_mfma_dma5_kernel" > $OUT/prof1024_summary.json 2>> $OUT/prof1024.log
   python tools/summarize_profile.py $OUT/prof1536 "sgemm_mfma_dma5_kernel" > $OUT/prof1536_summary.json 2>> $OUT/prof1536.log
@@ -126,7 +128,7 @@ if has misc; then
 fi
 if has regret; then   # the held-out shapes once more with the final table in the library: the `auto` column against the best forced candidate
   TAG=r06z STEPS="dataset" DATASETS="heldout" bash tools/gpu_call.sh > $OUT/regret_pass.log 2>&1
-  python tools/policy_fit.py --fit profiles/r05_policy_dataset_fit.json --heldout $OUT/dataset_heldout.json 2>/dev/null | grep "^held-out" | cut -c1-600
+  python tools/policy_fit.py --fit profiles/r06_policy_dataset_fit.json --heldout $OUT/dataset_heldout.json 2>/dev/null | grep "^held-out" | cut -c1-600
 fi
 if has sktl; then     # where a persistent workgroup's time goes, part by part (timeline build)
   TAG=r06z STEPS="sktl" SKTL_SHAPES="2304,2304,2304 2303,2303,2303 1152,1152,1152 1280,1280,1280" bash tools/gpu_call.sh > $OUT/sktl.log 2>&1
