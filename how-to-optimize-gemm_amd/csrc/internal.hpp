@@ -147,6 +147,7 @@ struct mmh_context {
   int ab_nodefer = 0;          // tools build only (option 102): stream-K heads publish on the spot (no deferred publish)
   int ab_valu_old = 0;         // tools build only (option 105): the K1 ids run the register-staged K1 of rounds 1-4, not K1W
   int ab_own_occ = 0;          // tools build only (option 103): a whole-tile stream-K launch is bounded by ITS OWN instantiation's residency
+  int stagger = 0;             // plain K2W launches whose last round would pair up: the first round's second / third slots start |stagger| x 3.4 us late (< 0: where the rule of launch_dma5.hip wants it; > 0: always; 0: never = the product -- tools build: option 107; measured: +20-29 % on the launches it is for, -14 % on others, profiles/r06_notes.md section 10)
   int ab_group_m = 0;          // tools build only (option 101): raster group height of the plain K2W launch, 0 = GROUP_M
   int persist = 0;             // whole rounds of the persistent grid run persistent too (MMH_OPT_PERSIST)
   int rim = 0;                 // MMH_KERNEL_AUTO trims up to this many rows / columns past a 64-boundary off the tiles (MMH_OPT_RIM; off: measured, it does not pay)

@@ -100,8 +100,21 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
                    : sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, false, NL, D, RS>;
   const int ok = allow_big_lds(kern, T::LDS_BYTES);
   if (ok != MMH_OK) return ok;
+  // first-round stagger (sgemm_mfma_dma5_kernel): when the LAST round has a tile or less per free slot-level to gain --
+  // more than one round, and 0 < tiles mod (w CUs) <= (w - 1) CUs (two co-resident workgroups: a last round of at most one
+  // tile per CU); never on whole rounds (it would leave a ragged end: 96x96 at 3072^3 151 -> 138 TFLOP/s when forced)
+  int stagger = 0;
+  if (ctx && ctx->stagger != 0) {
+    const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    const int w = std::min(resident_per_cu(ctx, kern, T::THREADS, T::LDS_BYTES), 3);
+    const long tiles = (long)nbm * nbn, rem = tiles % ((long)w * cus);
+    const bool wanted = ctx->stagger > 0 ? true : (w >= 2 && tiles > (long)w * cus && rem > 0 && rem <= (long)(w - 1) * cus);
+    const int sleeps = ctx->stagger > 0 ? ctx->stagger : -ctx->stagger;
+    if (wanted && sleeps > 0 && w >= 2 && cus >= 8 && cus < 2048)
+      stagger = (int)(((unsigned)(cus / 8) << 24) | ((unsigned)w << 20) | ((unsigned)(sleeps & 0xf) << 16));
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(T::THREADS), T::LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda, g.B,
-                     g.ldb, g.C, g.ldc, edge ? g.acc : ga.acc, nbm, nbn);
+                     g.ldb, g.C, g.ldc, (edge ? g.acc : ga.acc) | stagger, nbm, nbn);
   HIP_TRY(hipGetLastError());
   snprintf(what, sizeof what,
            "sgemm_mfma_dma5_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by %d loader wave%s' LDS-DMA, fragments %d k-steps "

@@ -106,8 +106,11 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
       for (int c = f.skw; c >= 1; --c)
         if (tiles >= (long)c * cus) { wp = c; break; }
       if (wp > 0 && tiles % ((long)wp * cus) != 0 && tiles <= (1L << 24)) {
-        const double ts = (whole ? f.fix_s_whole[wp - 1] : f.fix_s[wp - 1]) +
-                          (double)tiles / (double)cus * (nk * f.s_s[wp - 1] + f.tile_s[wp - 1]);
+        double ts = (whole ? f.fix_s_whole[wp - 1] : f.fix_s[wp - 1]) +
+                    (double)tiles / (double)cus * (nk * f.s_s[wp - 1] + f.tile_s[wp - 1]);
+        // the K2W 64x64 tile under stream-K: the one candidate whose rate moves 2-5 % from run to run (tools/policy_fit.py
+        // T64SK): priced at the risk
+        if (f.kernel == MMH_KERNEL_MFMA_64X64_DMA5 && wp >= 2) ts *= MMH_POLICY_T64SK_MARGIN;   // (two per CU: from 512 tiles)
         if (ts < best.us) best = Plan{f.kernel, 2, ts, wp, f.bm, f.bn};
       }
     }

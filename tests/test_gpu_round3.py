@@ -460,6 +460,7 @@ def test_the_host_plan_is_what_the_device_launches(mm):
            ("mfma_dma5", "128,64"): "mfma_128x64_dma5", ("dma5_streamk", "128,64"): "mfma_128x64_dma5",
            ("mfma_dma5", "128,128"): "mfma_128x128_dma5", ("dma5_streamk", "128,128"): "mfma_128x128_dma5",
            ("mfma_dma5", "96,96"): "mfma_96x96_dma5", ("mfma_dma5", "96,64"): "mfma_96x64_dma5",
+           ("mfma_dma5", "160,160"): "mfma_160x160_dma5",                                                 # round 6
            ("mfma_dma", "64,64"): "mfma_64x64_dma", ("dma_streamk", "64,64"): "mfma_64x64_dma",           # round 5: K2L is a candidate
            ("mfma_dma", "128,64"): "mfma_128x64_dma", ("dma_streamk", "128,64"): "mfma_128x64_dma",
            ("mfma_dma", "128,128"): "mfma_128x128_dma", ("dma_streamk", "128,128"): "mfma_128x128_dma",

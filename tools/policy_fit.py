@@ -42,6 +42,11 @@ PAIRING = 1.10   # a plain launch whose last round holds between half a tile and
                  # one round): the dispatcher may hand those tiles out one per CU -- or in pairs, to the CUs whose two workgroups ended
                  # together, and the launch takes a whole extra round (round 6: 4822 x 1268 x 2551 on the 128x64 tile, 760 tiles,
                  # 142.2 TFLOP/s in one pass and 110.1 in the next; eight such shapes of 500).  Priced at the risk, not the median.
+T64SK = 1.03     # persistent stream-K launches of the K2W 64x64 tile at two workgroups per CU (from 512 tiles): the one candidate whose rate moves from run to run (3000^3 .. 3500^3,
+                 # N + 1 shapes: 141.9 / 136.8 / 143.8 / 137.7 TFLOP/s in the dataset passes, 139.6 - 141.7 / 133.1 - 135.2 / 138.6 - 141.4 / 133.4 - 134.0
+                 # in five later runs of the same launches, 134.7 - 135.8 / 129.5 - 131.6 / 136.2 - 137.4 / 131.8 - 133.6 inside two off-grid
+                 # passes; every other family repeats within 1 %) -- priced at the risk: with the fitted cost alone AUTO took it on 36 of
+                 # 117 off-grid shapes and lost 5-8 % on a dozen of them (profiles/r06_notes.md section 10)
 RIM5 = False     # MMH_OPT_RIM5 (tools build; measured, it loses): the fused rim launch of the 64x64 tile
 # family: (kernel short name, BM, BN, co-resident workgroups per CU of a plain launch, has a stream-K form,
 #          persistent workgroups per CU of its stream-K launches, the kernel id's macro)
@@ -231,8 +236,8 @@ def predict(table, fam, form, m, n, k, cus=CUS):
         return t * table.get("_margin", 1.0) if g["cmax"] > g["w"] and rem != 0 else t
     if not g["sk_possible"] or e["n_s"] == 0:
         return math.inf
-    return (e["fix_s_whole" if g["whole"] else "fix_s"][g["wp"] - 1] +
-            g["tiles"] / cus * (g["nk"] * e["s_s"][g["wp"] - 1] + e["tile_s"][g["wp"] - 1]))
+    return ((e["fix_s_whole" if g["whole"] else "fix_s"][g["wp"] - 1] +
+             g["tiles"] / cus * (g["nk"] * e["s_s"][g["wp"] - 1] + e["tile_s"][g["wp"] - 1])) * (T64SK if fam == "t64" and g["wp"] >= 2 else 1.0))      # (two persistent workgroups per CU: from 512 tiles)
 
 
 def choose(table, m, n, k, cus=CUS):
@@ -322,6 +327,7 @@ def emit(table, path, source):
         f.write(f"#define MMH_POLICY_THIN {THIN:.2f}f   // a round of K2W's thin edge tiles, in rounds of whole tiles (plain launches)\n")
         f.write(f"#define MMH_POLICY_MULTIROUND_MARGIN {table.get('_margin', 1.0):.3f}f   // plain launches of more than one round: p90 of measured / predicted\n")
         f.write(f"#define MMH_POLICY_PAIRING_MARGIN {PAIRING:.3f}f   // ... whose last round holds between half a tile and one tile per CU: may pair up on half the CUs\n")
+        f.write(f"#define MMH_POLICY_T64SK_MARGIN {T64SK:.3f}f   // stream-K launches of the K2W 64x64 tile: the one candidate whose rate moves from run to run\n")
         f.write("#define MMH_POLICY_FAMILIES \\\n")
         for fam, e in fams.items():
             kern = FAMILIES[fam][6]
