@@ -20,6 +20,11 @@
 //   * D: fragments are read D k-steps ahead of the MFMAs that use them; with one wave per SIMD a ds_read_b32/_b64
 //     stream reaches a fifth of the LDS rate (MI355X_MICROARCH.md, LDS: "from ~4 waves per SIMD"), so the one-
 //     workgroup-per-CU launches want more reads in flight than the co-resident ones.
+//   * RS (round 6): WHERE in the k-step those reads are issued.  Rounds 4-5 issued them as a block in front of the
+//     k-step's MFMAs; a consumer wave alone on its SIMD feeds nothing to the matrix pipe while three to eight LDS
+//     instructions leave (62 cycles per k-step on the 160x160 tile: the "slower loop" that kept it out of the product).
+//     RS = 1: read unit j (an A pair, a B float or the B vector) follows MFMA j, in that instruction's 32 cycles of shadow.
+//     Same slots, same fragments, same bits; +0.4 .. 5 % (profiles/r06_notes.md section 8).  RS = 0: the block form (tools build).
 //
 // Tiles of 32 i x 32 j (round 4: 96x96, 160x160, 160x96 -- the shapes that land N = 1536, 2560, 1920 of the reference
 // sweep on one whole round of CUs).  The A side generalises at once (a fragment is one float per 16-row block).  For
