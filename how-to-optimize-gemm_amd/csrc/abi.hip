@@ -173,9 +173,8 @@ int mmh_set_option(mmh_handle_t h, int option, int value) {
                 // deterministic share per CU where a plain launch's last round is placed greedily (profiles/r06_notes.md section 6)
       h->ab_whole_ranges = value ? 1 : 0;
       return MMH_OK;
-    case 107:   // A/B (round 6): the first-round stagger of plain K2W launches: 0 never, n > 0 always (n x 3.4 us), -n by the launcher's rule (product: 0 -- measured, not shipped)
-      if (value < -16 || value > 16) return MMH_ERR_INVALID_ARG;
-      h->stagger = value;
+    case 107:   // A/B (round 6): the tail split of plain K2W launches (launch_dma5.hip) on (product) / off
+      h->split_tail = value ? 1 : 0;
       return MMH_OK;
     case 105:   // A/B: the vector-ALU rung as it was before round 5 (register-staged K1) instead of K1W
       h->ab_valu_old = value ? 1 : 0;

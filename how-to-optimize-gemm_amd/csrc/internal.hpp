@@ -147,7 +147,7 @@ struct mmh_context {
   int ab_nodefer = 0;          // tools build only (option 102): stream-K heads publish on the spot (no deferred publish)
   int ab_valu_old = 0;         // tools build only (option 105): the K1 ids run the register-staged K1 of rounds 1-4, not K1W
   int ab_own_occ = 0;          // tools build only (option 103): a whole-tile stream-K launch is bounded by ITS OWN instantiation's residency
-  int stagger = 0;             // plain K2W launches whose last round would pair up: the first round's second / third slots start |stagger| x 3.4 us late (< 0: where the rule of launch_dma5.hip wants it; > 0: always; 0: never = the product -- tools build: option 107; measured: +20-29 % on the launches it is for, -14 % on others, profiles/r06_notes.md section 10)
+  int split_tail = 1;          // a plain K2W launch whose last round the dispatcher would pack two per CU goes out as two launches (launch_dma5.hip; tools build: option 107 switches it off)
   int ab_group_m = 0;          // tools build only (option 101): raster group height of the plain K2W launch, 0 = GROUP_M
   int persist = 0;             // whole rounds of the persistent grid run persistent too (MMH_OPT_PERSIST)
   int rim = 0;                 // MMH_KERNEL_AUTO trims up to this many rows / columns past a 64-boundary off the tiles (MMH_OPT_RIM; off: measured, it does not pay)
@@ -237,6 +237,13 @@ bool dma32_shape_ok(const mmh_context *ctx, int kernel, const GemmArgs &g);
 int warm_dma32(mmh_context *ctx, float *scratch, hipStream_t s);
 // The RIM launch of the 64x64 K2W tile (sgemm_dma5.hpp, rim_wave): m and / or n ONE element past a multiple of 64, at
 // least one whole tile each way.  *r_m / *r_n: rim rows / columns (0 or 1).
+// Which plain K2W launches go out as two (launch_dma5.hip, "the tail split"): one whole round of w workgroups per CU and a
+// last round of just under one tile per CU, deep enough in K.  Shared with the cost table (policy.hip).
+inline bool dma5_tail_split(long tiles, long w, long cus, int k) {
+  const long rem = tiles - w * cus;
+  return w >= 2 && k >= 512 && 100 * rem > 85 * cus && rem <= cus;
+}
+
 inline bool dma5_rim_dims(int m, int n, int *r_m, int *r_n) {
   const int rm = m % 64, rn = n % 64;
   const int a = (rm == 1 && m > 64) ? 1 : 0, b = (rn == 1 && n > 64) ? 1 : 0;

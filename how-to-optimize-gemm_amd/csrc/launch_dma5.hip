@@ -29,7 +29,7 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
   const int form = dma5_form<BM, BN, KB>(ctx, g);
   if (form < 0) return 1;
   const bool edge = form == 1;
-  char what[256];
+  char what[320];
 #ifdef MMH_AB_BUILD
   if constexpr (BM == 64 && BN == 64 && NL == 2 && SK) {
     // The RIM launch (tools build: measured slower than the thin edge tiles, sgemm_dma5.hpp rim_wave): one row and / or column past a 64-boundary rides on the trimmed shape's tiles (rim_wave,
@@ -100,26 +100,30 @@ int launch_dma5_tile(mmh_context *ctx, const GemmArgs &g) {
                    : sgemm_mfma_dma5_kernel<BM, BN, KB, WTM, WTN, NBUF, false, NL, D, RS>;
   const int ok = allow_big_lds(kern, T::LDS_BYTES);
   if (ok != MMH_OK) return ok;
-  // first-round stagger (sgemm_mfma_dma5_kernel): when the LAST round has a tile or less per free slot-level to gain --
-  // more than one round, and 0 < tiles mod (w CUs) <= (w - 1) CUs (two co-resident workgroups: a last round of at most one
-  // tile per CU); never on whole rounds (it would leave a ragged end: 96x96 at 3072^3 151 -> 138 TFLOP/s when forced)
-  int stagger = 0;
-  if (ctx && ctx->stagger != 0) {
-    const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-    const int w = std::min(resident_per_cu(ctx, kern, T::THREADS, T::LDS_BYTES), 3);
-    const long tiles = (long)nbm * nbn, rem = tiles % ((long)w * cus);
-    const bool wanted = ctx->stagger > 0 ? true : (w >= 2 && tiles > (long)w * cus && rem > 0 && rem <= (long)(w - 1) * cus);
-    const int sleeps = ctx->stagger > 0 ? ctx->stagger : -ctx->stagger;
-    if (wanted && sleeps > 0 && w >= 2 && cus >= 8 && cus < 2048)
-      stagger = (int)(((unsigned)(cus / 8) << 24) | ((unsigned)w << 20) | ((unsigned)(sleeps & 0xf) << 16));
+  // the tail split (sgemm_mfma_dma5_kernel): ONE whole round and a last round of JUST UNDER one tile per CU -- 0.85 CUs <
+  // tiles - w CUs <= CUs: where the dispatcher was seen to pack (229 .. 256 of 256; a smaller last round spreads by itself,
+  // and after two or more rounds the slots of a CU have drifted apart: splitting then only costs the overlap of the rounds,
+  // -3 .. -15 % when forced) -- and K-slices enough that a second launch is small beside a tile (k >= 512): the last
+  // round goes out as a launch of its own behind the whole one (dma5_tail_split, internal.hpp: the cost table prices it)
+  const long tiles = (long)nbm * nbn;
+  long first = tiles;
+  if (ctx && ctx->split_tail) {
+    const long cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    const long w = std::min(resident_per_cu(ctx, kern, T::THREADS, T::LDS_BYTES), 3);
+    if (dma5_tail_split(tiles, w, cus, g.k) && (w * cus) % 8 == 0) first = w * cus;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * nbn)), dim3(T::THREADS), T::LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda, g.B,
-                     g.ldb, g.C, g.ldc, (edge ? g.acc : ga.acc) | stagger, nbm, nbn);
+  const int acc_bits = edge ? g.acc : ga.acc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)first), dim3(T::THREADS), T::LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda, g.B, g.ldb, g.C,
+                     g.ldc, acc_bits, nbm, nbn);
+  if (first < tiles)
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles - first)), dim3(T::THREADS), T::LDS_BYTES, g.s, g.m, g.n, g.k, g.A, g.lda, g.B,
+                       g.ldb, g.C, g.ldc, acc_bits | (int)((unsigned)(first >> 3) << 16), nbm, nbn);
   HIP_TRY(hipGetLastError());
   snprintf(what, sizeof what,
            "sgemm_mfma_dma5_kernel<%d,%d> wave tile %dx%d, K-slice %d x %d ring buffers by %d loader wave%s' LDS-DMA, fragments %d k-steps "
-           "ahead, %s%d workgroups of %d threads",
-           BM, BN, 16 * WTM, 16 * WTN, KB, NBUF, NL, NL > 1 ? "s" : "", D, edge ? "guarded, " : "", nbm * nbn, T::THREADS);
+           "ahead, %s%d workgroups of %d threads%s",
+           BM, BN, 16 * WTM, 16 * WTN, KB, NBUF, NL, NL > 1 ? "s" : "", D, edge ? "guarded, " : "", nbm * nbn, T::THREADS,
+           first < tiles ? " (the last round as a launch of its own)" : "");
   set_last_launch(what);
   return MMH_OK;
 }

@@ -95,8 +95,10 @@ Plan auto_plan_for(const mmh_context *ctx, const GemmArgs &g) {
       // ... of between half a tile and one tile per CU: the dispatcher hands those out one per CU, or in pairs to the
       // CUs whose workgroups ended together -- a whole extra round (the same launch 142 and 110 TFLOP/s in two passes:
       // tools/policy_fit.py PAIRING); priced at the risk
+      // (the launches launch_dma5.hip splits -- one round and a last round of just under a tile per CU -- are out of that class)
       const long rem = tiles % ((long)f.w * cus);
-      t *= (2 * rem > cus && rem <= cus) ? std::max(MMH_POLICY_PAIRING_MARGIN, MMH_POLICY_MULTIROUND_MARGIN) : MMH_POLICY_MULTIROUND_MARGIN;
+      const bool split = is_k2w(f.kernel) && (!ctx || ctx->split_tail) && dma5_tail_split(tiles, f.w, cus, g.k);
+      t *= (2 * rem > cus && rem <= cus && !split) ? std::max(MMH_POLICY_PAIRING_MARGIN, MMH_POLICY_MULTIROUND_MARGIN) : MMH_POLICY_MULTIROUND_MARGIN;
     }
     if (best.kernel < 0 || t < best.us) best = Plan{f.kernel, 1, t, 0, f.bm, f.bn};
     if (f.has_sk && (!ctx || ctx->streamk) && !tiles_rim) {

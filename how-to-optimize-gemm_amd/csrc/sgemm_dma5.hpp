@@ -703,31 +703,23 @@ sgemm_mfma_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda
   // dimensions only behind the branch to the loader path, a second scalar-memory round trip in front of the first DMA)
   asm volatile("" ::"s"(A), "s"(B), "s"(C), "s"(lda), "s"(ldb), "s"(ldc), "s"(k));
   dma_stamp(0);
-  {
-    // STAGGER (bits 16-19 of `accumulate`: sleeps, bits 20-23: workgroups per CU, bits 24-31: CUs / 8; 0 = off:
-    // launch_dma5.hip decides).  The dispatcher hands a
-    // launch's first workgroups out one per CU -- ids 0 .. CUs - 1 --, then the second slot of every CU, then the third; they
-    // start together and, the kernels being what they are, the ones that share a CU END together: all slots of a CU are
-    // refilled at once, and a last round of fewer tiles than free slots lands two (three) per CU on a part of the chip
-    // instead of one per CU -- a whole extra round (4822 x 1268 x 2551, 760 tiles of 128x64: 110 TFLOP/s, 143 with one per
-    // CU; 2048^3 on 1024 tiles of 64x64: 120 / 148).  With the first round's SECOND slots starting `sleeps` x 3.4 us late
-    // (the third: twice that) the slots of a CU stay out of step for the rest of the launch and free up one at a time.
-    // Patterns that delay every other id, or every other group of eight, do nothing: it is the id / CUs that names the slot.
-    const unsigned stg = (unsigned)accumulate >> 16;
-    accumulate &= 0xffff;
-    if (stg) {
-      const int sleeps = (int)(stg & 0xf), w = (int)((stg >> 4) & 0xf), cus = (int)(stg >> 8) * 8;
-      const int slot = (int)blockIdx.x / cus;   // (first round only: the later workgroups start when a slot frees up)
-      if (slot >= 1 && slot < w)
-        for (int i = 0; i < sleeps * slot; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
+  // TAIL SPLIT (bits 16-31 of `accumulate`: the id of this launch's first workgroup, / 8; launch_dma5.hip decides).  The
+  // dispatcher hands a launch's first workgroups out one per CU -- ids 0 .. CUs - 1 --, then the second slot of every CU, then
+  // the third; they start together and, the kernels being what they are, the ones that share a CU END together: all slots of
+  // a CU are refilled at once, and a last round of fewer tiles than CUs lands two (three) per CU on a part of the chip instead
+  // of one per CU -- a whole extra round (4822 x 1268 x 2551, 760 tiles of 128x64: 110 TFLOP/s, 143 with one per CU).  Such a
+  // launch goes out as TWO: the whole rounds, then the last round as a launch of its own -- whose workgroups are "first
+  // workgroups" again, one per CU -- continuing the first one's ids.  (Round 6 first proved the diagnosis with a stagger of the
+  // first round's second slots: +20-29 % where it held, but a tile-dependent delay and -14 % elsewhere;
+  // profiles/r06_first_round_stagger_ab.md.)
+  const unsigned bid = blockIdx.x + (((unsigned)accumulate >> 16) << 3);
+  accumulate &= 0xffff;
   if constexpr (EDGE) {
     const int thin_row = (nbm > 1 && m - (nbm - 1) * BM <= 16) ? 1 : 0, thin_col = (nbn > 1 && n - (nbn - 1) * BN <= 16) ? 1 : 0;
     const int nbm_f = nbm - thin_row, nbn_f = nbn - thin_col, n_full = nbm_f * nbn_f;
-    int r = (int)blockIdx.x - n_full;
+    int r = (int)bid - n_full;
     if (r < 0) {
-      block_to_tile_g(blockIdx.x, n_full, nbm_f, nbn_f, Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>::GM, tm, tn);
+      block_to_tile_g(bid, n_full, nbm_f, nbn_f, Dma5Tile<BM, BN, KB, WTM, WTN, NBUF, NL>::GM, tm, tn);
     } else if (thin_col && r < nbm) {   // the thin column, top to bottom (its corner with a thin row included)
       tm = r;
       tn = nbn - 1;
@@ -743,7 +735,7 @@ sgemm_mfma_dma5_kernel(int m, int n, int k, const float *__restrict__ A, int lda
       accumulate &= 1;
       if (ab_gm > 0) gm = ab_gm;
     }
-    block_to_tile_g(blockIdx.x, nbm * nbn, nbm, nbn, gm, tm, tn);
+    block_to_tile_g(bid, nbm * nbn, nbm, nbn, gm, tm, tn);
   }
   typename S::Lane L;
   L.init(lda, ldb);

@@ -70,6 +70,12 @@ FAMILIES = {
 }
 
 
+def tail_split(tiles, w, cus, k):
+    """csrc/internal.hpp dma5_tail_split: the plain K2W launches that go out as one whole round + the last round as a launch of its own."""
+    rem = tiles - w * cus
+    return w >= 2 and k >= 512 and 100 * rem > 85 * cus and rem <= cus
+
+
 def rim_dims(m, n):
     """csrc/internal.hpp dma5_rim_dims: rim rows / columns of the 64x64 tile's RIM launch (0, 0: none)."""
     rm, rn = m % 64, n % 64
@@ -231,7 +237,8 @@ def predict(table, fam, form, m, n, k, cus=CUS):
     if form == "plain":
         t = e["fix_p_whole" if g["whole"] else "fix_p"] + g["cmax_p"] * (g["nk"] * e["s_p"][g["occ"] - 1] + e["tile_p"][g["occ"] - 1])
         rem = g["tiles"] % (g["w"] * cus)
-        if g["cmax"] > g["w"] and cus / 2 < rem <= cus:
+        split = FAMILIES[fam][0].endswith("_dma5") and tail_split(g["tiles"], g["w"], cus, k)      # (those go out as two launches: not of the class)
+        if g["cmax"] > g["w"] and cus / 2 < rem <= cus and not split:
             return t * max(PAIRING, table.get("_margin", 1.0))
         return t * table.get("_margin", 1.0) if g["cmax"] > g["w"] and rem != 0 else t
     if not g["sk_possible"] or e["n_s"] == 0:

@@ -79,8 +79,7 @@ def main():
             mm.set_option(100, 0 if "np" in parts[1:] else 1)   # /np: persistent launches ask for their own LDS only (no 160 KiB / w pin)
             mm.set_option(105, 1 if "k1old" in parts[1:] else 0)   # /k1old: the register-staged K1 of rounds 1-4
             mm.set_option(106, 1 if "wr" in parts[1:] else 0)      # /wr: persistent launches with whole-tile ranges (round 6)
-            st = [x for x in parts[1:] if x.startswith("st") and x[2:].lstrip("m").isdigit()]   # /stN: first-round stagger of plain K2W launches always (N x 3.4 us), /stmN: by the launcher's rule (launch_dma5.hip); default and /st0: never (the product)
-            mm.set_option(107, (-int(st[0][3:]) if st[0][2] == "m" else int(st[0][2:])) if st else 0)
+            mm.set_option(107, 0 if "ns" in parts[1:] else 1)     # /ns: no tail split of plain K2W launches (the last round in the same launch: rounds 4-6)
             om = [x for x in parts[1:] if x.startswith("om") and x[2:].isdigit()]   # /omNN: phase-ordered tables from NN/10 tiles per workgroup
             mm.set_option(104, int(om[0][2:]) if om else 18)
 
