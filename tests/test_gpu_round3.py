@@ -276,6 +276,7 @@ def test_a_capture_never_borrows_another_streams_workspaces(oracle):
         for rep in range(4):                             # replays on `side` beside eager launches on the current stream
             c.fill_(float("nan"))
             c2.fill_(float("nan"))
+            side.wait_stream(torch.cuda.current_stream())   # (the fills run on the current stream; the replay must not race them)
             with torch.cuda.stream(side):
                 graph.replay()
             h.matmul(da, db, out=c2)
@@ -448,6 +449,35 @@ def test_single_device_shard_through_a_one_rank_rccl_communicator():
     broadcast B on it: rccl_ranks == 1, the broadcast phase takes time, the result is the single-GPU chain's bits."""
     r = subprocess.run([sys.executable, "-c", _SHARD_RCCL1, REPO], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "shard-rccl1 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_a_packed_last_round_goes_out_as_a_launch_of_its_own(mm):
+    """launch_dma5.hip, the tail split (round 6): one whole round of w workgroups per CU plus a last round of 0.85 .. 1 tile per
+    CU (k >= 512) is two launches -- same bits -- and nothing else is.  The co-residency w the launcher reads off the binary
+    must be the one csrc/policy_table.inc prices with (3 / 2 / 2 / 2 for the 64x64 / 128x64 / 96x96 / 96x64 tiles)."""
+    import torch
+    import how_to_optimize_gemm_amd as H
+    note = "the last round as a launch of its own"
+    cases = [("mfma_128x64_dma5", (4822, 1268, 2551), True), ("mfma_96x96_dma5", (1539, 4288, 747), True),
+             ("mfma_96x64_dma5", (7125, 628, 2092), True), ("mfma_64x64_dma5", (1017, 4064, 4263), True),
+             ("mfma_128x64_dma5", (4096, 4096, 512), False),      # whole rounds
+             ("mfma_128x64_dma5", (4822, 1268, 256), False),      # too shallow
+             ("mfma_96x64_dma5", (1539, 4288, 747), False),       # two whole rounds and 115 tiles
+             ("mfma_128x128_dma5", (4822, 1268, 2551), False)]    # one workgroup per CU
+    mm.set_streamk(0)
+    try:
+        for kern, (m, n, k), split in cases:
+            a = torch.rand((m, k), device="cuda") * 2 - 1
+            b = torch.rand((k, n), device="cuda") * 2 - 1
+            mm.set_kernel(kern)
+            c = mm.matmul(a, b)
+            assert (note in H.last_launch()) == split, (kern, m, n, k, H.last_launch())
+            if split:
+                mm.set_kernel("mfma_128x128_dma5")
+                assert torch.equal(c, mm.matmul(a, b)), (kern, m, n, k)
+    finally:
+        mm.set_streamk(1)
+        mm.set_kernel("auto")
 
 
 def test_the_host_plan_is_what_the_device_launches(mm):

@@ -212,6 +212,7 @@ def test_reserve_stream_covers_a_forced_register_staged_tile(oracle, kernel):
                 h.matmul(da, db, out=c)                # (refused with MMH_ERR_UNSUPPORTED before round 5)
         for rep in range(3):
             c.fill_(float("nan"))
+            side.wait_stream(torch.cuda.current_stream())   # (the fill runs on the current stream: without this the replay on `side` races it -- seen once in ~2 500 runs)
             with torch.cuda.stream(side):
                 graph.replay()
             torch.cuda.synchronize()
